@@ -1,0 +1,174 @@
+/* ofdis.h -- C ABI of the MI355X-native OF_DIS hot path (libofdis_hip.so).
+ *
+ * The reference has exactly one API: the constructor of OFC::OFClass
+ * (reference oflow.h:84-111, definition oflow.cpp:32-363, sole call site run_dense.cpp:391-400).
+ * Everything happens inside that constructor; nothing is retained afterwards.  ofdis_flow() below
+ * is that constructor as a C function (same argument meaning, same buffers, same output), and
+ * ofdis_batch_* is the same computation over many independent frame pairs resident in HBM, which
+ * is how a GPU reaches throughput on problems this small.
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Device pointers are HIP device pointers,
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *
+ * Arithmetic contract: fp32 throughout, every operation separately rounded (no FMA contraction),
+ * IEEE divide/sqrt, same operation order as the reference's SSE path; vector reductions use the
+ * 64-lane butterfly order documented in DESIGN.md ("reduction order").  The result is bit-identical
+ * to the reference sources compiled against oracle/eigen_shim with -DOFDIS_SHIM_WAVE64.
+ */
+#ifndef OFDIS_H_
+#define OFDIS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFDIS_VERSION 1
+
+/* status codes (the reference reports nothing and has UB on bad input; we return a status) */
+enum {
+  OFDIS_OK = 0,
+  OFDIS_ERR_INVALID = -1,      /* bad argument / unsupported parameter combination */
+  OFDIS_ERR_UNSUPPORTED = -2,  /* valid in the reference but outside this path */
+  OFDIS_ERR_DEVICE = -3,       /* HIP runtime error (ofdis_last_error() has the text) */
+  OFDIS_ERR_NOMEM = -4
+};
+
+/* The run-time parameters of OFC::OFClass::OFClass, in the constructor's order
+ * (oflow.h:91-111; parsed at oflow.cpp:76-108).  `noc` is a run-time value here instead of the
+ * reference's per-binary SELECTCHANNEL. */
+typedef struct ofdis_params {
+  int   width, height;      /* size of level 0 (already padded to a multiple of 2^sc_f), oflow.h:92 */
+  int   imgpadding;         /* border of every pyramid plane, == p_samp_s at the call site (run_dense.cpp:393) */
+  int   sc_f, sc_l;         /* coarsest / finest pyramid level used */
+  int   max_iter, min_iter;
+  float dp_thresh, dr_thresh, res_thresh;
+  int   p_samp_s;           /* patch edge length P */
+  float patove;             /* patch overlap in [0,1) */
+  int   usefbcon;           /* forward-backward merging: must be 0 */
+  int   costfct;            /* 0 L2, 1 L1, 2 pseudo-Huber (patch.cpp:230-261) */
+  int   noc;                /* channels: 1 (run_OF_INT) or 3 (run_OF_RGB) */
+  int   patnorm;            /* subtract patch mean */
+  int   usetvref;           /* TV-L1 variational refinement on/off */
+  float tv_alpha, tv_gamma, tv_delta;
+  int   tv_innerit, tv_solverit;
+  float tv_sor;
+  int   verbosity;          /* 0 silent, 1 total time, 2 per-level TIME lines (oflow.cpp:179,303,359) */
+} ofdis_params;
+
+/* Fill `p` with the reference's operating point 1..4 for an image of `width_org` columns
+ * (run_dense.cpp:225-265, AutoFirstScaleSelect run_dense.cpp:180-183).  width/height/imgpadding are
+ * set by the caller after padding.  Returns OFDIS_OK or OFDIS_ERR_INVALID. */
+int ofdis_params_oppoint(ofdis_params* p, int op_point, int width_org, int noc);
+
+const char* ofdis_last_error(void);
+int ofdis_version(void);
+/* number of HIP devices visible / select one (one process per GPU: call once at start) */
+int ofdis_device_count(void);
+int ofdis_set_device(int device);
+
+/* ---------------------------------------------------------------------------------------------
+ * Drop-in for the constructor: host pointers in, host flow out, synchronous.
+ * Replaces: OFC::OFClass::OFClass(...) oflow.h:84-111 / run_dense.cpp:391-400.
+ * im_*: arrays of sc_f+1 host pointers; entries sc_l..sc_f must be valid (oflow.h:85-87).  Each
+ * plane is row-major fp32, (w/2^l + 2*imgpadding) x (h/2^l + 2*imgpadding) x noc, channel
+ * interleaved, images replicate-padded, gradients zero-padded (run_dense.cpp:166-175).
+ * im_b_dx / im_b_dy may be NULL (never read when usefbcon == 0).
+ * outflow: 2*(w>>sc_l)*(h>>sc_l) floats, AoS (u,v), fully overwritten.
+ * initflow: optional (w>>(sc_f+1))*(h>>(sc_f+1))*2 floats or NULL (oflow.cpp:217-220).
+ * ------------------------------------------------------------------------------------------- */
+int ofdis_flow(const ofdis_params* p,
+               const float* const* im_a, const float* const* im_a_dx, const float* const* im_a_dy,
+               const float* const* im_b, const float* const* im_b_dx, const float* const* im_b_dy,
+               float* outflow, const float* initflow);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched, device-resident form (the throughput path).
+ * A batch context owns every intermediate buffer for `nframes` frame pairs of one geometry.
+ * Pyramid layout in HBM, per level l in [sc_l, sc_f], one array per plane kind:
+ *     float plane[nframes][tmp_h_l][tmp_w_l][noc]    tmp_* = level size + 2*imgpadding
+ * i.e. the reference's per-level plane, frame-major.  Output: float flow[nframes][h_l][w_l][2]
+ * at l = sc_l.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ofdis_batch ofdis_batch;
+
+int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes);
+void ofdis_batch_destroy(ofdis_batch* b);
+
+/* device pointers to the context-owned input planes of level l: kind 0 = image A, 1 = A_dx,
+ * 2 = A_dy, 3 = image B.  The caller fills them (hipMemcpy, its own kernels, ofdis_batch_upload
+ * or ofdis_batch_build_pyramids_u8). */
+float* ofdis_batch_input(ofdis_batch* b, int level, int kind);
+size_t ofdis_batch_input_elems(const ofdis_batch* b, int level); /* floats per frame per plane */
+/* copy one frame's host pyramid (the ofdis_flow() layout) into slot `frame` */
+int ofdis_batch_upload(ofdis_batch* b, int frame, const float* const* im_a, const float* const* im_a_dx,
+                       const float* const* im_a_dy, const float* const* im_b, void* stream);
+/* build all input planes of levels sc_l..sc_f on the device from raw 8-bit frames
+ * (run_dense.cpp:130-178,298-311,326-344 restated on device): img_a/img_b are device pointers to
+ * [nframes][height_org][width_org][noc] uint8; padding to params.width x params.height is applied
+ * as the reference does (replicate, floor/ceil split). */
+int ofdis_batch_build_pyramids_u8(ofdis_batch* b, const uint8_t* img_a, const uint8_t* img_b, int width_org,
+                                  int height_org, void* stream);
+
+/* enqueue the whole hot path (all levels, DIS + densify + TV) for all frames on `stream` */
+int ofdis_batch_run(ofdis_batch* b, void* stream);
+/* device pointer to the result, [nframes][h>>sc_l][w>>sc_l][2] */
+const float* ofdis_batch_flow(const ofdis_batch* b);
+/* device pointer to the dense flow of an intermediate level (for per-level parity tests) */
+const float* ofdis_batch_level_flow(const ofdis_batch* b, int level);
+int ofdis_batch_download(ofdis_batch* b, int frame, float* outflow_host, void* stream);
+
+/* Kernel timing for the roofline report: when enabled, ofdis_batch_run brackets every launch of
+ * the named kernel class with hipEvents on `stream`; ofdis_batch_kernel_time returns the summed
+ * milliseconds and launch count since the last reset (synchronises the events). */
+enum { OFDIS_K_WARP = 0, OFDIS_K_DERIV = 1, OFDIS_K_SYSTEM = 2, OFDIS_K_SOR = 3, OFDIS_K_PATCH = 4,
+       OFDIS_K_DENSIFY = 5, OFDIS_K_UPDATE = 6, OFDIS_K_COUNT = 7 };
+int ofdis_batch_timing(ofdis_batch* b, int enable);
+int ofdis_batch_kernel_time(ofdis_batch* b, int kernel_class, double* ms_sum, long* launches);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-function entry points (device pointers, batched over `nframes` frames, packed planes
+ * [nframes][h][w]).  Each replaces one FDF1.0.1 / PatGrid function; used by the parity tests and
+ * available to a maintainer who wants to swap a single stage.
+ * ------------------------------------------------------------------------------------------- */
+/* image_warp, opticalflow_aux.c:18-60.  src/dst: [nframes][noc][h][w]; wx, wy, mask: [nframes][h][w] */
+int ofdis_image_warp(float* dst, float* mask, const float* src, const float* wx, const float* wy,
+                     int w, int h, int noc, int nframes, void* stream);
+/* get_derivatives, opticalflow_aux.c:65-116.  out: [nframes][8][noc][h][w] in the order
+ * Ix,Iy,Iz,Ixx,Ixy,Iyy,Ixz,Iyz */
+int ofdis_get_derivatives(float* out, const float* im1, const float* im2w, int w, int h, int noc,
+                          int nframes, void* stream);
+/* compute_smoothness + compute_data + 2x sub_laplacian fused (opticalflow_aux.c:123-199,310-438):
+ * out: [nframes][7][h][w] = a11,a12,a22,b1,b2,smooth_horiz,smooth_vert */
+int ofdis_tv_system(float* out, const float* mask, const float* wx, const float* wy, const float* du,
+                    const float* dv, const float* derivs, float tv_alpha, float tv_gamma, float tv_delta,
+                    int w, int h, int noc, int nframes, void* stream);
+/* sor_coupled, solver.c:77-421: `iterations` lexicographic block-SOR sweeps; du, dv in place.
+ * sys: the [nframes][7][h][w] array of ofdis_tv_system (not modified; the reference's in-place
+ * block inverse, solver.c:113-120, lives in registers). */
+int ofdis_sor_coupled(float* du, float* dv, const float* sys, int iterations, float omega, int w, int h,
+                      int nframes, void* stream);
+/* one pyramid level of PatGridClass::{InitializeGrid,SetTargetImage,InitializeFromCoarserOF,
+ * Optimize} + AggregateFlowDense (patchgrid.cpp:98-141,195-275,377-397).
+ * im_*: [nframes][tmp_h][tmp_w][noc]; flow_prev: [nframes][h/2][w/2][2] or NULL;
+ * p_out: [nframes][nopatches][2] or NULL; flow_out: [nframes][h][w][2] */
+int ofdis_patchgrid_level(const ofdis_params* p, int level, const float* im_a, const float* im_a_dx,
+                          const float* im_a_dy, const float* im_b, const float* flow_prev, float* p_out,
+                          float* flow_out, int nframes, void* stream);
+/* one pyramid level of VarRefClass (refine_variational.cpp:25-241); flow [nframes][h][w][2] in place */
+int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, const float* im_b, float* flow,
+                       int nframes, void* stream);
+
+/* plain device memory helpers so that C callers need no HIP headers */
+void* ofdis_dev_alloc(size_t bytes);
+void ofdis_dev_free(void* p);
+int ofdis_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int ofdis_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int ofdis_sync(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFDIS_H_ */
