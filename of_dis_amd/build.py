@@ -1,0 +1,86 @@
+"""Build the product: libofdis_hip.so (HIP kernels + C ABI, gfx950) and the run_OF_* executables.
+
+    python -m of_dis_amd.build          # incremental
+    python -m of_dis_amd.build --force
+
+Everything is compiled in-tree (of_dis_amd/lib/) so that the built .so travels with the repo
+snapshot to the GPU box.  hipcc cross-compiles gfx950 without a GPU.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+ROOT = os.path.dirname(HERE)
+
+HIP_SOURCES = ["ofdis_dis.hip", "ofdis_tv.hip", "ofdis_sor.hip", "ofdis_pyr.hip", "ofdis_capi.hip"]
+# -ffp-contract=off: every fp32 operation separately rounded, like the reference's SSE path.
+HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+            "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    if verbose and (r.stdout or r.stderr):
+        print(r.stdout + r.stderr)
+
+
+def lib_path():
+    return os.path.join(LIBDIR, "libofdis_hip.so")
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "ofdis.h"))
+    objs = []
+    for src in HIP_SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        if force or _newer(obj, [sp] + headers):
+            _run([hipcc] + HIPFLAGS + ["-c", sp, "-o", obj], verbose)
+        objs.append(obj)
+    so = lib_path()
+    if force or _newer(so, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs, verbose)
+    # host executables (reference CLI contract: run_OF_INT / run_OF_RGB)
+    host_dir = os.path.join(CSRC, "host")
+    main_cpp = os.path.join(host_dir, "run_dense_main.cpp")
+    if os.path.exists(main_cpp):
+        host_srcs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".cpp")]
+        host_hdrs = [os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".h")]
+        for name, noc in (("run_OF_INT", 1), ("run_OF_RGB", 3)):
+            exe = os.path.join(LIBDIR, name)
+            if force or _newer(exe, host_srcs + host_hdrs + headers + [so]):
+                _run(["g++", "-O2", "-std=c++17", "-Wall", f"-DOFDIS_NOC={noc}", "-I", os.path.join(ROOT, "include")]
+                     + host_srcs + ["-o", exe, "-L", LIBDIR, "-lofdis_hip", "-lz", "-Wl,-rpath,$ORIGIN"], verbose)
+    return so
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, verbose=True)
+    print("built", p)

@@ -1,0 +1,298 @@
+"""ctypes binding of the C ABI (include/ofdis.h) -- the only way Python reaches the product.
+
+There is no CPU fallback: `lib()` raises if of_dis_amd/lib/libofdis_hip.so is missing, and every
+call raises OfdisError on a non-zero status.  numpy helpers move data through the library's own
+device-memory helpers so that the tests need nothing but the shared library; the benchmark passes
+torch device pointers straight through.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .params import OfdisParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libofdis_hip.so")
+_f32 = np.float32
+FP = C.POINTER(C.c_float)
+VP = C.c_void_p
+
+K_WARP, K_DERIV, K_SYSTEM, K_SOR, K_PATCH, K_DENSIFY, K_UPDATE, K_COUNT = range(8)
+K_NAMES = ["warp", "derivatives", "tv_system", "sor", "patch_optimize", "densify", "tv_finish"]
+
+# every symbol include/ofdis.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "ofdis_params_oppoint", "ofdis_last_error", "ofdis_version", "ofdis_device_count", "ofdis_set_device",
+    "ofdis_flow", "ofdis_batch_create", "ofdis_batch_destroy", "ofdis_batch_input", "ofdis_batch_input_elems",
+    "ofdis_batch_upload", "ofdis_batch_build_pyramids_u8", "ofdis_batch_run", "ofdis_batch_flow",
+    "ofdis_batch_level_flow", "ofdis_batch_download", "ofdis_batch_timing", "ofdis_batch_kernel_time",
+    "ofdis_image_warp", "ofdis_get_derivatives", "ofdis_tv_system", "ofdis_sor_coupled", "ofdis_patchgrid_level",
+    "ofdis_varref_level", "ofdis_dev_alloc", "ofdis_dev_free", "ofdis_memcpy_h2d", "ofdis_memcpy_d2h", "ofdis_sync",
+]
+
+
+class OfdisError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libofdis_hip.so (built by of_dis_amd.build).  Fails loudly when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OfdisError(f"{LIB_PATH} is missing: run `python -m of_dis_amd.build` (no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        L.ofdis_last_error.restype = C.c_char_p
+        L.ofdis_dev_alloc.restype = VP
+        L.ofdis_dev_alloc.argtypes = [C.c_size_t]
+        L.ofdis_dev_free.argtypes = [VP]
+        L.ofdis_memcpy_h2d.argtypes = [VP, VP, C.c_size_t]
+        L.ofdis_memcpy_d2h.argtypes = [VP, VP, C.c_size_t]
+        L.ofdis_sync.argtypes = [VP]
+        L.ofdis_batch_create.argtypes = [C.POINTER(VP), C.POINTER(OfdisParams), C.c_int]
+        L.ofdis_batch_destroy.argtypes = [VP]
+        L.ofdis_batch_input.restype = VP
+        L.ofdis_batch_input.argtypes = [VP, C.c_int, C.c_int]
+        L.ofdis_batch_input_elems.restype = C.c_size_t
+        L.ofdis_batch_input_elems.argtypes = [VP, C.c_int]
+        L.ofdis_batch_upload.argtypes = [VP, C.c_int, C.POINTER(FP), C.POINTER(FP), C.POINTER(FP), C.POINTER(FP), VP]
+        L.ofdis_batch_build_pyramids_u8.argtypes = [VP, VP, VP, C.c_int, C.c_int, VP]
+        L.ofdis_batch_run.argtypes = [VP, VP]
+        L.ofdis_batch_flow.restype = VP
+        L.ofdis_batch_flow.argtypes = [VP]
+        L.ofdis_batch_level_flow.restype = VP
+        L.ofdis_batch_level_flow.argtypes = [VP, C.c_int]
+        L.ofdis_batch_download.argtypes = [VP, C.c_int, FP, VP]
+        L.ofdis_batch_timing.argtypes = [VP, C.c_int]
+        L.ofdis_batch_kernel_time.argtypes = [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+        L.ofdis_image_warp.argtypes = [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]
+        L.ofdis_get_derivatives.argtypes = [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]
+        L.ofdis_tv_system.argtypes = [VP, VP, VP, VP, VP, VP, VP, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, VP]
+        L.ofdis_sor_coupled.argtypes = [VP, VP, VP, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, VP]
+        L.ofdis_patchgrid_level.argtypes = [C.POINTER(OfdisParams), C.c_int, VP, VP, VP, VP, VP, VP, VP, C.c_int, VP]
+        L.ofdis_varref_level.argtypes = [C.POINTER(OfdisParams), C.c_int, VP, VP, VP, C.c_int, VP]
+        L.ofdis_flow.argtypes = [C.POINTER(OfdisParams)] + [C.POINTER(FP)] * 6 + [FP, FP]
+        L.ofdis_params_oppoint.argtypes = [C.POINTER(OfdisParams), C.c_int, C.c_int, C.c_int]
+        L.ofdis_test_wave_sum.argtypes = [VP, VP, C.c_int, VP]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise OfdisError(f"ofdis status {rc}: {lib().ofdis_last_error().decode()}")
+
+
+class Dev:
+    """A device buffer owned through ofdis_dev_alloc / ofdis_dev_free."""
+
+    def __init__(self, arr=None, nbytes=None):
+        L = lib()
+        if arr is not None:
+            arr = np.ascontiguousarray(arr)
+            nbytes = arr.nbytes
+        self.nbytes = int(nbytes)
+        self.ptr = L.ofdis_dev_alloc(self.nbytes)
+        if not self.ptr:
+            raise OfdisError("device allocation failed")
+        if arr is not None:
+            check(L.ofdis_memcpy_h2d(self.ptr, arr.ctypes.data, self.nbytes))
+
+    def get(self, shape, dtype=_f32):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib().ofdis_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().ofdis_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=_f32)
+
+
+# ------------------------------------------------------------------ per-function entry points (numpy in/out)
+def image_warp(src, wx, wy):
+    """src [B,noc,h,w], wx/wy [B,h,w] -> dst [B,noc,h,w], mask [B,h,w]"""
+    src, wx, wy = _f(src), _f(wx), _f(wy)
+    B, noc, h, w = src.shape
+    dsrc, dwx, dwy = Dev(src), Dev(wx), Dev(wy)
+    ddst, dmask = Dev(nbytes=src.nbytes), Dev(nbytes=wx.nbytes)
+    check(lib().ofdis_image_warp(ddst.ptr, dmask.ptr, dsrc.ptr, dwx.ptr, dwy.ptr, w, h, noc, B, None))
+    check(lib().ofdis_sync(None))
+    return ddst.get(src.shape), dmask.get(wx.shape)
+
+
+def get_derivatives(im1, im2w):
+    """im1, im2w [B,noc,h,w] -> [B,8,noc,h,w]"""
+    im1, im2w = _f(im1), _f(im2w)
+    B, noc, h, w = im1.shape
+    d1, d2 = Dev(im1), Dev(im2w)
+    dout = Dev(nbytes=im1.nbytes * 8)
+    check(lib().ofdis_get_derivatives(dout.ptr, d1.ptr, d2.ptr, w, h, noc, B, None))
+    check(lib().ofdis_sync(None))
+    return dout.get((B, 8, noc, h, w))
+
+
+def tv_system(mask, wx, wy, du, dv, derivs, tv_alpha, tv_gamma, tv_delta):
+    """-> [B,7,h,w] = a11,a12,a22,b1,b2,smooth_horiz,smooth_vert"""
+    mask, wx, wy, du, dv, derivs = [_f(x) for x in (mask, wx, wy, du, dv, derivs)]
+    B, h, w = mask.shape
+    noc = derivs.shape[2]
+    bufs = [Dev(x) for x in (mask, wx, wy, du, dv, derivs)]
+    dout = Dev(nbytes=mask.nbytes * 7)
+    check(lib().ofdis_tv_system(dout.ptr, *[b.ptr for b in bufs], tv_alpha, tv_gamma, tv_delta, w, h, noc, B, None))
+    check(lib().ofdis_sync(None))
+    return dout.get((B, 7, h, w))
+
+
+def sor_coupled(du, dv, sys, iterations, omega):
+    """du, dv [B,h,w]; sys [B,7,h,w] -> new du, dv"""
+    du, dv, sys = _f(du), _f(dv), _f(sys)
+    B, h, w = du.shape
+    ddu, ddv, dsys = Dev(du), Dev(dv), Dev(sys)
+    check(lib().ofdis_sor_coupled(ddu.ptr, ddv.ptr, dsys.ptr, iterations, omega, w, h, B, None))
+    check(lib().ofdis_sync(None))
+    return ddu.get(du.shape), ddv.get(dv.shape)
+
+
+def patchgrid_level(p, level, im_a, im_a_dx, im_a_dy, im_b, flow_prev=None):
+    """Planes [B,tmp_h,tmp_w,noc]; flow_prev [B,h/2,w/2,2] or None -> p [B,nop,2], flow [B,h,w,2]"""
+    im_a, im_a_dx, im_a_dy, im_b = [_f(x) for x in (im_a, im_a_dx, im_a_dy, im_b)]
+    B = im_a.shape[0]
+    w, h = p.level_size(level)
+    nw, nh = p.grid(level)
+    nop = nw * nh
+    bufs = [Dev(x) for x in (im_a, im_a_dx, im_a_dy, im_b)]
+    dprev = Dev(_f(flow_prev)) if flow_prev is not None else None
+    dp, dflow = Dev(nbytes=B * nop * 2 * 4), Dev(nbytes=B * h * w * 2 * 4)
+    check(lib().ofdis_patchgrid_level(C.byref(p), level, *[b.ptr for b in bufs], dprev.ptr if dprev else None,
+                                      dp.ptr, dflow.ptr, B, None))
+    return dp.get((B, nop, 2)), dflow.get((B, h, w, 2))
+
+
+def varref_level(p, level, im_a, im_b, flow):
+    """im_a, im_b [B,tmp_h,tmp_w,noc]; flow [B,h,w,2] -> refined flow"""
+    im_a, im_b, flow = _f(im_a), _f(im_b), _f(flow)
+    B = im_a.shape[0]
+    da, db, df = Dev(im_a), Dev(im_b), Dev(flow)
+    check(lib().ofdis_varref_level(C.byref(p), level, da.ptr, db.ptr, df.ptr, B, None))
+    return df.get(flow.shape)
+
+
+def _ptr_array(planes, n):
+    arr = (FP * n)()
+    for i in range(n):
+        arr[i] = planes[i].ctypes.data_as(FP) if (i < len(planes) and planes[i] is not None) else None
+    return arr
+
+
+def flow(p, pyr_a, pyr_a_dx, pyr_a_dy, pyr_b):
+    """ofdis_flow(): the drop-in for OFC::OFClass::OFClass with host pyramids (lists over levels 0..sc_f)."""
+    n = p.sc_f + 1
+    keep = [[_f(x) if x is not None else None for x in pl] for pl in (pyr_a, pyr_a_dx, pyr_a_dy, pyr_b)]
+    w, h = p.level_size(p.sc_l)
+    out = np.zeros((h, w, 2), _f32)
+    nullarr = C.cast(None, C.POINTER(FP))
+    check(lib().ofdis_flow(C.byref(p), _ptr_array(keep[0], n), _ptr_array(keep[1], n), _ptr_array(keep[2], n),
+                           _ptr_array(keep[3], n), nullarr, nullarr, out.ctypes.data_as(FP), None))
+    return out
+
+
+def wave_sum_test(x):
+    x = _f(x)
+    d, o = Dev(x), Dev(nbytes=x.nbytes)
+    check(lib().ofdis_test_wave_sum(d.ptr, o.ptr, x.size, None))
+    check(lib().ofdis_sync(None))
+    return o.get(x.shape)
+
+
+class Batch:
+    """ofdis_batch: `nframes` frame pairs of one geometry resident in HBM."""
+
+    def __init__(self, p, nframes):
+        self.p = p.copy()
+        self.nframes = nframes
+        self.h = VP()
+        check(lib().ofdis_batch_create(C.byref(self.h), C.byref(self.p), nframes))
+
+    def close(self):
+        if self.h:
+            lib().ofdis_batch_destroy(self.h)
+            self.h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def input_ptr(self, level, kind):
+        return lib().ofdis_batch_input(self.h, level, kind)
+
+    def input_elems(self, level):
+        return lib().ofdis_batch_input_elems(self.h, level)
+
+    def upload(self, frame, pyr_a, pyr_a_dx, pyr_a_dy, pyr_b, stream=None):
+        n = self.p.sc_f + 1
+        keep = [[_f(x) if x is not None else None for x in pl] for pl in (pyr_a, pyr_a_dx, pyr_a_dy, pyr_b)]
+        check(lib().ofdis_batch_upload(self.h, frame, _ptr_array(keep[0], n), _ptr_array(keep[1], n),
+                                       _ptr_array(keep[2], n), _ptr_array(keep[3], n), stream))
+        check(lib().ofdis_sync(stream))
+
+    def set_input(self, level, kind, arr):
+        """arr: [nframes, tmp_h, tmp_w, noc] float32 host array"""
+        arr = _f(arr)
+        assert arr.size == self.input_elems(level) * self.nframes, (arr.shape, self.input_elems(level))
+        check(lib().ofdis_memcpy_h2d(self.input_ptr(level, kind), arr.ctypes.data, arr.nbytes))
+
+    def build_pyramids_u8(self, img_a_ptr, img_b_ptr, width_org, height_org, stream=None):
+        check(lib().ofdis_batch_build_pyramids_u8(self.h, img_a_ptr, img_b_ptr, width_org, height_org, stream))
+
+    def run(self, stream=None):
+        check(lib().ofdis_batch_run(self.h, stream))
+
+    def flow_ptr(self):
+        return lib().ofdis_batch_flow(self.h)
+
+    def download(self, frame, stream=None):
+        w, h = self.p.level_size(self.p.sc_l)
+        out = np.zeros((h, w, 2), _f32)
+        check(lib().ofdis_batch_download(self.h, frame, out.ctypes.data_as(FP), stream))
+        return out
+
+    def download_all(self):
+        w, h = self.p.level_size(self.p.sc_l)
+        out = np.zeros((self.nframes, h, w, 2), _f32)
+        check(lib().ofdis_sync(None))
+        check(lib().ofdis_memcpy_d2h(out.ctypes.data, self.flow_ptr(), out.nbytes))
+        return out
+
+    def level_flow(self, level):
+        w, h = self.p.level_size(level)
+        out = np.zeros((self.nframes, h, w, 2), _f32)
+        check(lib().ofdis_sync(None))
+        check(lib().ofdis_memcpy_d2h(out.ctypes.data, lib().ofdis_batch_level_flow(self.h, level), out.nbytes))
+        return out
+
+    def timing(self, enable=True):
+        check(lib().ofdis_batch_timing(self.h, int(enable)))
+
+    def kernel_time(self, k):
+        ms, n = C.c_double(0), C.c_long(0)
+        check(lib().ofdis_batch_kernel_time(self.h, k, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,600 @@
+// ofdis_capi.hip -- the C ABI of include/ofdis.h: parameter handling, the batch context (all HBM
+// buffers of the hot path), the coarse-to-fine launch schedule of OFC::OFClass::OFClass
+// (oflow.cpp:184-337) and the per-function entry points used for parity testing.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/time.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "ofdis_kernels.h"
+
+using namespace ofdis;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+int hipfail(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return OFDIS_ERR_DEVICE;
+}
+#define HIPCHK(expr)                                  \
+  do {                                                \
+    hipError_t _e = (expr);                           \
+    if (_e != hipSuccess) return hipfail(_e, #expr);  \
+  } while (0)
+
+// Level geometry exactly as the reference derives it (oflow.cpp:91-92,138-151; patchgrid.cpp:42-48).
+LevelGeom make_geom(const ofdis_params& p, int sl) {
+  LevelGeom g;
+  memset(&g, 0, sizeof(g));
+  const float sc_fct = (float)pow(2, -sl);
+  g.level = sl;
+  g.h = (int)(p.height * sc_fct);
+  g.w = (int)(p.width * sc_fct);
+  g.pad = p.imgpadding;
+  g.noc = p.noc;
+  g.P = p.p_samp_s;
+  g.lb = -(float)p.p_samp_s / 2;
+  g.ubw = (float)(g.w + p.p_samp_s / 2 - 2);
+  g.ubh = (float)(g.h + p.p_samp_s / 2 - 2);
+  g.tmp_w = g.w + 2 * g.pad;
+  g.tmp_h = g.h + 2 * g.pad;
+  int steps = (int)floor(p.p_samp_s * (1 - p.patove));
+  g.steps = steps < 1 ? 1 : steps;
+  g.novals = p.noc * p.p_samp_s * p.p_samp_s;
+  g.nopw = (int)ceil((float)g.w / (float)g.steps);
+  g.noph = (int)ceil((float)g.h / (float)g.steps);
+  g.offw = (int)floor((g.w - (g.nopw - 1) * g.steps) / 2);
+  g.offh = (int)floor((g.h - (g.noph - 1) * g.steps) / 2);
+  g.nop = g.nopw * g.noph;
+  g.plane_elems = (size_t)g.tmp_w * g.tmp_h * g.noc;
+  return g;
+}
+
+int check_params(const ofdis_params* p) {
+  if (!p) return fail(OFDIS_ERR_INVALID, "params is NULL");
+  if (p->usefbcon) return fail(OFDIS_ERR_UNSUPPORTED, "usefbcon=1 (forward-backward merging) is outside this path");
+  if (p->noc != 1 && p->noc != 3) return fail(OFDIS_ERR_INVALID, "noc must be 1 or 3");
+  if (p->sc_l < 0 || p->sc_f < p->sc_l || p->sc_f > 20) return fail(OFDIS_ERR_INVALID, "need 0 <= sc_l <= sc_f");
+  if (p->width <= 0 || p->height <= 0 || (p->width % (1 << p->sc_f)) || (p->height % (1 << p->sc_f)))
+    return fail(OFDIS_ERR_INVALID, "width/height must be positive multiples of 2^sc_f (oflow.h:87)");
+  if (p->p_samp_s < 2 || (p->p_samp_s & 1)) return fail(OFDIS_ERR_INVALID, "p_samp_s must be even and >= 2");
+  if (p->imgpadding < p->p_samp_s) return fail(OFDIS_ERR_INVALID, "imgpadding must be >= p_samp_s (oflow.cpp:147-149)");
+  if (p->noc * p->p_samp_s * p->p_samp_s > 64 * 12) return fail(OFDIS_ERR_UNSUPPORTED, "patch too large (novals > 768)");
+  if (p->costfct < 0 || p->costfct > 2) return fail(OFDIS_ERR_UNSUPPORTED, "costfct must be 0, 1 or 2");
+  if (!(p->patove >= 0.0f && p->patove < 1.0f)) return fail(OFDIS_ERR_INVALID, "patove must be in [0,1)");
+  if (p->usetvref && ((p->height >> p->sc_f) < 4))
+    return fail(OFDIS_ERR_INVALID, "coarsest level must have >= 4 rows for the TV derivative filter (image.c:401-434)");
+  if (p->max_iter < 0 || p->tv_innerit < 0 || p->tv_solverit < 0) return fail(OFDIS_ERR_INVALID, "negative iteration count");
+  return OFDIS_OK;
+}
+
+double now_ms() {
+  struct timeval tv;
+  gettimeofday(&tv, nullptr);
+  return tv.tv_sec * 1000.0 + tv.tv_usec / 1000.0;
+}
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct ofdis_batch {
+  ofdis_params p;
+  int nframes = 0;
+  int nlevels = 0;
+  std::vector<LevelGeom> geom;       // index = level - sc_l
+  std::vector<float*> in[4];         // A, A_dx, A_dy, B per level
+  std::vector<float*> flow;          // AoS dense flow per level
+  // scratch, sized for the finest level
+  float *pvec = nullptr, *pweight = nullptr;
+  float *wx = nullptr, *wy = nullptr, *du = nullptr, *dv = nullptr, *mask = nullptr;
+  float *w_im2 = nullptr, *derivs = nullptr, *sys = nullptr;
+  std::vector<void*> allocs;
+  // timing
+  bool timing = false;
+  std::vector<EventPair> ev[OFDIS_K_COUNT];
+  size_t ev_used[OFDIS_K_COUNT] = {0};
+
+  const LevelGeom& g(int level) const { return geom[level - p.sc_l]; }
+};
+
+namespace {
+
+int dalloc(ofdis_batch* b, float** ptr, size_t elems) {
+  void* d = nullptr;
+  hipError_t e = hipMalloc(&d, (elems ? elems : 1) * sizeof(float));
+  if (e != hipSuccess) return hipfail(e, "hipMalloc");
+  b->allocs.push_back(d);
+  *ptr = (float*)d;
+  return OFDIS_OK;
+}
+
+struct KTimer {  // brackets one launch with events when timing is on
+  ofdis_batch* b;
+  int k;
+  hipStream_t s;
+  EventPair* ep = nullptr;
+  KTimer(ofdis_batch* b_, int k_, hipStream_t s_) : b(b_), k(k_), s(s_) {
+    if (!b || !b->timing) return;
+    auto& v = b->ev[k];
+    if (b->ev_used[k] == v.size()) {
+      EventPair e;
+      hipEventCreate(&e.a);
+      hipEventCreate(&e.b);
+      v.push_back(e);
+    }
+    ep = &v[b->ev_used[k]++];
+    hipEventRecord(ep->a, s);
+  }
+  ~KTimer() {
+    if (ep) hipEventRecord(ep->b, s);
+  }
+};
+
+DisArgs dis_args(const ofdis_params& p, const LevelGeom& g, int nframes) {
+  DisArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = g;
+  a.nframes = nframes;
+  a.max_iter = p.max_iter;
+  a.min_iter = p.min_iter;
+  a.costfct = p.costfct;
+  a.patnorm = p.patnorm;
+  a.dp_thresh_sq = p.dp_thresh * p.dp_thresh;  // oflow.cpp:88
+  a.dr_thresh = p.dr_thresh;
+  a.res_thresh = p.res_thresh;
+  a.outlierthresh = (float)p.p_samp_s / 2;  // oflow.cpp:82
+  return a;
+}
+
+struct TvConsts {
+  float quarter_alpha, half_delta_over3, half_gamma_over3;
+};
+TvConsts tv_consts(float alpha, float gamma, float delta) {  // refine_variational.cpp:40-42
+  TvConsts c;
+  c.quarter_alpha = 0.25f * alpha;
+  c.half_gamma_over3 = gamma * 0.5f / 3.0f;
+  c.half_delta_over3 = delta * 0.5f / 3.0f;
+  return c;
+}
+
+// VarRefClass for one level, all frames (refine_variational.cpp:25-241).  wx/wy hold the dense flow
+// (planar) on entry; the refined flow is written AoS to flow_out.
+int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow_out,
+               hipStream_t s) {
+  const ofdis_params& p = b->p;
+  TvGeom t{g.w, g.h, g.noc, b->nframes};
+  const size_t npx = (size_t)g.w * g.h;
+  const int n_inner = p.tv_innerit * (g.level + 1);  // :36
+  const TvConsts c = tv_consts(p.tv_alpha, p.tv_gamma, p.tv_delta);
+  {
+    KTimer kt(b, OFDIS_K_WARP, s);
+    WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx, b->wy, b->w_im2, b->mask};
+    HIPCHK(launch_warp(wa, s));
+  }
+  {
+    KTimer kt(b, OFDIS_K_DERIV, s);
+    DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs};
+    HIPCHK(launch_derivatives(da, s));
+  }
+  HIPCHK(hipMemsetAsync(b->du, 0, npx * b->nframes * sizeof(float), s));  // image_erase :186-187
+  HIPCHK(hipMemsetAsync(b->dv, 0, npx * b->nframes * sizeof(float), s));
+  for (int it = 0; it < n_inner; ++it) {
+    {
+      KTimer kt(b, OFDIS_K_SYSTEM, s);
+      SystemArgs sa{t, b->mask, b->wx, b->wy, b->du, b->dv, b->derivs, c.quarter_alpha, c.half_delta_over3,
+                    c.half_gamma_over3, b->sys};
+      HIPCHK(launch_tv_system(sa, s));
+    }
+    {
+      KTimer kt(b, OFDIS_K_SOR, s);
+      SorArgs so{t, b->sys, b->du, b->dv, p.tv_solverit, p.tv_sor};
+      HIPCHK(launch_sor(so, s));
+    }
+  }
+  {
+    KTimer kt(b, OFDIS_K_UPDATE, s);
+    HIPCHK(launch_tv_finish(t, b->wx, b->wy, b->du, b->dv, flow_out, s));
+  }
+  return OFDIS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ofdis_last_error(void) { return g_err.c_str(); }
+int ofdis_version(void) { return OFDIS_VERSION; }
+
+int ofdis_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int ofdis_set_device(int device) {
+  HIPCHK(hipSetDevice(device));
+  return OFDIS_OK;
+}
+
+// run_dense.cpp:225-265 (operating points) and :180-183 (AutoFirstScaleSelect)
+int ofdis_params_oppoint(ofdis_params* p, int op_point, int width_org, int noc) {
+  if (!p || width_org <= 0 || (noc != 1 && noc != 3)) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  memset(p, 0, sizeof(*p));
+  p->dp_thresh = 0.05f; p->dr_thresh = 0.95f; p->res_thresh = 0.0f;
+  p->usefbcon = 0; p->patnorm = 1; p->costfct = 0;
+  p->tv_alpha = 10.0f; p->tv_gamma = 10.0f; p->tv_delta = 5.0f;
+  p->tv_innerit = 1; p->tv_solverit = 3; p->tv_sor = 1.6f;
+  p->verbosity = 2;
+  p->noc = noc;
+  const int fratio = 5;
+  int patchsz, dl, it, tv;
+  float poverl;
+  switch (op_point) {
+    case 1: patchsz = 8; poverl = 0.3f; dl = 2; it = 16; tv = 0; break;
+    case 3: patchsz = 12; poverl = 0.75f; dl = 4; it = 16; tv = 1; break;
+    case 4: patchsz = 12; poverl = 0.75f; dl = 5; it = 128; tv = 1; break;
+    case 2:
+    default: patchsz = 8; poverl = 0.4f; dl = 2; it = 12; tv = 1; break;
+  }
+  const int lv_f = std::max(0, (int)floor(log2((2.0f * (float)width_org) / ((float)fratio * (float)patchsz))));
+  p->p_samp_s = patchsz;
+  p->patove = poverl;
+  p->sc_f = lv_f;
+  p->sc_l = std::max(lv_f - dl, 0);
+  p->max_iter = p->min_iter = it;
+  p->usetvref = tv;
+  p->imgpadding = patchsz;
+  return OFDIS_OK;
+}
+
+// ------------------------------------------------------------------------------------ batch context
+int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
+  if (!out) return fail(OFDIS_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (nframes < 1) return fail(OFDIS_ERR_INVALID, "nframes must be >= 1");
+  ofdis_batch* b = new ofdis_batch();
+  b->p = *p;
+  b->nframes = nframes;
+  b->nlevels = p->sc_f - p->sc_l + 1;
+  for (int l = p->sc_l; l <= p->sc_f; ++l) b->geom.push_back(make_geom(*p, l));
+  for (int k = 0; k < 4; ++k) b->in[k].assign(b->nlevels, nullptr);
+  b->flow.assign(b->nlevels, nullptr);
+  rc = OFDIS_OK;
+  for (int i = 0; i < b->nlevels && !rc; ++i) {
+    const LevelGeom& g = b->geom[i];
+    for (int k = 0; k < 4 && !rc; ++k) rc = dalloc(b, &b->in[k][i], g.plane_elems * nframes);
+    if (!rc) rc = dalloc(b, &b->flow[i], (size_t)g.w * g.h * 2 * nframes);
+  }
+  const LevelGeom& g0 = b->geom[0];  // finest level: largest of everything
+  const size_t npx = (size_t)g0.w * g0.h * nframes;
+  size_t nop_max = 0;
+  for (auto& g : b->geom) nop_max = std::max(nop_max, (size_t)g.nop);
+  if (!rc) rc = dalloc(b, &b->pvec, nop_max * 2 * nframes);
+  if (!rc) rc = dalloc(b, &b->pweight, nop_max * g0.novals * nframes);
+  if (!rc && p->usetvref) {
+    if (!rc) rc = dalloc(b, &b->wx, npx);
+    if (!rc) rc = dalloc(b, &b->wy, npx);
+    if (!rc) rc = dalloc(b, &b->du, npx);
+    if (!rc) rc = dalloc(b, &b->dv, npx);
+    if (!rc) rc = dalloc(b, &b->mask, npx);
+    if (!rc) rc = dalloc(b, &b->w_im2, npx * p->noc);
+    if (!rc) rc = dalloc(b, &b->derivs, npx * 8 * p->noc);
+    if (!rc) rc = dalloc(b, &b->sys, npx * 7);
+  }
+  if (rc) {
+    ofdis_batch_destroy(b);
+    return rc == OFDIS_ERR_DEVICE ? OFDIS_ERR_NOMEM : rc;
+  }
+  *out = b;
+  return OFDIS_OK;
+}
+
+void ofdis_batch_destroy(ofdis_batch* b) {
+  if (!b) return;
+  for (void* d : b->allocs) hipFree(d);
+  for (int k = 0; k < OFDIS_K_COUNT; ++k)
+    for (auto& e : b->ev[k]) {
+      hipEventDestroy(e.a);
+      hipEventDestroy(e.b);
+    }
+  delete b;
+}
+
+float* ofdis_batch_input(ofdis_batch* b, int level, int kind) {
+  if (!b || level < b->p.sc_l || level > b->p.sc_f || kind < 0 || kind > 3) return nullptr;
+  return b->in[kind][level - b->p.sc_l];
+}
+size_t ofdis_batch_input_elems(const ofdis_batch* b, int level) {
+  if (!b || level < b->p.sc_l || level > b->p.sc_f) return 0;
+  return b->g(level).plane_elems;
+}
+
+int ofdis_batch_upload(ofdis_batch* b, int frame, const float* const* im_a, const float* const* im_a_dx,
+                       const float* const* im_a_dy, const float* const* im_b, void* stream) {
+  if (!b || frame < 0 || frame >= b->nframes || !im_a || !im_a_dx || !im_a_dy || !im_b)
+    return fail(OFDIS_ERR_INVALID, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const float* const* src[4] = {im_a, im_a_dx, im_a_dy, im_b};
+  for (int l = b->p.sc_l; l <= b->p.sc_f; ++l) {
+    const size_t n = b->g(l).plane_elems;
+    for (int k = 0; k < 4; ++k) {
+      if (!src[k][l]) return fail(OFDIS_ERR_INVALID, "pyramid level pointer is NULL");
+      HIPCHK(hipMemcpyAsync(b->in[k][l - b->p.sc_l] + (size_t)frame * n, src[k][l], n * sizeof(float),
+                            hipMemcpyHostToDevice, s));
+    }
+  }
+  return OFDIS_OK;
+}
+
+int ofdis_batch_build_pyramids_u8(ofdis_batch* b, const uint8_t* img_a, const uint8_t* img_b, int width_org,
+                                  int height_org, void* stream) {
+  (void)b; (void)img_a; (void)img_b; (void)width_org; (void)height_org; (void)stream;
+  return fail(OFDIS_ERR_UNSUPPORTED, "on-device pyramid construction is not built yet (SURVEY.md 8f-1)");
+}
+
+// The coarse-to-fine loop of OFClass::OFClass (oflow.cpp:184-337), every stage batched over frames.
+int ofdis_batch_run(ofdis_batch* b, void* stream) {
+  if (!b) return fail(OFDIS_ERR_INVALID, "batch is NULL");
+  hipStream_t s = (hipStream_t)stream;
+  const ofdis_params& p = b->p;
+  const int verbose = p.verbosity;
+  double t_all0 = 0;
+  if (verbose > 0) {
+    hipStreamSynchronize(s);
+    t_all0 = now_ms();
+  }
+  if (verbose > 1) printf("TIME (Grid Memo. Alloc. ) (ms): %3g\n", 0.0);  // buffers live in the batch context
+  for (int sl = p.sc_f; sl >= p.sc_l; --sl) {
+    const int ii = sl - p.sc_l;
+    const LevelGeom& g = b->geom[ii];
+    double tt[5] = {0, 0, 0, 0, 0};
+    double t0 = 0;
+    if (verbose > 1) { hipStreamSynchronize(s); t0 = now_ms(); }
+    // steps 1-3: patch grid construction, initialisation from the coarser flow and the inverse
+    // search run as ONE kernel (pconst/pinit are reported as 0, poptim carries the time)
+    {
+      KTimer kt(b, OFDIS_K_PATCH, s);
+      DisArgs a = dis_args(p, g, b->nframes);
+      a.im_a = b->in[0][ii];
+      a.im_a_dx = b->in[1][ii];
+      a.im_a_dy = b->in[2][ii];
+      a.im_b = b->in[3][ii];
+      a.flow_prev = (sl < p.sc_f) ? b->flow[ii + 1] : nullptr;  // initflow: see ofdis_flow()
+      a.p_out = b->pvec;
+      a.pweight = b->pweight;
+      HIPCHK(launch_patch_optimize(a, s));
+    }
+    if (verbose > 1) { hipStreamSynchronize(s); tt[2] = now_ms() - t0; t0 = now_ms(); }
+    // step 4: densification
+    {
+      KTimer kt(b, OFDIS_K_DENSIFY, s);
+      DensifyArgs d;
+      memset(&d, 0, sizeof(d));
+      d.g = g;
+      d.nframes = b->nframes;
+      d.p = b->pvec;
+      d.pweight = b->pweight;
+      if (p.usetvref) { d.wx = b->wx; d.wy = b->wy; } else d.flow_aos = b->flow[ii];
+      HIPCHK(launch_densify(d, s));
+    }
+    if (verbose > 1) { hipStreamSynchronize(s); tt[3] = now_ms() - t0; t0 = now_ms(); }
+    // step 5: variational refinement
+    if (p.usetvref) {
+      int rc = run_varref(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s);
+      if (rc) return rc;
+    }
+    if (verbose > 1) {
+      hipStreamSynchronize(s);
+      tt[4] = now_ms() - t0;
+      printf("TIME (Sc: %i, #p:%6i, pconst, pinit, poptim, cflow, tvopt, total): %8.2f %8.2f %8.2f %8.2f %8.2f -> %8.2f ms.\n",
+             sl, g.nop, tt[0], tt[1], tt[2], tt[3], tt[4], tt[0] + tt[1] + tt[2] + tt[3] + tt[4]);
+    }
+  }
+  if (verbose > 0) {
+    hipStreamSynchronize(s);
+    printf("TIME (O.Flow Run-Time   ) (ms): %3g\n", now_ms() - t_all0);
+    fflush(stdout);
+  }
+  return OFDIS_OK;
+}
+
+const float* ofdis_batch_flow(const ofdis_batch* b) { return b ? b->flow[0] : nullptr; }
+const float* ofdis_batch_level_flow(const ofdis_batch* b, int level) {
+  if (!b || level < b->p.sc_l || level > b->p.sc_f) return nullptr;
+  return b->flow[level - b->p.sc_l];
+}
+
+int ofdis_batch_download(ofdis_batch* b, int frame, float* outflow_host, void* stream) {
+  if (!b || frame < 0 || frame >= b->nframes || !outflow_host) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  const LevelGeom& g = b->geom[0];
+  const size_t n = (size_t)g.w * g.h * 2;
+  HIPCHK(hipMemcpyAsync(outflow_host, b->flow[0] + (size_t)frame * n, n * sizeof(float), hipMemcpyDeviceToHost,
+                        (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return OFDIS_OK;
+}
+
+int ofdis_batch_timing(ofdis_batch* b, int enable) {
+  if (!b) return fail(OFDIS_ERR_INVALID, "batch is NULL");
+  b->timing = enable != 0;
+  for (int k = 0; k < OFDIS_K_COUNT; ++k) b->ev_used[k] = 0;
+  return OFDIS_OK;
+}
+
+int ofdis_batch_kernel_time(ofdis_batch* b, int k, double* ms_sum, long* launches) {
+  if (!b || k < 0 || k >= OFDIS_K_COUNT) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  double sum = 0;
+  for (size_t i = 0; i < b->ev_used[k]; ++i) {
+    HIPCHK(hipEventSynchronize(b->ev[k][i].b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev[k][i].a, b->ev[k][i].b));
+    sum += ms;
+  }
+  if (ms_sum) *ms_sum = sum;
+  if (launches) *launches = (long)b->ev_used[k];
+  return OFDIS_OK;
+}
+
+// ------------------------------------------------------------------------------------ drop-in
+int ofdis_flow(const ofdis_params* p, const float* const* im_a, const float* const* im_a_dx,
+               const float* const* im_a_dy, const float* const* im_b, const float* const* im_b_dx,
+               const float* const* im_b_dy, float* outflow, const float* initflow) {
+  (void)im_b_dx; (void)im_b_dy;  // never read when usefbcon == 0
+  if (!outflow) return fail(OFDIS_ERR_INVALID, "outflow is NULL");
+  if (initflow) return fail(OFDIS_ERR_UNSUPPORTED, "initflow warm start is not supported yet (SURVEY.md 8f-4)");
+  ofdis_batch* b = nullptr;
+  int rc = ofdis_batch_create(&b, p, 1);
+  if (rc) return rc;
+  rc = ofdis_batch_upload(b, 0, im_a, im_a_dx, im_a_dy, im_b, nullptr);
+  if (!rc) rc = ofdis_batch_run(b, nullptr);
+  if (!rc) rc = ofdis_batch_download(b, 0, outflow, nullptr);
+  ofdis_batch_destroy(b);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------ per-function
+int ofdis_image_warp(float* dst, float* mask, const float* src, const float* wx, const float* wy, int w, int h,
+                     int noc, int nframes, void* stream) {
+  if (!dst || !mask || !src || !wx || !wy || w < 1 || h < 1 || nframes < 1) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  WarpArgs a{TvGeom{w, h, noc, nframes}, src, 0, 0, 0, 0, wx, wy, dst, mask};
+  HIPCHK(launch_warp(a, (hipStream_t)stream));
+  return OFDIS_OK;
+}
+
+int ofdis_get_derivatives(float* out, const float* im1, const float* im2w, int w, int h, int noc, int nframes,
+                          void* stream) {
+  if (!out || !im1 || !im2w || w < 1 || h < 4 || nframes < 1) return fail(OFDIS_ERR_INVALID, "bad arguments (need h >= 4)");
+  DerivArgs a{TvGeom{w, h, noc, nframes}, im1, 0, 0, 0, 0, im2w, out};
+  HIPCHK(launch_derivatives(a, (hipStream_t)stream));
+  return OFDIS_OK;
+}
+
+int ofdis_tv_system(float* out, const float* mask, const float* wx, const float* wy, const float* du,
+                    const float* dv, const float* derivs, float tv_alpha, float tv_gamma, float tv_delta, int w,
+                    int h, int noc, int nframes, void* stream) {
+  if (!out || !mask || !wx || !wy || !du || !dv || !derivs || w < 1 || h < 1) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  const TvConsts c = tv_consts(tv_alpha, tv_gamma, tv_delta);
+  SystemArgs a{TvGeom{w, h, noc, nframes}, mask, wx, wy, du, dv, derivs, c.quarter_alpha, c.half_delta_over3,
+               c.half_gamma_over3, out};
+  HIPCHK(launch_tv_system(a, (hipStream_t)stream));
+  return OFDIS_OK;
+}
+
+int ofdis_sor_coupled(float* du, float* dv, const float* sys, int iterations, float omega, int w, int h,
+                      int nframes, void* stream) {
+  if (!du || !dv || !sys || w < 1 || h < 1 || nframes < 1) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  SorArgs a{TvGeom{w, h, 1, nframes}, sys, du, dv, iterations, omega};
+  HIPCHK(launch_sor(a, (hipStream_t)stream));
+  return OFDIS_OK;
+}
+
+int ofdis_patchgrid_level(const ofdis_params* p, int level, const float* im_a, const float* im_a_dx,
+                          const float* im_a_dy, const float* im_b, const float* flow_prev, float* p_out,
+                          float* flow_out, int nframes, void* stream) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (level < 0 || level > p->sc_f || !im_a || !im_a_dx || !im_a_dy || !im_b || nframes < 1)
+    return fail(OFDIS_ERR_INVALID, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const LevelGeom g = make_geom(*p, level);
+  float *pv = nullptr, *pw = nullptr;
+  HIPCHK(hipMalloc((void**)&pv, (size_t)g.nop * 2 * nframes * sizeof(float)));
+  hipError_t e = hipMalloc((void**)&pw, (size_t)g.nop * g.novals * nframes * sizeof(float));
+  if (e != hipSuccess) { hipFree(pv); return hipfail(e, "hipMalloc"); }
+  DisArgs a = dis_args(*p, g, nframes);
+  a.im_a = im_a; a.im_a_dx = im_a_dx; a.im_a_dy = im_a_dy; a.im_b = im_b;
+  a.flow_prev = flow_prev;
+  a.p_out = pv;
+  a.pweight = pw;
+  e = launch_patch_optimize(a, s);
+  if (e == hipSuccess && flow_out) {
+    DensifyArgs d;
+    memset(&d, 0, sizeof(d));
+    d.g = g; d.nframes = nframes; d.p = pv; d.pweight = pw; d.flow_aos = flow_out;
+    e = launch_densify(d, s);
+  }
+  if (e == hipSuccess && p_out)
+    e = hipMemcpyAsync(p_out, pv, (size_t)g.nop * 2 * nframes * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(pv);
+  hipFree(pw);
+  if (e != hipSuccess) return hipfail(e, "ofdis_patchgrid_level");
+  return OFDIS_OK;
+}
+
+int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, const float* im_b, float* flow,
+                       int nframes, void* stream) {
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (level < 0 || level > p->sc_f || !im_a || !im_b || !flow || nframes < 1) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  // a throw-away context that only carries the TV scratch of this level
+  ofdis_batch b;
+  b.p = *p;
+  b.p.verbosity = 0;
+  b.nframes = nframes;
+  const LevelGeom g = make_geom(*p, level);
+  if (g.h < 4) return fail(OFDIS_ERR_INVALID, "level must have >= 4 rows");
+  const size_t npx = (size_t)g.w * g.h * nframes;
+  rc = dalloc(&b, &b.wx, npx);
+  if (!rc) rc = dalloc(&b, &b.wy, npx);
+  if (!rc) rc = dalloc(&b, &b.du, npx);
+  if (!rc) rc = dalloc(&b, &b.dv, npx);
+  if (!rc) rc = dalloc(&b, &b.mask, npx);
+  if (!rc) rc = dalloc(&b, &b.w_im2, npx * p->noc);
+  if (!rc) rc = dalloc(&b, &b.derivs, npx * 8 * p->noc);
+  if (!rc) rc = dalloc(&b, &b.sys, npx * 7);
+  if (!rc) {
+    TvGeom t{g.w, g.h, g.noc, nframes};
+    hipError_t e = launch_flow_split(t, flow, b.wx, b.wy, s);
+    if (e != hipSuccess) rc = hipfail(e, "flow_split");
+  }
+  if (!rc) rc = run_varref(&b, g, im_a, im_b, flow, s);
+  hipError_t e = hipStreamSynchronize(s);
+  if (!rc && e != hipSuccess) rc = hipfail(e, "sync");
+  for (void* d : b.allocs) hipFree(d);
+  b.allocs.clear();
+  return rc;
+}
+
+// test hook (not declared in ofdis.h): wave_sum over groups of 64
+int ofdis_test_wave_sum(const float* in, float* out, int n, void* stream) {
+  HIPCHK(launch_wave_sum_test(in, out, n, (hipStream_t)stream));
+  return OFDIS_OK;
+}
+
+// ------------------------------------------------------------------------------------ memory helpers
+void* ofdis_dev_alloc(size_t bytes) {
+  void* d = nullptr;
+  if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return nullptr;
+  return d;
+}
+void ofdis_dev_free(void* p) { hipFree(p); }
+int ofdis_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return OFDIS_OK;
+}
+int ofdis_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return OFDIS_OK;
+}
+int ofdis_sync(void* stream) {
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return OFDIS_OK;
+}
+
+}  // extern "C"

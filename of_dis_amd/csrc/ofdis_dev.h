@@ -1,0 +1,74 @@
+// ofdis_dev.h -- shared host/device definitions for the gfx950 kernels.
+//
+// Arithmetic contract (see include/ofdis.h): fp32, no contraction (the library is compiled with
+// -ffp-contract=off), IEEE divide/sqrt (hipcc default), reference operation order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ofdis.h"
+
+namespace ofdis {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// Per-level geometry, derived exactly as the reference does (oflow.cpp:138-157, patchgrid.cpp:42-48).
+struct LevelGeom {
+  int level;
+  int w, h;            // unpadded level size
+  int pad;             // imgpadding
+  int tmp_w, tmp_h;    // padded plane size
+  int noc;
+  float lb, ubw, ubh;  // valid patch-centre range (tmp_lb, tmp_ubw, tmp_ubh)
+  // patch grid
+  int P, steps, nopw, noph, nop, offw, offh, novals;
+  size_t plane_elems;  // tmp_w*tmp_h*noc
+};
+
+// ----------------------------------------------------------------------------- wave primitives
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x, float old = 0.0f) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+// lane l <- lane l-1 (lane 0 keeps `old`); lane l <- lane l+1 (lane 63 keeps `old`)
+__device__ __forceinline__ float wave_from_prev(float x, float old = 0.0f) { return dpp_mov<0x138>(x, old); }  // wave_shr:1
+__device__ __forceinline__ float wave_from_next(float x, float old = 0.0f) { return dpp_mov<0x130>(x, old); }  // wave_shl:1
+
+// 64-lane butterfly all-reduce.  Order of the additions (this IS the documented reduction order,
+// mirrored by oracle/eigen_shim -DOFDIS_SHIM_WAVE64 and oracle_set_reduce_order(1)):
+//   pairs at lane distance 1, then 2, 4, 8, 16, 32; every lane ends with the same bits.
+// Distances 1,2 are quad permutes, 4 and 8 the half-row / row mirrors (equivalent to xor once the
+// smaller groups are uniform), 16 and 32 the gfx950 v_permlane{16,32}_swap.
+// v_permlane{16,32}_swap exchange halves between TWO registers (vdst, src):
+//   permlane16_swap: odd 16-lane rows of vdst <-> even rows of src
+//   permlane32_swap: lanes 32-63 of vdst    <-> lanes 0-31 of src
+// With both registers holding x, vdst ends as {r0,r0,r2,r2} / {lo,lo} and src as {r1,r1,r3,r3} /
+// {hi,hi}; their sum is the butterfly step.  Written as inline asm because hipcc (ROCm 7.2) lowers
+// __builtin_amdgcn_permlane*_swap's second result to the first register (observed on gfx950:
+// "v_permlane16_swap v2, v3; v_add_f32 v2, v2, v2").  The s_nop 1 is the two wait states the
+// "VALU write -> v_permlane read" hazard needs (cdna_hip_programming.md T21); it must sit inside
+// the string because the compiler does not pad around asm statements.
+__device__ __forceinline__ float swap16_sum(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float swap32_sum(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+  x = x + dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
+  x = x + dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+  x = x + dpp_mov<0x141>(x);  // row_half_mirror
+  x = x + dpp_mov<0x140>(x);  // row_mirror
+  x = swap16_sum(x);
+  x = swap32_sum(x);
+  return x;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+}  // namespace ofdis

@@ -1,0 +1,339 @@
+// ofdis_dis.hip -- Dense Inverse Search kernels for gfx950 (CDNA4).
+//
+//   patch_optimize_kernel : one 64-lane wavefront per patch runs the whole inverse-compositional
+//                           Gauss-Newton loop of the reference in registers
+//                           (patchgrid.cpp:98-141,195-211; patch.cpp:57-402).
+//   densify_kernel        : AggregateFlowDense (patchgrid.cpp:213-275,377-397) as a gather that
+//                           visits a pixel's covering patches in the reference's scatter order.
+//
+// Mapping.  The reference's patch vector has novals = noc*P*P entries, ordered (row, col, channel)
+// (patch.cpp:306-324).  Lane l of the wave owns entries l, l+64, l+128, ... (M per lane, template
+// parameter), so for the gray P=8 operating points one lane is exactly one patch pixel and the
+// template T, its gradients Tx,Ty, the residual and the weights never leave VGPRs.  The five
+// reductions per iteration (mean, Tx.r, Ty.r, |r|) are DPP/permlane butterflies (ofdis_dev.h);
+// no LDS is used.  The bilinear taps are plain global loads from the padded level image, which is
+// 41 KB at op-point 2 and therefore L1/L2 resident; blocks are mapped so that all patches of a
+// frame run on one XCD (its L2 then holds that frame's four planes once).
+#include "ofdis_kernels.h"
+
+namespace ofdis {
+
+// blocks of one frame stay on one XCD: the dispatcher places block n on XCD n%8 (observed, used
+// for L2 affinity only -- correctness does not depend on it).
+__device__ __forceinline__ void xcd_frame_map(int n, int blocks_per_frame, int& frame, int& blk) {
+  const int xcd = n & 7;
+  const int m = n >> 3;
+  frame = (m / blocks_per_frame) * 8 + xcd;
+  blk = m % blocks_per_frame;
+}
+
+template <int M>
+__device__ __forceinline__ float lane_partial(const float (&x)[M], const bool (&valid)[M]) {
+  // lane l accumulates x[l], x[l+64], ... sequentially, starting FROM the first element
+  float s = valid[0] ? x[0] : 0.0f;
+#pragma unroll
+  for (int m = 1; m < M; ++m)
+    if (valid[m]) s = s + x[m];
+  return s;
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
+  const LevelGeom& g = a.g;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int blocks_per_frame = (g.nop + 3) >> 2;
+  int frame, blk;
+  xcd_frame_map(blockIdx.x, blocks_per_frame, frame, blk);
+  const int ip = blk * 4 + wave;
+  if (frame >= a.nframes || ip >= g.nop) return;  // wave-uniform
+
+  const int noc = g.noc, P = g.P, tw = g.tmp_w, nv = g.novals;
+  const int lb = -P / 2;
+  const size_t plane = g.plane_elems;
+  const float* __restrict__ imA = a.im_a + (size_t)frame * plane;
+  const float* __restrict__ imAx = a.im_a_dx + (size_t)frame * plane;
+  const float* __restrict__ imAy = a.im_a_dy + (size_t)frame * plane;
+  const float* __restrict__ imB = a.im_b + (size_t)frame * plane;
+
+  // grid position (patchgrid.cpp:62-69): ip = gx*noph + gy
+  const int gx = ip / g.noph, gy = ip - gx * g.noph;
+  const float rx = (float)(gx * g.steps + g.offw), ry = (float)(gy * g.steps + g.offh);
+
+  // per-lane entry offsets relative to the patch centre in the padded, interleaved plane
+  int off[M];
+  bool valid[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int k = lane + 64 * m;
+    valid[m] = k < nv;
+    const int kk = valid[m] ? k : 0;
+    const int c = kk % noc, q = kk / noc;
+    const int col = q % P, row = q / P;
+    off[m] = ((row + lb) * tw + (col + lb)) * noc + c;
+  }
+  const float fnv = (float)nv;
+
+  // ---- InitializePatch: template + gradients at the integer reference position (patch.cpp:287-332)
+  float T[M], Tx[M], Ty[M];
+  {
+    const int px = (int)roundf(rx) + g.pad, py = (int)roundf(ry) + g.pad;
+    const int base = (py * tw + px) * noc;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      T[m] = valid[m] ? imA[base + off[m]] : 0.0f;
+      Tx[m] = valid[m] ? imAx[base + off[m]] : 0.0f;
+      Ty[m] = valid[m] ? imAy[base + off[m]] : 0.0f;
+    }
+    if (a.patnorm > 0) {
+      const float mean = wave_sum(lane_partial<M>(T, valid)) / fnv;
+#pragma unroll
+      for (int m = 0; m < M; ++m) T[m] -= mean;
+    }
+  }
+  // ---- ComputeHessian (patch.cpp:71-88) and its Cholesky factor (Eigen LLT, call site patch.cpp:184;
+  //      semantics as written out in oracle/eigen_shim/Eigen/Core).  H is constant per patch, so the
+  //      factor is computed once instead of once per iteration.
+  float l00, l10, l11;
+  {
+    float pxx[M], pxy[M], pyy[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      pxx[m] = Tx[m] * Tx[m];
+      pxy[m] = Tx[m] * Ty[m];
+      pyy[m] = Ty[m] * Ty[m];
+    }
+    float H00 = wave_sum(lane_partial<M>(pxx, valid));
+    const float H01 = wave_sum(lane_partial<M>(pxy, valid));
+    float H11 = wave_sum(lane_partial<M>(pyy, valid));
+    if (H00 * H11 - H01 * H01 == 0.0f) {  // float += double literal in the reference
+      H00 = (float)((double)H00 + 1e-10);
+      H11 = (float)((double)H11 + 1e-10);
+    }
+    l00 = H00; l10 = H01; l11 = H11;
+    if (!(l00 <= 0.0f)) {
+      l00 = sqrtf(l00);
+      l10 = l10 / l00;
+      const float x = l11 - l10 * l10;
+      if (!(x <= 0.0f)) l11 = sqrtf(x);
+    }
+  }
+
+  // ---- InitializeFromCoarserOF (patchgrid.cpp:195-211)
+  float pin0 = 0.0f, pin1 = 0.0f;
+  if (a.flow_prev) {
+    const int x = (int)floorf(rx / 2), y = (int)floorf(ry / 2);
+    const int i = y * (g.w / 2) + x;
+    const float* fp = a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2) * 2;
+    pin0 = fp[2 * i] * 2;
+    pin1 = fp[2 * i + 1] * 2;
+  }
+
+  // ---- OptimizeIter (patch.cpp:159-212)
+  float p0 = pin0, p1 = pin1;
+  float ptx = rx + p0, pty = ry + p1;
+  const float stx = ptx, sty = pty;
+  float dp0 = 0.0f, dp1 = 0.0f;
+  float dpsq = 1e-10f, dpsq_init = 1e-10f, mares = 1e20f, mares_old = 1e20f;
+  int cnt = 0;
+  bool converged = false;
+  float pdiff[M], pw[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) { pdiff[m] = 0.0f; pw[m] = 0.0f; }  // pw = 0: the reference's never-written pweight
+
+  // OptimizeComputeErrImg (patch.cpp:264-284) = getPatchStaticBil (335-402) + LossComputeErrorImage (223-262)
+  auto compute_err = [&]() {
+    int pos0 = (int)ceilf(ptx + .00001f), pos1 = (int)ceilf(pty + .00001f);
+    const int pos2 = (int)floorf(ptx), pos3 = (int)floorf(pty);
+    const float r0 = ptx - (float)pos2, r1 = pty - (float)pos3;
+    const float we0 = r0 * r1, we1 = (1 - r0) * r1, we2 = r0 * (1 - r1), we3 = (1 - r0) * (1 - r1);
+    pos0 += g.pad;
+    pos1 += g.pad;
+    const int base = (pos1 * tw + pos0) * noc;
+    const int up = tw * noc;
+    float v[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int o = base + off[m];
+      const float ta = imB[o], tb = imB[o - noc], tc = imB[o - up], td = imB[o - up - noc];
+      v[m] = valid[m] ? (we0 * ta + we1 * tb + we2 * tc + we3 * td) : 0.0f;
+    }
+    if (a.patnorm > 0) {
+      const float mean = wave_sum(lane_partial<M>(v, valid)) / fnv;
+#pragma unroll
+      for (int m = 0; m < M; ++m) v[m] -= mean;
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      float d = v[m] - T[m];
+      if (a.costfct == 1) {
+        d = copysignf(sqrtf(fabsf(d)), d);
+      } else if (a.costfct == 2) {
+        const float bsq = 5.0f * 5.0f, bsq2 = bsq * 2.0f;
+        d = copysignf(sqrtf((sqrtf(1.0f + (d * d) / bsq) - 1.0f) * bsq2), d);
+      }
+      pdiff[m] = valid[m] ? d : 0.0f;
+      pw[m] = fabsf(pdiff[m]);
+    }
+    dpsq = dp0 * dp0 + dp1 * dp1;
+    if (cnt == 1) dpsq_init = dpsq;
+    mares_old = mares;
+    mares = wave_sum(lane_partial<M>(pw, valid)) / fnv;
+    if (!((cnt < a.max_iter) & (mares > a.res_thresh) &
+          ((cnt < a.min_iter) | (dpsq / dpsq_init >= a.dp_thresh_sq)) &
+          ((cnt < a.min_iter) | (mares / mares_old <= a.dr_thresh))))
+      converged = true;
+  };
+  auto oob = [&](float x, float y) { return x < g.lb || y < g.lb || x > g.ubw || y > g.ubh; };
+
+  // OptimizeStart (patch.cpp:120-156)
+  if (oob(ptx, pty) || !(isfinite(ptx) && isfinite(pty))) {
+    converged = true;
+  } else {
+    cnt = 0; dpsq = 1e-10f; dpsq_init = 1e-10f; mares = 1e5f; mares_old = 1e20f;
+    compute_err();
+  }
+  while (!converged) {
+    cnt++;
+    float gxr[M], gyr[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      gxr[m] = Tx[m] * pdiff[m];
+      gyr[m] = Ty[m] * pdiff[m];
+    }
+    const float b0 = wave_sum(lane_partial<M>(gxr, valid));
+    const float b1 = wave_sum(lane_partial<M>(gyr, valid));
+    // delta_p = LLT(H).solve(b)
+    const float y0 = b0 / l00;
+    const float y1 = (b1 - l10 * y0) / l11;
+    dp1 = y1 / l11;
+    dp0 = (y0 - l10 * dp1) / l00;
+    p0 -= dp0;
+    p1 -= dp1;
+    ptx = rx + p0;
+    pty = ry + p1;
+    const float ex = stx - ptx, ey = sty - pty;
+    // a NaN position passes every comparison of the reference and then indexes out of bounds
+    // (SURVEY.md 7-4b); here it is treated as an outlier.
+    if (sqrtf(ex * ex + ey * ey) > a.outlierthresh || oob(ptx, pty) || !(isfinite(ptx) && isfinite(pty))) {
+      p0 = pin0;
+      p1 = pin1;
+      ptx = rx + p0;
+      pty = ry + p1;
+      converged = true;
+    }
+    compute_err();
+  }
+
+  float* pout = a.p_out + ((size_t)frame * g.nop + ip) * 2;
+  if (lane == 0) {
+    pout[0] = p0;
+    pout[1] = p1;
+  }
+  float* pwout = a.pweight + ((size_t)frame * g.nop + ip) * nv;
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+    if (valid[m]) pwout[lane + 64 * m] = pw[m];
+}
+
+hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
+  const int blocks_per_frame = (a.g.nop + 3) / 4;
+  const int grid = ((a.nframes + 7) / 8) * 8 * blocks_per_frame;
+  const int M = (a.g.novals + 63) / 64;
+  if (M <= 1)
+    hipLaunchKernelGGL(patch_optimize_kernel<1>, dim3(grid), dim3(256), 0, s, a);
+  else if (M <= 3)
+    hipLaunchKernelGGL(patch_optimize_kernel<3>, dim3(grid), dim3(256), 0, s, a);
+  else if (M <= 7)
+    hipLaunchKernelGGL(patch_optimize_kernel<7>, dim3(grid), dim3(256), 0, s, a);
+  else if (M <= 12)
+    hipLaunchKernelGGL(patch_optimize_kernel<12>, dim3(grid), dim3(256), 0, s, a);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ densify
+// Reference: for ip ascending, for every pixel of the patch inside the image:
+//   absw = 1/max(2,|r|)  (RGB: 1/sum_c max(2,|r_c|));  we += absw;  flow += p*absw;
+// then flow /= we where we > 0 (patchgrid.cpp:221-271, 377-397).  A pixel is covered by at most
+// ceil(P/steps)^2 patches; visiting them with gx ascending then gy ascending reproduces the
+// reference's ip order, so the sums are bit-identical without atomics.
+template <bool PLANAR>
+__global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
+  const LevelGeom& g = a.g;
+  const int npx = g.w * g.h;
+  const long long total = (long long)npx * a.nframes;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int frame = (int)(idx / npx);
+    const int i = (int)(idx - (long long)frame * npx);
+    const int y = i / g.w, x = i - y * g.w;
+    const int P = g.P, lb = -P / 2, ub = P / 2 - 1, st = g.steps, noc = g.noc;
+    // rx + lb <= x <= rx + ub, rx = gx*st + offw
+    int gx_lo = (x - ub - g.offw + st - 1);
+    gx_lo = gx_lo < 0 ? 0 : gx_lo / st;
+    int gx_hi = x - lb - g.offw;
+    gx_hi = gx_hi < 0 ? -1 : gx_hi / st;
+    if (gx_hi > g.nopw - 1) gx_hi = g.nopw - 1;
+    int gy_lo = (y - ub - g.offh + st - 1);
+    gy_lo = gy_lo < 0 ? 0 : gy_lo / st;
+    int gy_hi = y - lb - g.offh;
+    gy_hi = gy_hi < 0 ? -1 : gy_hi / st;
+    if (gy_hi > g.noph - 1) gy_hi = g.noph - 1;
+    const float* pf = a.p + (size_t)frame * g.nop * 2;
+    const float* pwf = a.pweight + (size_t)frame * g.nop * g.novals;
+    float we = 0.0f, fu = 0.0f, fv = 0.0f;
+    for (int gx = gx_lo; gx <= gx_hi; ++gx)
+      for (int gy = gy_lo; gy <= gy_hi; ++gy) {
+        const int ip = gx * g.noph + gy;
+        const int kx = x - (gx * st + g.offw) - lb, ky = y - (gy * st + g.offh) - lb;
+        const float* pw = pwf + (size_t)ip * g.novals + (ky * P + kx) * noc;
+        float absw;
+        if (noc == 1) {
+          absw = 1.0f / fmaxf(2.0f, pw[0]);
+        } else {
+          absw = fmaxf(2.0f, pw[0]);
+          absw += fmaxf(2.0f, pw[1]);
+          absw += fmaxf(2.0f, pw[2]);
+          absw = 1.0f / absw;
+        }
+        we += absw;
+        fu += pf[2 * ip] * absw;
+        fv += pf[2 * ip + 1] * absw;
+      }
+    if (we > 0) {
+      fu /= we;
+      fv /= we;
+    }
+    if (PLANAR) {
+      a.wx[idx] = fu;
+      a.wy[idx] = fv;
+    } else {
+      reinterpret_cast<float2*>(a.flow_aos)[idx] = make_float2(fu, fv);
+    }
+  }
+}
+
+hipError_t launch_densify(const DensifyArgs& a, hipStream_t s) {
+  const long long total = (long long)a.g.w * a.g.h * a.nframes;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (a.flow_aos)
+    hipLaunchKernelGGL(densify_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(densify_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ test hook
+__global__ void wave_sum_test_kernel(const float* in, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = wave_sum(in[i]);
+}
+hipError_t launch_wave_sum_test(const float* in, float* out, int n, hipStream_t s) {
+  hipLaunchKernelGGL(wave_sum_test_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
+  return hipGetLastError();
+}
+
+}  // namespace ofdis

@@ -1,0 +1,101 @@
+// ofdis_kernels.h -- launchers of the gfx950 kernels (internal C++ API; the public ABI is include/ofdis.h).
+#pragma once
+#include "ofdis_dev.h"
+
+namespace ofdis {
+
+// flow-plane layouts used between kernels
+//   AoS   : [frame][h][w][2]   -- the reference's dense-flow format (DIS init / output)
+//   planar: [frame][h][w] x2   -- TV stage
+struct DisArgs {
+  LevelGeom g;
+  int nframes;
+  // solver parameters (oflow.cpp:76-108)
+  int max_iter, min_iter, costfct, patnorm;
+  float dp_thresh_sq, dr_thresh, res_thresh, outlierthresh;
+  const float* im_a;     // [B][tmp_h][tmp_w][noc]
+  const float* im_a_dx;
+  const float* im_a_dy;
+  const float* im_b;
+  const float* flow_prev;  // AoS [B][h/2][w/2][2] or nullptr
+  float* p_out;            // [B][nop][2]
+  float* pweight;          // [B][nop][novals]
+};
+// PatGridClass::{InitializeGrid, SetTargetImage, InitializeFromCoarserOF, Optimize}
+hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s);
+
+struct DensifyArgs {
+  LevelGeom g;
+  int nframes;
+  const float* p;        // [B][nop][2]
+  const float* pweight;  // [B][nop][novals]
+  float* flow_aos;       // if non-null: AoS output
+  float* wx;             // else planar outputs
+  float* wy;
+};
+// PatGridClass::AggregateFlowDense as an order-preserving gather
+hipError_t launch_densify(const DensifyArgs& a, hipStream_t s);
+
+struct TvGeom {
+  int w, h, noc, nframes;
+};
+
+// image_warp.  src: either the padded interleaved pyramid plane (src_padded=1: [B][tmp_h][tmp_w][noc],
+// pad/tmp_w given) or packed planar [B][noc][h][w] (src_padded=0).  dst: [B][noc][h][w], mask [B][h][w].
+struct WarpArgs {
+  TvGeom t;
+  const float* src;
+  int src_padded, pad, tmp_w, tmp_h;
+  const float* wx;
+  const float* wy;
+  float* dst;
+  float* mask;
+};
+hipError_t launch_warp(const WarpArgs& a, hipStream_t s);
+
+// get_derivatives.  im1 as for WarpArgs.src; im2w packed planar [B][noc][h][w].
+// out [B][8][noc][h][w]
+struct DerivArgs {
+  TvGeom t;
+  const float* im1;
+  int im1_padded, pad, tmp_w, tmp_h;
+  const float* im2w;
+  float* out;
+};
+hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s);
+
+// compute_smoothness + compute_data + sub_laplacian x2 -> sys [B][7][h][w]
+struct SystemArgs {
+  TvGeom t;
+  const float* mask;
+  const float* wx;
+  const float* wy;
+  const float* du;
+  const float* dv;
+  const float* derivs;
+  float quarter_alpha, half_delta_over3, half_gamma_over3;
+  float* sys;
+};
+hipError_t launch_tv_system(const SystemArgs& a, hipStream_t s);
+
+// sor_coupled
+struct SorArgs {
+  TvGeom t;
+  const float* sys;  // [B][7][h][w]: a11,a12,a22,b1,b2,sh,sv
+  float* du;
+  float* dv;
+  int iterations;
+  float omega;
+};
+hipError_t launch_sor(const SorArgs& a, hipStream_t s);
+
+// uu=wx+du, vv=wy+dv -> AoS flow (refine_variational.cpp:209-221, 92-99)
+hipError_t launch_tv_finish(const TvGeom& t, const float* wx, const float* wy, const float* du, const float* dv,
+                            float* flow_aos, hipStream_t s);
+// AoS flow -> planar wx, wy (refine_variational.cpp:56-68)
+hipError_t launch_flow_split(const TvGeom& t, const float* flow_aos, float* wx, float* wy, hipStream_t s);
+
+// test hook: out[i] = wave_sum over each consecutive group of 64 inputs (n multiple of 64)
+hipError_t launch_wave_sum_test(const float* in, float* out, int n, hipStream_t s);
+
+}  // namespace ofdis

@@ -1,0 +1,406 @@
+// ofdis_tv.hip -- FDF1.0.1 TV-L1 refinement kernels for gfx950 (everything except the SOR sweep).
+//
+//   warp_kernel        image_warp            opticalflow_aux.c:18-60
+//   derivatives_kernel get_derivatives       opticalflow_aux.c:65-116 (+ image.c:401-434,466-502)
+//   tv_system_kernel   compute_smoothness + compute_data + 2x sub_laplacian fused
+//                                            opticalflow_aux.c:123-199, 310-438 (+ image.c:376-399,436-464)
+//   tv_finish_kernel   uu=wx+du, vv=wy+dv -> AoS      refine_variational.cpp:209-221, 92-99
+//   flow_split_kernel  AoS -> planar                  refine_variational.cpp:56-68
+//
+// All kernels are batched over frames (blockIdx / flat index carries the frame), planes are packed
+// row-major [frame][...][h][w].  The stencil kernels stage a tile plus halo in LDS; the border
+// rules of the reference (replicated columns, folded coefficients on the first/last rows) are
+// applied per stage exactly as the reference applies them per convolution call.
+#include "ofdis_kernels.h"
+
+namespace ofdis {
+
+// ------------------------------------------------------------------------------------------ warp
+template <bool PADDED>
+__global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a) {
+  const int w = a.t.w, h = a.t.h, noc = a.t.noc;
+  const int npx = w * h;
+  const long long total = (long long)npx * a.t.nframes;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int frame = (int)(idx / npx);
+    const int o = (int)(idx - (long long)frame * npx);
+    const int j = o / w, i = o - j * w;
+    const float xx = i + a.wx[idx];
+    const float yy = j + a.wy[idx];
+    const float fxf = floorf(xx), fyf = floorf(yy);
+    const int x = (int)fxf, y = (int)fyf;
+    const float dx = xx - (float)x, dy = yy - (float)y;
+    a.mask[idx] = (xx >= 0 && xx <= (float)(w - 1) && yy >= 0 && yy <= (float)(h - 1)) ? 1.0f : 0.0f;
+    const int x1 = clampi(x, 0, w - 1), x2 = clampi(x + 1, 0, w - 1);
+    const int y1 = clampi(y, 0, h - 1), y2 = clampi(y + 1, 0, h - 1);
+    for (int c = 0; c < noc; ++c) {
+      float s11, s12, s21, s22;
+      if (PADDED) {
+        const float* s = a.src + (size_t)frame * a.tmp_w * a.tmp_h * noc;
+        s11 = s[((y1 + a.pad) * a.tmp_w + x1 + a.pad) * noc + c];
+        s12 = s[((y1 + a.pad) * a.tmp_w + x2 + a.pad) * noc + c];
+        s21 = s[((y2 + a.pad) * a.tmp_w + x1 + a.pad) * noc + c];
+        s22 = s[((y2 + a.pad) * a.tmp_w + x2 + a.pad) * noc + c];
+      } else {
+        const float* s = a.src + ((size_t)frame * noc + c) * npx;
+        s11 = s[y1 * w + x1];
+        s12 = s[y1 * w + x2];
+        s21 = s[y2 * w + x1];
+        s22 = s[y2 * w + x2];
+      }
+      a.dst[((size_t)frame * noc + c) * npx + o] =
+          s11 * (1.0f - dx) * (1.0f - dy) + s12 * dx * (1.0f - dy) + s21 * (1.0f - dx) * dy + s22 * dx * dy;
+    }
+  }
+}
+
+hipError_t launch_warp(const WarpArgs& a, hipStream_t s) {
+  const long long total = (long long)a.t.w * a.t.h * a.t.nframes;
+  long long blocks = (total + 255) / 256;
+  if (blocks > (1 << 20)) blocks = 1 << 20;
+  if (a.src_padded)
+    hipLaunchKernelGGL(warp_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(warp_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ derivatives
+// 5-tap derivative filter of refine_variational.cpp:45-46 through convolve_extract_coeffs(even=0)
+// (image.c:338-349): coeffs = { 1/12, -8/12, -0, 8/12, -1/12 }
+#define D5_C0 (1.0f / 12.0f)
+#define D5_C1 (-8.0f / 12.0f)
+#define D5_C2 (-0.0f)
+#define D5_C3 (-(-8.0f / 12.0f))
+#define D5_C4 (-(1.0f / 12.0f))
+
+constexpr int DT_W = 32, DT_H = 16;         // output tile
+constexpr int DA_W = DT_W + 8, DA_H = DT_H + 8;  // avg / Iz tile (halo 4)
+constexpr int DX_W = DT_W + 4, DX_H = DT_H + 4;  // Ix / Iy tile (halo 2)
+
+// horizontal 5-tap on an LDS tile whose entries are already border-replicated (image.c:466-502)
+__device__ __forceinline__ float h5(const float* t, int pitch, int qy, int qx) {
+  const float* r = t + qy * pitch + qx;
+  return D5_C0 * r[-2] + D5_C1 * r[-1] + D5_C2 * r[0] + D5_C3 * r[1] + D5_C4 * r[2];
+}
+// vertical 5-tap with the folded coefficients of the first/last two image rows (image.c:401-434);
+// j = image row of the output sample
+__device__ __forceinline__ float v5(const float* t, int pitch, int qy, int qx, int j, int h) {
+  const float* r = t + qy * pitch + qx;
+  const float m2 = r[-2 * pitch], m1 = r[-pitch], s0 = r[0], p1 = r[pitch], p2 = r[2 * pitch];
+  if (j == 0) return (D5_C0 + D5_C1 + D5_C2) * s0 + D5_C3 * p1 + D5_C4 * p2;
+  if (j == 1) return (D5_C0 + D5_C1) * m1 + D5_C2 * s0 + D5_C3 * p1 + D5_C4 * p2;
+  if (j == h - 2) return D5_C0 * m2 + D5_C1 * m1 + D5_C2 * s0 + (D5_C3 + D5_C4) * p1;
+  if (j == h - 1) return D5_C0 * m2 + D5_C1 * m1 + (D5_C2 + D5_C3 + D5_C4) * s0;
+  return D5_C0 * m2 + D5_C1 * m1 + D5_C2 * s0 + D5_C3 * p1 + D5_C4 * p2;
+}
+
+template <bool PADDED>
+__global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
+  __shared__ float avg_t[DA_H * DA_W];
+  __shared__ float iz_t[DA_H * DA_W];
+  __shared__ float ix_t[DX_H * DX_W];
+  __shared__ float iy_t[DX_H * DX_W];
+  const int w = a.t.w, h = a.t.h, noc = a.t.noc;
+  const int npx = w * h;
+  const int tiles_x = (w + DT_W - 1) / DT_W;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int frame = blockIdx.y;
+  const int x0 = tx * DT_W, y0 = ty * DT_H;
+  const int tid = threadIdx.x;
+
+  for (int c = 0; c < noc; ++c) {
+    // stage 0: avg = 0.5*(im2w + im1), Iz = im2w - im1 on tile + halo 4, at border-clamped coordinates
+    for (int n = tid; n < DA_H * DA_W; n += 256) {
+      const int qy = n / DA_W, qx = n - qy * DA_W;
+      const int y = clampi(y0 + qy - 4, 0, h - 1), x = clampi(x0 + qx - 4, 0, w - 1);
+      float i1;
+      if (PADDED)
+        i1 = a.im1[(size_t)frame * a.tmp_w * a.tmp_h * noc + ((size_t)(y + a.pad) * a.tmp_w + x + a.pad) * noc + c];
+      else
+        i1 = a.im1[((size_t)frame * noc + c) * npx + y * w + x];
+      const float i2 = a.im2w[((size_t)frame * noc + c) * npx + y * w + x];
+      avg_t[n] = 0.5f * (i2 + i1);
+      iz_t[n] = i2 - i1;
+    }
+    __syncthreads();
+    // stage 1: Ix = d/dx avg, Iy = d/dy avg on tile + halo 2.  An entry outside the image holds the
+    // value of the nearest image pixel (that is what the second convolution's replication reads).
+    for (int n = tid; n < DX_H * DX_W; n += 256) {
+      const int qy = n / DX_W, qx = n - qy * DX_W;
+      const int y = clampi(y0 + qy - 2, 0, h - 1), x = clampi(x0 + qx - 2, 0, w - 1);
+      const int ay = y - y0 + 4, ax = x - x0 + 4;  // position inside the avg tile
+      ix_t[n] = h5(avg_t, DA_W, ay, ax);
+      iy_t[n] = v5(avg_t, DA_W, ay, ax, y, h);
+    }
+    __syncthreads();
+    // stage 2: outputs
+    {
+      const int qy = tid / DT_W, qx = tid - qy * DT_W;
+      for (int ry = qy; ry < DT_H; ry += 256 / DT_W) {
+        const int y = y0 + ry, x = x0 + qx;
+        if (y < h && x < w) {
+          const int ey = ry + 2, ex = qx + 2;    // in Ix/Iy tile
+          const int ay = ry + 4, ax = qx + 4;    // in avg/Iz tile
+          float* out = a.out + ((size_t)frame * 8 * noc + c) * npx + y * w + x;
+          const size_t ks = (size_t)noc * npx;
+          out[0 * ks] = ix_t[ey * DX_W + ex];
+          out[1 * ks] = iy_t[ey * DX_W + ex];
+          out[2 * ks] = iz_t[ay * DA_W + ax];
+          out[3 * ks] = h5(ix_t, DX_W, ey, ex);
+          out[4 * ks] = v5(ix_t, DX_W, ey, ex, y, h);
+          out[5 * ks] = v5(iy_t, DX_W, ey, ex, y, h);
+          out[6 * ks] = h5(iz_t, DA_W, ay, ax);
+          out[7 * ks] = v5(iz_t, DA_W, ay, ax, y, h);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s) {
+  if (a.t.h < 4) return hipErrorInvalidValue;  // the reference's vertical filter reads rows 0..3
+  const int tiles = ((a.t.w + DT_W - 1) / DT_W) * ((a.t.h + DT_H - 1) / DT_H);
+  if (a.im1_padded)
+    hipLaunchKernelGGL(derivatives_kernel<true>, dim3(tiles, a.t.nframes), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(derivatives_kernel<false>, dim3(tiles, a.t.nframes), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ TV system
+// 3-tap flow derivative of refine_variational.cpp:47-48: coeffs = { -0.5, -0, 0.5 }
+#define D3_C0 (-0.5f)
+#define D3_C1 (-0.0f)
+#define D3_C2 (0.5f)
+#define EPS_SMOOTH (0.001f * 0.001f)
+#define EPS_COLOR (0.001f * 0.001f)
+#define EPS_GRAD (0.001f * 0.001f)
+#define DATANORM (0.1f * 0.1f)
+
+constexpr int ST_W = 32, ST_H = 16;
+constexpr int SU_W = ST_W + 4, SU_H = ST_H + 4;  // uu/vv/wx/wy tile (halo 2)
+constexpr int SS_W = ST_W + 2, SS_H = ST_H + 2;  // smoothness tile (halo 1)
+
+__device__ __forceinline__ float v3(const float* t, int pitch, int qy, int qx, int j, int h) {
+  const float* r = t + qy * pitch + qx;
+  if (j == 0) return (D3_C0 + D3_C1) * r[0] + D3_C2 * r[pitch];
+  if (j == h - 1) return D3_C0 * r[-pitch] + (D3_C1 + D3_C2) * r[0];
+  return D3_C0 * r[-pitch] + D3_C1 * r[0] + D3_C2 * r[pitch];
+}
+__device__ __forceinline__ float h3(const float* t, int pitch, int qy, int qx) {
+  const float* r = t + qy * pitch + qx;
+  return D3_C0 * r[-1] + D3_C1 * r[0] + D3_C2 * r[1];
+}
+
+// data term of one pixel (opticalflow_aux.c:342-427).  D(k,c): derivative plane k, channel c.
+template <typename DF>
+__device__ __forceinline__ void data_term(DF D, int noc, float m, float u, float v, float hd3, float hg3, float& a11,
+                                          float& a12, float& a22, float& b1, float& b2) {
+  a11 = 0.0f; a12 = 0.0f; a22 = 0.0f; b1 = 0.0f; b2 = 0.0f;
+  if (noc == 1) {
+    const float ix = D(0, 0), iy = D(1, 0), iz = D(2, 0), ixx = D(3, 0), ixy = D(4, 0), iyy = D(5, 0), ixz = D(6, 0),
+                iyz = D(7, 0);
+    float tmp, tmp2, n1, n2;
+    if (hd3 != 0.0f) {
+      tmp = iz + ix * u + iy * v;
+      n1 = ix * ix + iy * iy + DATANORM;
+      tmp = m * hd3 / sqrtf(3 * tmp * tmp / n1 + EPS_COLOR);
+      tmp /= n1;
+      a11 += tmp * ix * ix;
+      a12 += tmp * ix * iy;
+      a22 += tmp * iy * iy;
+      b1 -= tmp * iz * ix;
+      b2 -= tmp * iz * iy;
+    }
+    n1 = ixx * ixx + ixy * ixy + DATANORM;
+    n2 = iyy * iyy + ixy * ixy + DATANORM;
+    tmp = ixz + ixx * u + ixy * v;
+    tmp2 = iyz + ixy * u + iyy * v;
+    tmp = m * hg3 / sqrtf(3 * tmp * tmp / n1 + 3 * tmp2 * tmp2 / n2 + EPS_GRAD);
+    tmp2 = tmp / n2;
+    tmp /= n1;
+    a11 += tmp * ixx * ixx + tmp2 * ixy * ixy;
+    a12 += tmp * ixx * ixy + tmp2 * ixy * iyy;
+    a22 += tmp2 * iyy * iyy + tmp * ixy * ixy;
+    b1 -= tmp * ixx * ixz + tmp2 * ixy * iyz;
+    b2 -= tmp2 * iyy * iyz + tmp * ixy * ixz;
+    a11 *= 3; a12 *= 3; a22 *= 3; b1 *= 3; b2 *= 3;
+  } else {
+    float ix[3], iy[3], iz[3], ixx[3], ixy[3], iyy[3], ixz[3], iyz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ix[c] = D(0, c); iy[c] = D(1, c); iz[c] = D(2, c); ixx[c] = D(3, c);
+      ixy[c] = D(4, c); iyy[c] = D(5, c); ixz[c] = D(6, c); iyz[c] = D(7, c);
+    }
+    if (hd3 != 0.0f) {
+      float t[3], nn[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        t[c] = iz[c] + ix[c] * u + iy[c] * v;
+        nn[c] = ix[c] * ix[c] + iy[c] * iy[c] + DATANORM;
+      }
+      float tmp = m * hd3 / sqrtf(t[0] * t[0] / nn[0] + t[1] * t[1] / nn[1] + t[2] * t[2] / nn[2] + EPS_COLOR);
+      const float tt[3] = {tmp / nn[0], tmp / nn[1], tmp / nn[2]};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        a11 += tt[c] * ix[c] * ix[c];
+        a12 += tt[c] * ix[c] * iy[c];
+        a22 += tt[c] * iy[c] * iy[c];
+        b1 -= tt[c] * iz[c] * ix[c];
+        b2 -= tt[c] * iz[c] * iy[c];
+      }
+    }
+    float n1[3], n2[3], t1[3], t2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      n1[c] = ixx[c] * ixx[c] + ixy[c] * ixy[c] + DATANORM;
+      n2[c] = iyy[c] * iyy[c] + ixy[c] * ixy[c] + DATANORM;
+      t1[c] = ixz[c] + ixx[c] * u + ixy[c] * v;
+      t2[c] = iyz[c] + ixy[c] * u + iyy[c] * v;
+    }
+    const float tmp = m * hg3 /
+                      sqrtf(t1[0] * t1[0] / n1[0] + t2[0] * t2[0] / n2[0] + t1[1] * t1[1] / n1[1] +
+                            t2[1] * t2[1] / n2[1] + t1[2] * t1[2] / n1[2] + t2[2] * t2[2] / n2[2] + EPS_GRAD);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float w1 = tmp / n1[c], w2 = tmp / n2[c];
+      a11 += w1 * ixx[c] * ixx[c] + w2 * ixy[c] * ixy[c];
+      a12 += w1 * ixx[c] * ixy[c] + w2 * ixy[c] * iyy[c];
+      a22 += w2 * iyy[c] * iyy[c] + w1 * ixy[c] * ixy[c];
+      b1 -= w1 * ixx[c] * ixz[c] + w2 * ixy[c] * iyz[c];
+      b2 -= w2 * iyy[c] * iyz[c] + w1 * ixy[c] * ixz[c];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tv_system_kernel(const SystemArgs a) {
+  __shared__ float uu_t[SU_H * SU_W];
+  __shared__ float vv_t[SU_H * SU_W];
+  __shared__ float wx_t[SU_H * SU_W];
+  __shared__ float wy_t[SU_H * SU_W];
+  __shared__ float s_t[SS_H * SS_W];
+  const int w = a.t.w, h = a.t.h, noc = a.t.noc;
+  const int npx = w * h;
+  const int tiles_x = (w + ST_W - 1) / ST_W;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int frame = blockIdx.y;
+  const int x0 = tx * ST_W, y0 = ty * ST_H;
+  const int tid = threadIdx.x;
+  const size_t fo = (size_t)frame * npx;
+
+  // stage 0: uu = wx + du, vv = wy + dv (refine_variational.cpp:210-216) on tile + halo 2, clamped
+  for (int n = tid; n < SU_H * SU_W; n += 256) {
+    const int qy = n / SU_W, qx = n - qy * SU_W;
+    const int y = clampi(y0 + qy - 2, 0, h - 1), x = clampi(x0 + qx - 2, 0, w - 1);
+    const size_t o = fo + y * w + x;
+    const float fx = a.wx[o], fy = a.wy[o];
+    wx_t[n] = fx;
+    wy_t[n] = fy;
+    uu_t[n] = fx + a.du[o];
+    vv_t[n] = fy + a.dv[o];
+  }
+  __syncthreads();
+  // stage 1: smoothness = quarter_alpha / sqrt(|grad uu|^2 + |grad vv|^2 + eps) on tile + halo 1
+  // (opticalflow_aux.c:128-140); only in-image entries are ever read back.
+  for (int n = tid; n < SS_H * SS_W; n += 256) {
+    const int qy = n / SS_W, qx = n - qy * SS_W;
+    const int y = y0 + qy - 1, x = x0 + qx - 1;
+    float sval = 0.0f;
+    if (y >= 0 && y < h && x >= 0 && x < w) {
+      const int uy_ = qy + 1, ux_ = qx + 1;  // position in the uu tile
+      const float ux = h3(uu_t, SU_W, uy_, ux_), vx = h3(vv_t, SU_W, uy_, ux_);
+      const float uy = v3(uu_t, SU_W, uy_, ux_, y, h), vy = v3(vv_t, SU_W, uy_, ux_, y, h);
+      sval = a.quarter_alpha / sqrtf(ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH);
+    }
+    s_t[n] = sval;
+  }
+  __syncthreads();
+  // stage 2: per pixel -- data term, then the Laplacian of the CURRENT flow (wx, wy) subtracted from
+  // the right-hand side in the reference's scatter order: -left, +right, -top, +bottom
+  // (opticalflow_aux.c:172-199).
+  const int qx = tid % ST_W;
+  for (int ry = tid / ST_W; ry < ST_H; ry += 256 / ST_W) {
+    const int y = y0 + ry, x = x0 + qx;
+    if (y >= h || x >= w) continue;
+    const size_t o = fo + y * w + x;
+    const int sy = ry + 1, sx = qx + 1;  // in s tile
+    const int uy_ = ry + 2, ux_ = qx + 2;  // in wx tile
+    const float sc = s_t[sy * SS_W + sx];
+    const float sh_c = (x < w - 1) ? sc + s_t[sy * SS_W + sx + 1] : 0.0f;      // opticalflow_aux.c:150-154
+    const float sv_c = (y < h - 1) ? sc + s_t[(sy + 1) * SS_W + sx] : 0.0f;    // :158-163
+    float a11, a12, a22, b1, b2;
+    const float* dbase = a.derivs + (size_t)frame * 8 * noc * npx + (size_t)y * w + x;
+    auto D = [&](int k, int c) { return dbase[((size_t)k * noc + c) * npx]; };
+    data_term(D, noc, a.mask[o], a.du[o], a.dv[o], a.half_delta_over3, a.half_gamma_over3, a11, a12, a22, b1, b2);
+    const float wxc = wx_t[uy_ * SU_W + ux_], wyc = wy_t[uy_ * SU_W + ux_];
+    if (x > 0) {
+      const float sh_l = s_t[sy * SS_W + sx - 1] + sc;
+      b1 -= sh_l * (wxc - wx_t[uy_ * SU_W + ux_ - 1]);
+      b2 -= sh_l * (wyc - wy_t[uy_ * SU_W + ux_ - 1]);
+    }
+    if (x < w - 1) {
+      b1 += sh_c * (wx_t[uy_ * SU_W + ux_ + 1] - wxc);
+      b2 += sh_c * (wy_t[uy_ * SU_W + ux_ + 1] - wyc);
+    }
+    if (y > 0) {
+      const float sv_t = s_t[(sy - 1) * SS_W + sx] + sc;
+      b1 -= sv_t * (wxc - wx_t[(uy_ - 1) * SU_W + ux_]);
+      b2 -= sv_t * (wyc - wy_t[(uy_ - 1) * SU_W + ux_]);
+    }
+    if (y < h - 1) {
+      b1 += sv_c * (wx_t[(uy_ + 1) * SU_W + ux_] - wxc);
+      b2 += sv_c * (wy_t[(uy_ + 1) * SU_W + ux_] - wyc);
+    }
+    float* out = a.sys + (size_t)frame * 7 * npx + (size_t)y * w + x;
+    out[0 * (size_t)npx] = a11;
+    out[1 * (size_t)npx] = a12;
+    out[2 * (size_t)npx] = a22;
+    out[3 * (size_t)npx] = b1;
+    out[4 * (size_t)npx] = b2;
+    out[5 * (size_t)npx] = sh_c;
+    out[6 * (size_t)npx] = sv_c;
+  }
+}
+
+hipError_t launch_tv_system(const SystemArgs& a, hipStream_t s) {
+  const int tiles = ((a.t.w + ST_W - 1) / ST_W) * ((a.t.h + ST_H - 1) / ST_H);
+  hipLaunchKernelGGL(tv_system_kernel, dim3(tiles, a.t.nframes), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ finish / split
+__global__ __launch_bounds__(256) void tv_finish_kernel(long long total, const float* wx, const float* wy,
+                                                        const float* du, const float* dv, float2* flow) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    flow[i] = make_float2(wx[i] + du[i], wy[i] + dv[i]);
+}
+hipError_t launch_tv_finish(const TvGeom& t, const float* wx, const float* wy, const float* du, const float* dv,
+                            float* flow_aos, hipStream_t s) {
+  const long long total = (long long)t.w * t.h * t.nframes;
+  long long blocks = (total + 255) / 256;
+  if (blocks > (1 << 20)) blocks = 1 << 20;
+  hipLaunchKernelGGL(tv_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, total, wx, wy, du, dv,
+                     reinterpret_cast<float2*>(flow_aos));
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void flow_split_kernel(long long total, const float2* flow, float* wx, float* wy) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const float2 f = flow[i];
+    wx[i] = f.x;
+    wy[i] = f.y;
+  }
+}
+hipError_t launch_flow_split(const TvGeom& t, const float* flow_aos, float* wx, float* wy, hipStream_t s) {
+  const long long total = (long long)t.w * t.h * t.nframes;
+  long long blocks = (total + 255) / 256;
+  if (blocks > (1 << 20)) blocks = 1 << 20;
+  hipLaunchKernelGGL(flow_split_kernel, dim3((unsigned)blocks), dim3(256), 0, s, total,
+                     reinterpret_cast<const float2*>(flow_aos), wx, wy);
+  return hipGetLastError();
+}
+
+}  // namespace ofdis

@@ -1,0 +1,40 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _gpu_available():
+    try:
+        from of_dis_amd import capi
+        return capi.lib().ofdis_device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """The HIP library on a box with a GPU.  No fallback: a missing library is a failure, not a skip."""
+    from of_dis_amd import capi
+    L = capi.lib()  # raises if libofdis_hip.so is missing
+    if L.ofdis_device_count() < 1:
+        pytest.skip("no HIP device visible")
+    return capi
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """C restatement in the wave64 reduction order (the order the HIP kernels use)."""
+    import oracle
+    o = oracle.c_oracle()
+    o.set_reduce_order(True)
+    return o

@@ -1,0 +1,158 @@
+"""-m gpu: every HIP kernel against the oracle on the same seeded inputs, through the C ABI.
+
+Bar: bit-exact.  The path is fp32 with separately rounded operations in the reference's order, and the
+oracle (C restatement, pinned bit-for-bit to the reference compiled in place -- test_oracle_vs_ref.py)
+is switched to the 64-lane butterfly reduction order the kernels use.
+"""
+import numpy as np
+import pytest
+
+from common import assert_bits_equal, rand_planes, synth_case
+
+pytestmark = pytest.mark.gpu
+_f32 = np.float32
+
+
+def test_wave_sum_order(gpu, orc):
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((37, 64)) * 100).astype(_f32)
+    got = gpu.wave_sum_test(x)
+    for r in range(x.shape[0]):
+        part = x[r].copy()
+        o = 1
+        while o < 64:
+            part[0::2 * o] = part[0::2 * o] + part[o::2 * o]
+            o *= 2
+        assert np.all(got[r] == part[0]), (r, got[r][:4], part[0])
+
+
+@pytest.mark.parametrize("w,h,noc", [(128, 56, 1), (64, 28, 1), (32, 14, 1), (30, 17, 3), (67, 33, 1), (5, 4, 1)])
+def test_image_warp(gpu, orc, w, h, noc):
+    rng = np.random.default_rng(1)
+    B = 3
+    src = rand_planes(rng, B, noc, h, w, scale=50)
+    wx = rand_planes(rng, B, h, w, scale=3)
+    wy = rand_planes(rng, B, h, w, scale=3)
+    wx[0, 0, :4] = [-0.0, 0.0, 1.0, -1.0]          # exact-integer and border cases
+    wx[0, 1, :3] = [w + 5.0, -w - 5.0, 0.5]
+    wy[0, 2, :3] = [h + 5.0, -h - 5.0, h - 1.0]
+    dst, mask = gpu.image_warp(src, wx, wy)
+    for b in range(B):
+        rd, rm = orc.image_warp(src[b], wx[b], wy[b])
+        assert_bits_equal(dst[b], rd.reshape(noc, h, w), f"warp dst frame {b}")
+        assert_bits_equal(mask[b], rm, f"warp mask frame {b}")
+
+
+@pytest.mark.parametrize("w,h,noc", [(128, 56, 1), (32, 14, 1), (30, 17, 3), (67, 33, 1), (5, 4, 1), (40, 5, 1)])
+def test_get_derivatives(gpu, orc, w, h, noc):
+    rng = np.random.default_rng(2)
+    B = 2
+    im1 = rand_planes(rng, B, noc, h, w, scale=60)
+    im2 = rand_planes(rng, B, noc, h, w, scale=60)
+    got = gpu.get_derivatives(im1, im2)
+    for b in range(B):
+        ref = orc.get_derivatives(im1[b], im2[b])
+        assert_bits_equal(got[b], ref, f"derivatives frame {b}")
+
+
+def _tv_inputs(rng, B, noc, h, w):
+    mask = (rng.random((B, h, w)) > 0.1).astype(_f32)
+    wx = rand_planes(rng, B, h, w, scale=2)
+    wy = rand_planes(rng, B, h, w, scale=2)
+    du = rand_planes(rng, B, h, w, scale=0.3)
+    dv = rand_planes(rng, B, h, w, scale=0.3)
+    derivs = rand_planes(rng, B, 8, noc, h, w, scale=20)
+    return mask, wx, wy, du, dv, derivs
+
+
+def _oracle_system(orc, p_alpha, p_gamma, p_delta, mask, wx, wy, du, dv, derivs):
+    qa = _f32(0.25) * _f32(p_alpha)
+    hg = _f32(p_gamma) * _f32(0.5) / _f32(3.0)
+    hd = _f32(p_delta) * _f32(0.5) / _f32(3.0)
+    sh, sv = orc.compute_smoothness(wx + du, wy + dv, qa)
+    sys5 = orc.compute_data(mask, du, dv, derivs, hd, hg)
+    b1 = orc.sub_laplacian(sys5[3], wx, sh, sv)
+    b2 = orc.sub_laplacian(sys5[4], wy, sh, sv)
+    return np.stack([sys5[0], sys5[1], sys5[2], b1, b2, sh, sv])
+
+
+@pytest.mark.parametrize("w,h,noc", [(128, 56, 1), (32, 14, 1), (30, 17, 3), (67, 33, 1), (5, 4, 1), (2, 2, 1)])
+def test_tv_system(gpu, orc, w, h, noc):
+    rng = np.random.default_rng(3)
+    B = 2
+    mask, wx, wy, du, dv, derivs = _tv_inputs(rng, B, noc, h, w)
+    got = gpu.tv_system(mask, wx, wy, du, dv, derivs, 10.0, 10.0, 5.0)
+    for b in range(B):
+        ref = _oracle_system(orc, 10.0, 10.0, 5.0, mask[b], wx[b], wy[b], du[b], dv[b], derivs[b])
+        assert_bits_equal(got[b], ref, f"tv_system frame {b}")
+
+
+def _spd_system(rng, B, h, w):
+    a11 = (rng.random((B, h, w)) * 5 + 0.5).astype(_f32)
+    a22 = (rng.random((B, h, w)) * 5 + 0.5).astype(_f32)
+    a12 = ((rng.random((B, h, w)) - 0.5) * 0.8).astype(_f32)
+    b1 = rand_planes(rng, B, h, w)
+    b2 = rand_planes(rng, B, h, w)
+    sh = (rng.random((B, h, w)) * 3 + 0.1).astype(_f32)
+    sv = (rng.random((B, h, w)) * 3 + 0.1).astype(_f32)
+    sh[:, :, -1] = 0            # what compute_smoothness guarantees (opticalflow_aux.c:154,163)
+    sv[:, -1, :] = 0
+    return np.stack([a11, a12, a22, b1, b2, sh, sv], 1)
+
+
+@pytest.mark.parametrize("w,h,iters", [(128, 56, 3), (64, 28, 3), (32, 14, 3), (20, 15, 3), (40, 30, 1), (80, 60, 2),
+                                        (128, 64, 4), (7, 5, 3), (2, 2, 3), (1, 5, 2), (30, 17, 5), (16, 70, 3),
+                                        (33, 3, 3)])
+def test_sor_coupled(gpu, orc, w, h, iters):
+    rng = np.random.default_rng(4)
+    B = 5
+    sys = _spd_system(rng, B, h, w)
+    du = rand_planes(rng, B, h, w, scale=0.2)
+    dv = rand_planes(rng, B, h, w, scale=0.2)
+    gu, gv = gpu.sor_coupled(du, dv, sys, iters, 1.6)
+    for b in range(B):
+        ru, rv, _, _, _ = orc.sor_coupled(du[b], dv[b], sys[b, 0], sys[b, 1], sys[b, 2], sys[b, 3], sys[b, 4],
+                                          sys[b, 5], sys[b, 6], iters, 1.6)
+        assert_bits_equal(gu[b], ru, f"sor du frame {b}")
+        assert_bits_equal(gv[b], rv, f"sor dv frame {b}")
+
+
+def test_sor_arbitrary_border_weights(gpu, orc):
+    """sh/sv NOT zeroed on the last column/row: the reference still ignores the missing neighbours."""
+    rng = np.random.default_rng(5)
+    B, h, w = 2, 14, 32
+    sys = _spd_system(rng, B, h, w)
+    sys[:, 5, :, -1] = 0.7
+    sys[:, 6, -1, :] = 0.9
+    du = rand_planes(rng, B, h, w, scale=0.2)
+    dv = rand_planes(rng, B, h, w, scale=0.2)
+    gu, gv = gpu.sor_coupled(du, dv, sys, 3, 1.6)
+    for b in range(B):
+        ru, rv, _, _, _ = orc.sor_coupled(du[b], dv[b], *[sys[b, k] for k in range(7)], 3, 1.6)
+        assert_bits_equal(gu[b], ru, "sor du")
+        assert_bits_equal(gv[b], rv, "sor dv")
+
+
+@pytest.mark.parametrize("size,opp,tv", [((1024, 436), 2, 1), ((640, 480), 2, 1), ((1024, 436), 1, 0)])
+def test_patchgrid_levels(gpu, orc, size, opp, tv):
+    p, pa, pb, _, _ = synth_case(size[0], size[1], 1234, 1, opp, tv)
+    prev = None
+    for l in range(p.sc_f, p.sc_l - 1, -1):
+        rp, rflow = orc.patchgrid_level(p, l, pa[0][l], pa[1][l], pa[2][l], pb[0][l], prev)
+        gp, gflow = gpu.patchgrid_level(p, l, pa[0][l][None], pa[1][l][None], pa[2][l][None], pb[0][l][None],
+                                        None if prev is None else prev[None])
+        assert_bits_equal(gp[0], rp, f"patch displacements level {l}")
+        assert_bits_equal(gflow[0], rflow, f"dense flow level {l}")
+        prev = rflow
+
+
+@pytest.mark.parametrize("size", [(1024, 436), (640, 480)])
+def test_varref_levels(gpu, orc, size):
+    p, pa, pb, _, _ = synth_case(size[0], size[1], 1234, 1, 2, 1)
+    rng = np.random.default_rng(6)
+    for l in range(p.sc_f, p.sc_l - 1, -1):
+        w, h = p.level_size(l)
+        flow = rand_planes(rng, h, w, 2, scale=1.5)
+        ref = orc.varref_level(p, l, pa[0][l], pb[0][l], flow)
+        got = gpu.varref_level(p, l, pa[0][l][None], pb[0][l][None], flow[None])
+        assert_bits_equal(got[0], ref, f"varref level {l}")
