@@ -166,6 +166,7 @@ void* ofdis_dev_alloc(size_t bytes);
 void ofdis_dev_free(void* p);
 int ofdis_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int ofdis_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int ofdis_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 int ofdis_sync(void* stream);
 
 #ifdef __cplusplus

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "ofdis_batch_upload", "ofdis_batch_build_pyramids_u8", "ofdis_batch_run", "ofdis_batch_flow",
     "ofdis_batch_level_flow", "ofdis_batch_download", "ofdis_batch_timing", "ofdis_batch_kernel_time",
     "ofdis_image_warp", "ofdis_get_derivatives", "ofdis_tv_system", "ofdis_sor_coupled", "ofdis_patchgrid_level",
-    "ofdis_varref_level", "ofdis_dev_alloc", "ofdis_dev_free", "ofdis_memcpy_h2d", "ofdis_memcpy_d2h", "ofdis_sync",
+    "ofdis_varref_level", "ofdis_dev_alloc", "ofdis_dev_free", "ofdis_memcpy_h2d", "ofdis_memcpy_d2h", "ofdis_memcpy_d2d", "ofdis_sync",
 ]
 
 
@@ -53,6 +53,7 @@ def lib():
         L.ofdis_memcpy_h2d.argtypes = [VP, VP, C.c_size_t]
         L.ofdis_memcpy_d2h.argtypes = [VP, VP, C.c_size_t]
         L.ofdis_sync.argtypes = [VP]
+        L.ofdis_memcpy_d2d.argtypes = [VP, VP, C.c_size_t, VP]
         L.ofdis_batch_create.argtypes = [C.POINTER(VP), C.POINTER(OfdisParams), C.c_int]
         L.ofdis_batch_destroy.argtypes = [VP]
         L.ofdis_batch_input.restype = VP

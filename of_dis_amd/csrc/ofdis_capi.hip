@@ -101,6 +101,7 @@ struct ofdis_batch {
   float *pvec = nullptr, *pweight = nullptr;
   float *wx = nullptr, *wy = nullptr, *du = nullptr, *dv = nullptr, *mask = nullptr;
   float *w_im2 = nullptr, *derivs = nullptr, *sys = nullptr;
+  std::vector<float*> pyr_tmp;       // unpadded level images (ofdis_batch_build_pyramids_u8), lazily allocated
   std::vector<void*> allocs;
   // timing
   bool timing = false;
@@ -131,15 +132,15 @@ struct KTimer {  // brackets one launch with events when timing is on
     auto& v = b->ev[k];
     if (b->ev_used[k] == v.size()) {
       EventPair e;
-      hipEventCreate(&e.a);
-      hipEventCreate(&e.b);
+      (void)hipEventCreate(&e.a);
+      (void)hipEventCreate(&e.b);
       v.push_back(e);
     }
     ep = &v[b->ev_used[k]++];
-    hipEventRecord(ep->a, s);
+    (void)hipEventRecord(ep->a, s);
   }
   ~KTimer() {
-    if (ep) hipEventRecord(ep->b, s);
+    if (ep) (void)hipEventRecord(ep->b, s);
   }
 };
 
@@ -305,11 +306,11 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
 
 void ofdis_batch_destroy(ofdis_batch* b) {
   if (!b) return;
-  for (void* d : b->allocs) hipFree(d);
+  for (void* d : b->allocs) (void)hipFree(d);
   for (int k = 0; k < OFDIS_K_COUNT; ++k)
     for (auto& e : b->ev[k]) {
-      hipEventDestroy(e.a);
-      hipEventDestroy(e.b);
+      (void)hipEventDestroy(e.a);
+      (void)hipEventDestroy(e.b);
     }
   delete b;
 }
@@ -342,8 +343,38 @@ int ofdis_batch_upload(ofdis_batch* b, int frame, const float* const* im_a, cons
 
 int ofdis_batch_build_pyramids_u8(ofdis_batch* b, const uint8_t* img_a, const uint8_t* img_b, int width_org,
                                   int height_org, void* stream) {
-  (void)b; (void)img_a; (void)img_b; (void)width_org; (void)height_org; (void)stream;
-  return fail(OFDIS_ERR_UNSUPPORTED, "on-device pyramid construction is not built yet (SURVEY.md 8f-1)");
+  if (!b || !img_a || !img_b) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  const ofdis_params& p = b->p;
+  // the padded size must be what run_dense.cpp:298-305 derives from the original size
+  const int sc = 1 << p.sc_f;
+  if (width_org < 1 || height_org < 1 || width_org > p.width || height_org > p.height || p.width - width_org >= sc ||
+      p.height - height_org >= sc)
+    return fail(OFDIS_ERR_INVALID, "params.width/height are not the 2^sc_f padding of the original size");
+  if (p.sc_f > 8) return fail(OFDIS_ERR_UNSUPPORTED, "exact fp32 pyramid needs sc_f <= 8");
+  hipStream_t s = (hipStream_t)stream;
+  if (b->pyr_tmp.empty()) {
+    b->pyr_tmp.assign(b->nlevels, nullptr);
+    for (int i = 0; i < b->nlevels; ++i) {
+      const LevelGeom& g = b->geom[i];
+      int rc = dalloc(b, &b->pyr_tmp[i], (size_t)g.w * g.h * g.noc * b->nframes);
+      if (rc) return rc;
+    }
+  }
+  for (int which = 0; which < 2; ++which) {
+    const uint8_t* src = which ? img_b : img_a;
+    for (int i = 0; i < b->nlevels; ++i) {
+      const LevelGeom& g = b->geom[i];
+      if (i == 0)
+        HIPCHK(launch_pyr_base(src, b->pyr_tmp[0], b->nframes, width_org, height_org, p.width, p.height, p.noc, p.sc_l, s));
+      else
+        HIPCHK(launch_pyr_down(b->pyr_tmp[i - 1], b->pyr_tmp[i], b->nframes, b->geom[i - 1].w, b->geom[i - 1].h, p.noc, s));
+      if (which == 0)
+        HIPCHK(launch_pyr_planes(b->pyr_tmp[i], b->in[0][i], b->in[1][i], b->in[2][i], b->nframes, g.w, g.h, p.noc, g.pad, s));
+      else
+        HIPCHK(launch_pyr_planes(b->pyr_tmp[i], b->in[3][i], nullptr, nullptr, b->nframes, g.w, g.h, p.noc, g.pad, s));
+    }
+  }
+  return OFDIS_OK;
 }
 
 // The coarse-to-fine loop of OFClass::OFClass (oflow.cpp:184-337), every stage batched over frames.
@@ -354,7 +385,7 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
   const int verbose = p.verbosity;
   double t_all0 = 0;
   if (verbose > 0) {
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
     t_all0 = now_ms();
   }
   if (verbose > 1) printf("TIME (Grid Memo. Alloc. ) (ms): %3g\n", 0.0);  // buffers live in the batch context
@@ -363,7 +394,7 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
     const LevelGeom& g = b->geom[ii];
     double tt[5] = {0, 0, 0, 0, 0};
     double t0 = 0;
-    if (verbose > 1) { hipStreamSynchronize(s); t0 = now_ms(); }
+    if (verbose > 1) { (void)hipStreamSynchronize(s); t0 = now_ms(); }
     // steps 1-3: patch grid construction, initialisation from the coarser flow and the inverse
     // search run as ONE kernel (pconst/pinit are reported as 0, poptim carries the time)
     {
@@ -378,7 +409,7 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
       a.pweight = b->pweight;
       HIPCHK(launch_patch_optimize(a, s));
     }
-    if (verbose > 1) { hipStreamSynchronize(s); tt[2] = now_ms() - t0; t0 = now_ms(); }
+    if (verbose > 1) { (void)hipStreamSynchronize(s); tt[2] = now_ms() - t0; t0 = now_ms(); }
     // step 4: densification
     {
       KTimer kt(b, OFDIS_K_DENSIFY, s);
@@ -391,21 +422,21 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
       if (p.usetvref) { d.wx = b->wx; d.wy = b->wy; } else d.flow_aos = b->flow[ii];
       HIPCHK(launch_densify(d, s));
     }
-    if (verbose > 1) { hipStreamSynchronize(s); tt[3] = now_ms() - t0; t0 = now_ms(); }
+    if (verbose > 1) { (void)hipStreamSynchronize(s); tt[3] = now_ms() - t0; t0 = now_ms(); }
     // step 5: variational refinement
     if (p.usetvref) {
       int rc = run_varref(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s);
       if (rc) return rc;
     }
     if (verbose > 1) {
-      hipStreamSynchronize(s);
+      (void)hipStreamSynchronize(s);
       tt[4] = now_ms() - t0;
       printf("TIME (Sc: %i, #p:%6i, pconst, pinit, poptim, cflow, tvopt, total): %8.2f %8.2f %8.2f %8.2f %8.2f -> %8.2f ms.\n",
              sl, g.nop, tt[0], tt[1], tt[2], tt[3], tt[4], tt[0] + tt[1] + tt[2] + tt[3] + tt[4]);
     }
   }
   if (verbose > 0) {
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
     printf("TIME (O.Flow Run-Time   ) (ms): %3g\n", now_ms() - t_all0);
     fflush(stdout);
   }
@@ -514,7 +545,7 @@ int ofdis_patchgrid_level(const ofdis_params* p, int level, const float* im_a, c
   float *pv = nullptr, *pw = nullptr;
   HIPCHK(hipMalloc((void**)&pv, (size_t)g.nop * 2 * nframes * sizeof(float)));
   hipError_t e = hipMalloc((void**)&pw, (size_t)g.nop * g.novals * nframes * sizeof(float));
-  if (e != hipSuccess) { hipFree(pv); return hipfail(e, "hipMalloc"); }
+  if (e != hipSuccess) { (void)hipFree(pv); return hipfail(e, "hipMalloc"); }
   DisArgs a = dis_args(*p, g, nframes);
   a.im_a = im_a; a.im_a_dx = im_a_dx; a.im_a_dy = im_a_dy; a.im_b = im_b;
   a.flow_prev = flow_prev;
@@ -530,8 +561,8 @@ int ofdis_patchgrid_level(const ofdis_params* p, int level, const float* im_a, c
   if (e == hipSuccess && p_out)
     e = hipMemcpyAsync(p_out, pv, (size_t)g.nop * 2 * nframes * sizeof(float), hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  hipFree(pv);
-  hipFree(pw);
+  (void)hipFree(pv);
+  (void)hipFree(pw);
   if (e != hipSuccess) return hipfail(e, "ofdis_patchgrid_level");
   return OFDIS_OK;
 }
@@ -566,7 +597,7 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   if (!rc) rc = run_varref(&b, g, im_a, im_b, flow, s);
   hipError_t e = hipStreamSynchronize(s);
   if (!rc && e != hipSuccess) rc = hipfail(e, "sync");
-  for (void* d : b.allocs) hipFree(d);
+  for (void* d : b.allocs) (void)hipFree(d);
   b.allocs.clear();
   return rc;
 }
@@ -583,13 +614,17 @@ void* ofdis_dev_alloc(size_t bytes) {
   if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return nullptr;
   return d;
 }
-void ofdis_dev_free(void* p) { hipFree(p); }
+void ofdis_dev_free(void* p) { (void)hipFree(p); }
 int ofdis_memcpy_h2d(void* dst, const void* src, size_t bytes) {
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return OFDIS_OK;
 }
 int ofdis_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return OFDIS_OK;
+}
+int ofdis_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return OFDIS_OK;
 }
 int ofdis_sync(void* stream) {

@@ -95,6 +95,13 @@ hipError_t launch_tv_finish(const TvGeom& t, const float* wx, const float* wy, c
 // AoS flow -> planar wx, wy (refine_variational.cpp:56-68)
 hipError_t launch_flow_split(const TvGeom& t, const float* flow_aos, float* wx, float* wy, hipStream_t s);
 
+// on-device pyramid (ofdis_pyr.hip; run_dense.cpp:130-178,298-311 restated)
+hipError_t launch_pyr_base(const uint8_t* src, float* dst, int nframes, int wo, int ho, int W, int H, int noc, int l,
+                           hipStream_t s);
+hipError_t launch_pyr_down(const float* src, float* dst, int nframes, int w, int h, int noc, hipStream_t s);
+hipError_t launch_pyr_planes(const float* src, float* img, float* dx, float* dy, int nframes, int w, int h, int noc,
+                             int pad, hipStream_t s);
+
 // test hook: out[i] = wave_sum over each consecutive group of 64 inputs (n multiple of 64)
 hipError_t launch_wave_sum_test(const float* in, float* out, int n, hipStream_t s);
 

@@ -1,0 +1,137 @@
+// ofdis_pyr.hip -- on-device image pyramid from raw 8-bit frames, i.e. the part of
+// run_dense.cpp that feeds OFClass: replicate-pad to a multiple of 2^sc_f (run_dense.cpp:298-311),
+// convertTo float (326-327), ConstructImgPyramide (130-178): cv::resize x0.5 INTER_LINEAR per level,
+// cv::Sobel(ksize 3, scale 1/8, BORDER_DEFAULT), copyMakeBorder(REPLICATE for images, CONSTANT 0 for
+// gradients) by imgpadding.
+//
+// Exactness.  For 8-bit input every level-l value is the mean of a 2^l x 2^l block of integers: a
+// dyadic rational with at most 8+2l significant bits, exactly representable in fp32 for l <= 8, and
+// every Sobel/8 value likewise (3 more bits).  All fp32 sums involved are therefore exact, so the
+// hierarchical 2x2 means OpenCV computes, an integer block sum scaled by 4^-l, and any summation
+// order give bit-identical results.  Only levels sc_l..sc_f are materialised (the reference builds
+// all of 0..sc_f, run_dense.cpp:132, and never reads the rest), and image B gets no gradients (never
+// read when usefbcon == 0).
+#include "ofdis_kernels.h"
+
+namespace ofdis {
+
+// level `l` image (unpadded, [B][h][w][noc] float) straight from the u8 frames
+__global__ __launch_bounds__(256) void pyr_base_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                       int nframes, int wo, int ho, int W, int H, int noc, int l) {
+  const int w = W >> l, h = H >> l;
+  const int left = (W - wo) / 2, top = (H - ho) / 2;  // floor(pad/2) on the left/top (run_dense.cpp:308)
+  const long long total = (long long)nframes * h * w * noc;
+  const int bs = 1 << l;
+  const float scale = 1.0f / (float)(1 << (2 * l));
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % noc);
+    long long r = idx / noc;
+    const int x = (int)(r % w);
+    r /= w;
+    const int y = (int)(r % h);
+    const int f = (int)(r / h);
+    const uint8_t* s = src + (size_t)f * wo * ho * noc;
+    unsigned sum = 0;
+    for (int yy = 0; yy < bs; ++yy) {
+      const int sy = clampi(y * bs + yy - top, 0, ho - 1);
+      for (int xx = 0; xx < bs; ++xx) {
+        const int sx = clampi(x * bs + xx - left, 0, wo - 1);
+        sum += s[((size_t)sy * wo + sx) * noc + c];
+      }
+    }
+    dst[idx] = (float)sum * scale;
+  }
+}
+
+// next coarser level: 2x2 mean (cv::resize(.5,.5,INTER_LINEAR))
+__global__ __launch_bounds__(256) void pyr_down_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       int nframes, int w, int h, int noc) {
+  const int w2 = w / 2, h2 = h / 2;
+  const long long total = (long long)nframes * h2 * w2 * noc;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % noc);
+    long long r = idx / noc;
+    const int x = (int)(r % w2);
+    r /= w2;
+    const int y = (int)(r % h2);
+    const int f = (int)(r / h2);
+    const float* s = src + (size_t)f * w * h * noc;
+    const float a = s[((size_t)(2 * y) * w + 2 * x) * noc + c], b = s[((size_t)(2 * y) * w + 2 * x + 1) * noc + c];
+    const float cc = s[((size_t)(2 * y + 1) * w + 2 * x) * noc + c], d = s[((size_t)(2 * y + 1) * w + 2 * x + 1) * noc + c];
+    dst[idx] = ((a + b) + (cc + d)) * 0.25f;
+  }
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+  }
+  return i;
+}
+
+// padded planes of one level: image (replicate border) and, if dx != nullptr, Sobel/8 gradients
+// (zero border)
+__global__ __launch_bounds__(256) void pyr_planes_kernel(const float* __restrict__ src, float* __restrict__ img,
+                                                         float* __restrict__ dx, float* __restrict__ dy, int nframes,
+                                                         int w, int h, int noc, int pad) {
+  const int tw = w + 2 * pad, th = h + 2 * pad;
+  const long long total = (long long)nframes * th * tw * noc;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % noc);
+    long long r = idx / noc;
+    const int X = (int)(r % tw);
+    r /= tw;
+    const int Y = (int)(r % th);
+    const int f = (int)(r / th);
+    const float* s = src + (size_t)f * w * h * noc;
+    const int x = X - pad, y = Y - pad;
+    img[idx] = s[((size_t)clampi(y, 0, h - 1) * w + clampi(x, 0, w - 1)) * noc + c];
+    if (dx) {
+      float gx = 0.0f, gy = 0.0f;
+      if (x >= 0 && x < w && y >= 0 && y < h) {
+        float v[3][3];
+#pragma unroll
+        for (int j = -1; j <= 1; ++j)
+#pragma unroll
+          for (int i = -1; i <= 1; ++i)
+            v[j + 1][i + 1] = s[((size_t)reflect101(y + j, h) * w + reflect101(x + i, w)) * noc + c];
+        gx = ((v[0][2] - v[0][0]) + 2.0f * (v[1][2] - v[1][0]) + (v[2][2] - v[2][0])) * 0.125f;
+        gy = ((v[2][0] - v[0][0]) + 2.0f * (v[2][1] - v[0][1]) + (v[2][2] - v[0][2])) * 0.125f;
+      }
+      dx[idx] = gx;
+      dy[idx] = gy;
+    }
+  }
+}
+
+static unsigned grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > (1 << 20)) b = 1 << 20;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+hipError_t launch_pyr_base(const uint8_t* src, float* dst, int nframes, int wo, int ho, int W, int H, int noc, int l,
+                           hipStream_t s) {
+  const long long total = (long long)nframes * (H >> l) * (W >> l) * noc;
+  hipLaunchKernelGGL(pyr_base_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, dst, nframes, wo, ho, W, H, noc, l);
+  return hipGetLastError();
+}
+hipError_t launch_pyr_down(const float* src, float* dst, int nframes, int w, int h, int noc, hipStream_t s) {
+  const long long total = (long long)nframes * (h / 2) * (w / 2) * noc;
+  hipLaunchKernelGGL(pyr_down_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, dst, nframes, w, h, noc);
+  return hipGetLastError();
+}
+hipError_t launch_pyr_planes(const float* src, float* img, float* dx, float* dy, int nframes, int w, int h, int noc,
+                             int pad, hipStream_t s) {
+  const long long total = (long long)nframes * (h + 2 * pad) * (w + 2 * pad) * noc;
+  hipLaunchKernelGGL(pyr_planes_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, img, dx, dy, nframes, w, h, noc, pad);
+  return hipGetLastError();
+}
+
+}  // namespace ofdis
