@@ -287,8 +287,21 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
     for (int gx = gx_lo; gx <= gx_hi; ++gx)
       for (int gy = gy_lo; gy <= gy_hi; ++gy) {
         const int ip = gx * g.noph + gy;
-        const int kx = x - (gx * st + g.offw) - lb, ky = y - (gy * st + g.offh) - lb;
-        const float* pw = pwf + (size_t)ip * g.novals + (ky * P + kx) * noc;
+        const int rxi = gx * st + g.offw, ryi = gy * st + g.offh;
+        const int kx = x - rxi - lb, ky = y - ryi - lb;
+        // The reference walks pweight with a RUNNING pointer: +1 per visited patch pixel and, for RGB,
+        // +2 more only for pixels inside the image (patchgrid.cpp:242,256-257), so for RGB patches that
+        // overlap the border the entries are shifted.  Closed form of that pointer for pixel (kx,ky):
+        int pidx;
+        if (noc == 1) {
+          pidx = ky * P + kx;
+        } else {
+          const int left_out = max(0, -(rxi + lb)), right_out = max(0, rxi + ub - (g.w - 1));
+          const int top_out = max(0, -(ryi + lb));
+          const int in_row = P - left_out - right_out;
+          pidx = top_out * P + (ky - top_out) * (3 * in_row + (P - in_row)) + left_out + (kx - left_out) * 3;
+        }
+        const float* pw = pwf + (size_t)ip * g.novals + pidx;
         float absw;
         if (noc == 1) {
           absw = 1.0f / fmaxf(2.0f, pw[0]);

@@ -716,18 +716,22 @@ int oracle_patchgrid_level(const ofdis_params* p, int level, const float* im_a, 
         const int ip = gx * noph + gy;
         const float* pweight = pw_all + (size_t)ip * nv;
         const float rx = (float)(gx * steps + offw), ry = (float)(gy * steps + offh);
+        /* pweight is a RUNNING pointer in the reference: +1 per visited pixel (loop header,
+         * patchgrid.cpp:242) and, for RGB, +2 more only when the pixel lies inside the image
+         * (patchgrid.cpp:256-257).  For RGB patches that overlap the image border the weights are
+         * therefore read from shifted entries; reproduced literally. */
         for (int y = lb; y <= ub; ++y)
-          for (int x = lb; x <= ub; ++x, pweight += noc) {
+          for (int x = lb; x <= ub; ++x, ++pweight) {
             const int yt = (int)(y + ry), xt = (int)(x + rx);
             if (xt >= 0 && yt >= 0 && xt < w && yt < h) {
               const int i = yt * w + xt;
               float absw;
               if (noc == 1) {
-                absw = 1.0f / (float)(fmaxf(minerrval, pweight[0]));
+                absw = 1.0f / (float)(fmaxf(minerrval, *pweight));
               } else {
-                absw = (float)(fmaxf(minerrval, pweight[0]));
-                absw += (float)(fmaxf(minerrval, pweight[1]));
-                absw += (float)(fmaxf(minerrval, pweight[2]));
+                absw = (float)(fmaxf(minerrval, *pweight)); ++pweight;
+                absw += (float)(fmaxf(minerrval, *pweight)); ++pweight;
+                absw += (float)(fmaxf(minerrval, *pweight));
                 absw = 1.0f / absw;
               }
               we[i] += absw;

@@ -11,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "tools")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: long-running case")
 
 
 def _gpu_available():

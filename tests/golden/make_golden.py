@@ -1,0 +1,95 @@
+"""Generates tests/golden/*.npz from the REFERENCE ITSELF (oracle/_ref: the unmodified reference
+sources compiled in place from /root/reference by oracle/Makefile).  Run in the authoring container:
+
+    python tests/golden/make_golden.py
+
+The vectors pin the oracle restatement (tests/test_golden.py, CPU) and the HIP path (-m gpu) on boxes
+where /root/reference does not exist.  Inputs are seeded synthetic frames (tools/gen_synth.py);
+everything needed to replay a case (8-bit frames, parameters) is stored next to the expected outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import gen_synth  # noqa: E402
+import oracle  # noqa: E402
+from of_dis_amd.params import oppoint  # noqa: E402
+
+_f32 = np.float32
+
+
+def flow_case(name, w, h, seed, channels, op_point, **over):
+    ia, ib, _ = gen_synth.make_pair(w, h, seed, channels)
+    p = oppoint(op_point, w, h, noc=channels).copy(**over)
+    O = oracle.c_oracle()  # host pyramid (exact for 8-bit input; checked against numpy in test_golden.py)
+    pa, pb = O.build_pyramid(p, ia), O.build_pyramid(p, ib)
+    kind = "int" if channels == 1 else "rgb"
+    out = {"img_a": ia, "img_b": ib, "size": np.array([w, h]),
+           "params": np.array([getattr(p, n) for n, _ in p._fields_], np.float64),
+           "param_names": np.array([n for n, _ in p._fields_])}
+    for wave64 in (False, True):
+        R = oracle.ref(kind, wave64)
+        tag = "w64" if wave64 else "seq"
+        out[f"flow_{tag}"] = R.flow(p, pa[0], pa[1], pa[2], pb[0])
+        prev = None
+        for l in range(p.sc_f, p.sc_l - 1, -1):  # per-level chain: DIS -> (TV) -> next level
+            pp, fl = R.patchgrid_level(p, l, pa[0][l], pa[1][l], pa[2][l], pb[0][l], prev)
+            out[f"p_l{l}_{tag}"] = pp
+            out[f"dis_l{l}_{tag}"] = fl
+            if p.usetvref:
+                fl = R.varref_level(p, l, pa[0][l], pb[0][l], fl)
+            out[f"lvl_l{l}_{tag}"] = fl
+            prev = fl
+        assert np.array_equal(prev, out[f"flow_{tag}"])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items() if k.startswith("flow")})
+
+
+def kernel_vectors():
+    """FDF1.0.1 functions on small random planes (gray 32x14 and rgb 30x17)."""
+    out = {}
+    for kind, noc, w, h in (("int", 1, 32, 14), ("rgb", 3, 30, 17)):
+        R = oracle.ref(kind, False)
+        rng = np.random.default_rng(99 + noc)
+        t = f"{kind}_"
+        src = (rng.standard_normal((noc, h, w)) * 50).astype(_f32)
+        im2 = (rng.standard_normal((noc, h, w)) * 50).astype(_f32)
+        wx = (rng.standard_normal((h, w)) * 3).astype(_f32)
+        wy = (rng.standard_normal((h, w)) * 3).astype(_f32)
+        du = (rng.standard_normal((h, w)) * 0.3).astype(_f32)
+        dv = (rng.standard_normal((h, w)) * 0.3).astype(_f32)
+        out.update({t + "src": src, t + "im2": im2, t + "wx": wx, t + "wy": wy, t + "du": du, t + "dv": dv})
+        dst, mask = R.image_warp(src, wx, wy)
+        out[t + "warp_dst"], out[t + "warp_mask"] = dst.reshape(noc, h, w), mask
+        d = R.get_derivatives(src, im2)
+        out[t + "derivs"] = d
+        qa, hd, hg = _f32(2.5), _f32(5.0) * _f32(0.5) / _f32(3.0), _f32(10.0) * _f32(0.5) / _f32(3.0)
+        sh, sv = R.compute_smoothness(wx + du, wy + dv, qa)
+        out[t + "sh"], out[t + "sv"] = sh, sv
+        s5 = R.compute_data(mask, du, dv, d, hd, hg)
+        out[t + "data"] = s5
+        b1 = R.sub_laplacian(s5[3], wx, sh, sv)
+        b2 = R.sub_laplacian(s5[4], wy, sh, sv)
+        out[t + "b1"], out[t + "b2"] = b1, b2
+        u, v, i11, i12, i22 = R.sor_coupled(du, dv, s5[0], s5[1], s5[2], b1, b2, sh, sv, 3, 1.6)
+        out[t + "sor_du"], out[t + "sor_dv"] = u, v
+        out[t + "sor_inv"] = np.stack([i11, i12, i22])
+    np.savez_compressed(os.path.join(HERE, "fdf_kernels.npz"), **out)
+    print("fdf_kernels", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    if not os.path.isdir("/root/reference"):
+        raise SystemExit("needs /root/reference (authoring container)")
+    oracle.build()
+    kernel_vectors()
+    flow_case("op2_gray_256x128", 256, 128, 2024, 1, 2)
+    flow_case("op2_gray_320x200_notv_l1", 320, 200, 2025, 1, 2, usetvref=0, costfct=1)
+    flow_case("op3_rgb_192x96_l1", 192, 96, 2026, 3, 3, costfct=1, max_iter=6, min_iter=6)

@@ -1,0 +1,108 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ofdis.h declares; host-side parameter
+logic (operating points, geometry) matches the reference's derivations.  No compute calls (no GPU here)."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from of_dis_amd import capi
+from of_dis_amd.params import OfdisParams, auto_first_scale, oppoint, padded_size
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "ofdis.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ofdis_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_functions() == sorted(capi.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    for name in _declared_functions():
+        assert hasattr(L, name), f"{name} declared in include/ofdis.h but not exported"
+    assert L.ofdis_version() == 1
+
+
+def test_params_struct_layout_matches_header():
+    src = open(os.path.join(ROOT, "include", "ofdis.h")).read()
+    body = re.search(r"typedef struct ofdis_params \{(.*?)\} ofdis_params;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        typ, names = decl.split(None, 1)
+        fields += [(n.strip(), typ) for n in names.split(",")]
+    assert [n for n, _ in fields] == [n for n, _ in OfdisParams._fields_]
+    for (n, typ), (_, ct) in zip(fields, OfdisParams._fields_):
+        assert (typ == "float") == (ct is C.c_float), n
+    assert C.sizeof(OfdisParams) == 4 * len(fields)
+
+
+@pytest.mark.parametrize("op", [1, 2, 3, 4])
+@pytest.mark.parametrize("width", [1024, 640, 1920, 320])
+def test_oppoint_table_matches_c_abi(op, width):
+    """ofdis_params_oppoint (C++) and params.oppoint (Python) both restate run_dense.cpp:225-265."""
+    q = OfdisParams()
+    capi.check(capi.lib().ofdis_params_oppoint(C.byref(q), op, width, 1))
+    p = oppoint(op, width, 436, verbosity=2)
+    for name in ("sc_f", "sc_l", "max_iter", "min_iter", "p_samp_s", "usetvref", "imgpadding", "costfct", "patnorm",
+                 "usefbcon", "tv_innerit", "tv_solverit", "verbosity", "noc"):
+        assert getattr(p, name) == getattr(q, name), name
+    for name in ("dp_thresh", "dr_thresh", "res_thresh", "patove", "tv_alpha", "tv_gamma", "tv_delta", "tv_sor"):
+        assert np.float32(getattr(p, name)) == np.float32(getattr(q, name)), name
+
+
+def test_readme_operating_point_2():
+    """README.md:51-67: op-point 2 == `5 3 12 12 0.05 0.95 0 8 0.40 0 1 0 1 10 10 5 1 3 1.6 2` at width 1024."""
+    p = oppoint(2, 1024, 436, verbosity=2)
+    assert (p.sc_f, p.sc_l, p.max_iter, p.min_iter) == (5, 3, 12, 12)
+    assert (p.p_samp_s, p.usefbcon, p.patnorm, p.costfct, p.usetvref) == (8, 0, 1, 0, 1)
+    assert (p.tv_innerit, p.tv_solverit, p.verbosity) == (1, 3, 2)
+    assert np.float32(p.patove) == np.float32(0.4) and np.float32(p.tv_sor) == np.float32(1.6)
+    assert (p.width, p.height) == (1024, 448)
+    assert auto_first_scale(1024, 5, 8) == 5
+
+
+def test_geometry_matches_survey_table():
+    """level sizes and patch counts of the BASELINE configs."""
+    p = oppoint(2, 1024, 436)
+    assert [p.level_size(l) for l in (5, 4, 3)] == [(32, 14), (64, 28), (128, 56)]
+    assert p.steps == 4
+    assert [p.grid(l)[0] * p.grid(l)[1] for l in (5, 4, 3)] == [32, 112, 448]
+    p = oppoint(2, 640, 480)
+    assert (p.width, p.height) == (640, 480)
+    assert [p.level_size(l) for l in (5, 4, 3)] == [(20, 15), (40, 30), (80, 60)]
+    assert [p.grid(l)[0] * p.grid(l)[1] for l in (5, 4, 3)] == [20, 80, 300]
+    assert oppoint(1, 1024, 436).steps == 5          # 8*(1-0.3f) = 5.6 -> 5
+    assert oppoint(4, 1920, 1080, noc=3).steps == 3  # 12*(1-0.75f) = 3
+    assert padded_size(1920, 1080, 6) == (1920, 1088)
+
+
+def test_status_codes_without_a_gpu():
+    """Argument validation happens before any device work, so it is testable here."""
+    L = capi.lib()
+    h = C.c_void_p()
+    p = oppoint(2, 1024, 436)
+    for bad, code in ((p.copy(usefbcon=1), -2), (p.copy(width=1000), -1), (p.copy(imgpadding=4), -1),
+                      (p.copy(noc=2), -1), (p.copy(sc_l=6), -1), (p.copy(costfct=10), -2)):
+        rc = L.ofdis_batch_create(C.byref(h), C.byref(bad), 4)
+        assert rc == code, (bad.as_dict(), rc, L.ofdis_last_error())
+        assert L.ofdis_last_error()
+    assert L.ofdis_batch_create(C.byref(h), C.byref(p), 0) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libofdis_hip.so")
+    with pytest.raises(capi.OfdisError):
+        capi.lib()
