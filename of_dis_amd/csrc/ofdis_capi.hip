@@ -514,22 +514,53 @@ int ofdis_get_derivatives(float* out, const float* im1, const float* im2w, int w
   return OFDIS_OK;
 }
 
+// The public per-function interface is row-major; the solver's operands are converted to / from the
+// internal diag layout here (temporary buffers; these entry points are for parity tests and single-stage use).
 int ofdis_tv_system(float* out, const float* mask, const float* wx, const float* wy, const float* du,
                     const float* dv, const float* derivs, float tv_alpha, float tv_gamma, float tv_delta, int w,
                     int h, int noc, int nframes, void* stream) {
-  if (!out || !mask || !wx || !wy || !du || !dv || !derivs || w < 1 || h < 1) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  if (!out || !mask || !wx || !wy || !du || !dv || !derivs || w < 1 || h < 1 || nframes < 1)
+    return fail(OFDIS_ERR_INVALID, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t npx = (size_t)w * h * nframes;
+  float* tmp = nullptr;  // du_d, dv_d, sys_d
+  HIPCHK(hipMalloc((void**)&tmp, npx * 9 * sizeof(float)));
+  float *du_d = tmp, *dv_d = tmp + npx, *sys_d = tmp + 2 * npx;
   const TvConsts c = tv_consts(tv_alpha, tv_gamma, tv_delta);
-  SystemArgs a{TvGeom{w, h, noc, nframes}, mask, wx, wy, du, dv, derivs, c.quarter_alpha, c.half_delta_over3,
-               c.half_gamma_over3, out};
-  HIPCHK(launch_tv_system(a, (hipStream_t)stream));
+  hipError_t e = launch_to_diag(du, du_d, w, h, nframes, s);
+  if (e == hipSuccess) e = launch_to_diag(dv, dv_d, w, h, nframes, s);
+  if (e == hipSuccess) {
+    SystemArgs a{TvGeom{w, h, noc, nframes}, mask, wx, wy, du_d, dv_d, derivs, c.quarter_alpha, c.half_delta_over3,
+                 c.half_gamma_over3, sys_d};
+    e = launch_tv_system(a, s);
+  }
+  if (e == hipSuccess) e = launch_from_diag(sys_d, out, w, h, (long long)nframes * 7, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return hipfail(e, "ofdis_tv_system");
   return OFDIS_OK;
 }
 
 int ofdis_sor_coupled(float* du, float* dv, const float* sys, int iterations, float omega, int w, int h,
                       int nframes, void* stream) {
   if (!du || !dv || !sys || w < 1 || h < 1 || nframes < 1) return fail(OFDIS_ERR_INVALID, "bad arguments");
-  SorArgs a{TvGeom{w, h, 1, nframes}, sys, du, dv, iterations, omega};
-  HIPCHK(launch_sor(a, (hipStream_t)stream));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t npx = (size_t)w * h * nframes;
+  float* tmp = nullptr;
+  HIPCHK(hipMalloc((void**)&tmp, npx * 9 * sizeof(float)));
+  float *du_d = tmp, *dv_d = tmp + npx, *sys_d = tmp + 2 * npx;
+  hipError_t e = launch_to_diag(du, du_d, w, h, nframes, s);
+  if (e == hipSuccess) e = launch_to_diag(dv, dv_d, w, h, nframes, s);
+  if (e == hipSuccess) e = launch_to_diag(sys, sys_d, w, h, (long long)nframes * 7, s);
+  if (e == hipSuccess) {
+    SorArgs a{TvGeom{w, h, 1, nframes}, sys_d, du_d, dv_d, iterations, omega};
+    e = launch_sor(a, s);
+  }
+  if (e == hipSuccess) e = launch_from_diag(du_d, du, w, h, nframes, s);
+  if (e == hipSuccess) e = launch_from_diag(dv_d, dv, w, h, nframes, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return hipfail(e, "ofdis_sor_coupled");
   return OFDIS_OK;
 }
 

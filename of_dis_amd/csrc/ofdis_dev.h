@@ -71,4 +71,10 @@ __device__ __forceinline__ float wave_sum(float x) {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// "diag" plane layout used for the SOR solver's operands (7 system planes, du, dv): pixel (x,y) of a
+// w x h plane lives at ((x+y) mod w)*h + y, i.e. wrapped anti-diagonal d = (x+y) mod w is ONE
+// contiguous row of h floats (a bijection onto w*h, no padding).  The wavefront SOR reads/writes
+// one such row per step (ofdis_sor.hip).
+__host__ __device__ __forceinline__ int diag_index(int x, int y, int w, int h) { return ((x + y) % w) * h + y; }
+
 }  // namespace ofdis

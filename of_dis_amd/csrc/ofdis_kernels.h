@@ -64,13 +64,13 @@ struct DerivArgs {
 };
 hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s);
 
-// compute_smoothness + compute_data + sub_laplacian x2 -> sys [B][7][h][w]
+// compute_smoothness + compute_data + sub_laplacian x2 -> sys [B][7][w*h] in DIAG layout (ofdis_dev.h)
 struct SystemArgs {
   TvGeom t;
-  const float* mask;
-  const float* wx;
+  const float* mask;   // row-major [B][h][w]
+  const float* wx;     // row-major
   const float* wy;
-  const float* du;
+  const float* du;     // DIAG layout [B][w*h]
   const float* dv;
   const float* derivs;
   float quarter_alpha, half_delta_over3, half_gamma_over3;
@@ -78,18 +78,23 @@ struct SystemArgs {
 };
 hipError_t launch_tv_system(const SystemArgs& a, hipStream_t s);
 
-// sor_coupled
+// sor_coupled; every operand in DIAG layout
 struct SorArgs {
   TvGeom t;
-  const float* sys;  // [B][7][h][w]: a11,a12,a22,b1,b2,sh,sv
-  float* du;
+  const float* sys;  // [B][7][w*h]: a11,a12,a22,b1,b2,sh,sv
+  float* du;         // [B][w*h]
   float* dv;
   int iterations;
   float omega;
 };
 hipError_t launch_sor(const SorArgs& a, hipStream_t s);
 
-// uu=wx+du, vv=wy+dv -> AoS flow (refine_variational.cpp:209-221, 92-99)
+// layout conversion of `nplanes` planes of w x h (row-major <-> diag); used by the per-function entry
+// points, whose public interface is row-major
+hipError_t launch_to_diag(const float* src_rm, float* dst_diag, int w, int h, long long nplanes, hipStream_t s);
+hipError_t launch_from_diag(const float* src_diag, float* dst_rm, int w, int h, long long nplanes, hipStream_t s);
+
+// uu=wx+du, vv=wy+dv -> AoS flow (refine_variational.cpp:209-221, 92-99); wx,wy row-major, du,dv DIAG
 hipError_t launch_tv_finish(const TvGeom& t, const float* wx, const float* wy, const float* du, const float* dv,
                             float* flow_aos, hipStream_t s);
 // AoS flow -> planar wx, wy (refine_variational.cpp:56-68)

@@ -17,112 +17,120 @@
 // once per call and the 2x2 block inverse of the first sweep (solver.c:113-120) never leaves
 // registers.  The per-pixel arithmetic is the reference's, operation for operation; the three row
 // classes of the reference (first / middle / last line) are selected per lane.
+//
+// Memory layout ("diag", ofdis_dev.h): the solver's operands -- the 7 system planes and du, dv --
+// are stored so that anti-diagonal d = (i+j) mod w is one contiguous row of h floats.  Step t then
+// reads row t mod w: 9 fully coalesced row loads per step instead of 9 x 64 scattered cache lines
+// (the row-major version of this kernel spent >90 % of its time in those gathers: profiles/r01_a).
+// Loads run PD steps ahead of their use through a register ring that also serves as the delay line
+// handing each pixel's coefficients from sweep 0 to the trailing sweeps.
 #include "ofdis_kernels.h"
 
 namespace ofdis {
 
-struct SorCoef {  // coefficients of one pixel as sweep 0 sees them, reused by the trailing sweeps
-  float i11, i12, i22, b1, b2, hr, hl, vb, vt;
+// One ring slot = everything the sweeps need about pixel (j, tau - j), tau = the step at which
+// sweep 0 reaches it.  a11/a12/a22 are overwritten by the block inverse when sweep 0 gets there.
+struct SorSlot {
+  float a11, a12, a22, b1, b2, sh, sv;  // loaded (diag row tau)
+  float dur, dvr;                       // initial du,dv of the right neighbour (diag row tau+1)
+  float hl, vt;                         // left / top edge weights, filled in at step tau
 };
 
-template <int NS>
+template <int NS, int PD>
 __global__ __launch_bounds__(256) void sor_wave_kernel(const SorArgs a, const int R) {
+  constexpr int LIFE = (2 * (NS - 1) > 1) ? 2 * (NS - 1) : 1;  // a slot is last read LIFE steps after tau
+  constexpr int RS = PD + LIFE + 1;                            // ring size = unroll factor
   const int w = a.t.w, h = a.t.h;
   const int npx = w * h;
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int G = 64 / R;  // frames per wavefront
+  if (wid * G >= a.t.nframes) return;  // whole wave idle (uniform)
   int f = wid * G + lane / R;
   const int jr = lane % R;
   const bool row_ok = (f < a.t.nframes) && (jr < h);
-  if (wid * G >= a.t.nframes) return;  // whole wave idle (uniform)
   if (f >= a.t.nframes) f = a.t.nframes - 1;
   const int j = jr < h ? jr : h - 1;
   const bool has_top = j > 0, has_bot = j < h - 1;
   const float omega = a.omega;
 
-  const float* __restrict__ sysr = a.sys + (size_t)f * 7 * npx + (size_t)j * w;
-  float* __restrict__ dur_ = a.du + (size_t)f * npx + (size_t)j * w;
-  float* __restrict__ dvr_ = a.dv + (size_t)f * npx + (size_t)j * w;
+  const float* __restrict__ sysf = a.sys + (size_t)f * 7 * npx + j;  // + k*npx + drow*h
+  float* __restrict__ duf = a.du + (size_t)f * npx + j;
+  float* __restrict__ dvf = a.dv + (size_t)f * npx + j;
 
-  constexpr int RING = 2 * NS;
-  SorCoef ring[RING];
+  SorSlot ring[RS];
+#pragma unroll
+  for (int r = 0; r < RS; ++r) ring[r] = SorSlot{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   float ru[NS], rv[NS];    // result of sweep s at the previous step
   float ru2[NS], rv2[NS];  // ... two steps ago (own-old of sweep s+1)
 #pragma unroll
   for (int s = 0; s < NS; ++s) { ru[s] = rv[s] = ru2[s] = rv2[s] = 0.0f; }
-#pragma unroll
-  for (int r = 0; r < RING; ++r) ring[r] = SorCoef{0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-  struct Raw { float a11, a12, a22, b1, b2, sh, sv, dur, dvr; };
-  auto load_raw = [&](int t) {  // values sweep 0 needs at step t: pixel (j, t-j) and du/dv of (j, t-j+1)
-    const int c = clampi(t - j, 0, w - 1), c1 = clampi(t - j + 1, 0, w - 1);
-    Raw r;
-    r.a11 = sysr[0 * (size_t)npx + c];
-    r.a12 = sysr[1 * (size_t)npx + c];
-    r.a22 = sysr[2 * (size_t)npx + c];
-    r.b1 = sysr[3 * (size_t)npx + c];
-    r.b2 = sysr[4 * (size_t)npx + c];
-    r.sh = sysr[5 * (size_t)npx + c];
-    r.sv = sysr[6 * (size_t)npx + c];
-    r.dur = dur_[c1];
-    r.dvr = dvr_[c1];
-    return r;
+  // diag row of step tau is tau mod w; rows are tracked incrementally (wave-uniform scalars)
+  auto load_slot = [&](SorSlot& sl, int drow, int drow1) {
+    const int o = drow * h;
+    sl.a11 = sysf[0 * (size_t)npx + o];
+    sl.a12 = sysf[1 * (size_t)npx + o];
+    sl.a22 = sysf[2 * (size_t)npx + o];
+    sl.b1 = sysf[3 * (size_t)npx + o];
+    sl.b2 = sysf[4 * (size_t)npx + o];
+    sl.sh = sysf[5 * (size_t)npx + o];
+    sl.sv = sysf[6 * (size_t)npx + o];
+    sl.dur = duf[drow1 * h];
+    sl.dvr = dvf[drow1 * h];
   };
+  auto next_row = [&](int r) { return (r + 1 == w) ? 0 : r + 1; };
+
+  // prologue: slots of steps 0..PD-1, and the step "-1" right-values (= own values of step 0)
+  int lrow = 0;  // diag row of the next step to be loaded
+#pragma unroll
+  for (int q = 0; q < PD; ++q) {
+    load_slot(ring[q], lrow, next_row(lrow));
+    lrow = next_row(lrow);
+  }
+  ring[RS - 1].dur = duf[0];  // pixel (j, 0 - j + ... ) of step -1: diag row 0
+  ring[RS - 1].dvr = dvf[0];
+  int srow = (w - ((2 * (NS - 1)) % w)) % w;  // diag row of the pixel finished at step 0 is (0 - 2(NS-1)) mod w
 
   const int tend = (w - 1) + (h - 1) + 2 * (NS - 1);
-  // own-old of sweep 0 at step t is the "right" value loaded for step t-1
-  float own_u, own_v;
-  {
-    const int c = clampi(0 - j, 0, w - 1);
-    own_u = dur_[c];
-    own_v = dvr_[c];
-  }
-  Raw cur = load_raw(0);
-  float prev_sh = 0.0f, prev_sv = 0.0f;  // sh(j,i-1) and this lane's sv at the previous step
-
-  for (int t0 = 0; t0 <= tend; t0 += RING) {
+  for (int t0 = 0; t0 <= tend; t0 += RS) {
 #pragma unroll
-    for (int u = 0; u < RING; ++u) {
-      const int t = t0 + u;
-      if (t > tend) break;
-      const Raw nxt = load_raw(t + 1);  // prefetch for the next step
-      // ---------------- sweep 0: build the coefficient record of pixel (j, i0) (first iteration,
-      // solver.c:112-120 / 167-173 / 219-225) and store it in the ring for the trailing sweeps
+    for (int u = 0; u < RS; ++u) {
+      const int t = t0 + u;  // up to RS-1 steps past tend are executed: every pixel is then out of range
+      // prefetch the slot of step t+PD
+      load_slot(ring[(u + PD) % RS], lrow, next_row(lrow));
+      lrow = next_row(lrow);
+      // ---------------- sweep 0 reaches pixel (j, i0): finish its slot (first iteration,
+      // solver.c:112-120 / 167-173 / 219-225: edge-weight sum, block inverse)
       {
         const int i0 = t - j;
-        SorCoef c;
-        c.hr = cur.sh;
-        c.hl = (i0 > 0) ? prev_sh : 0.0f;
-        c.vb = cur.sv;
-        c.vt = wave_from_prev(prev_sv);  // sv(j-1, i0): lane j-1 was at column i0 one step ago
-        c.b1 = cur.b1;
-        c.b2 = cur.b2;
-        float d = c.hl + c.hr;
+        SorSlot& c = ring[u];
+        const SorSlot& p = ring[(u + RS - 1) % RS];
+        c.hl = (i0 > 0) ? p.sh : 0.0f;
+        c.vt = wave_from_prev(p.sv);  // sv(j-1, i0): lane j-1 was at column i0 one step ago
+        float d = c.hl + c.sh;
         if (has_top) d = d + c.vt;
-        if (has_bot) d = d + c.vb;
-        const float A11 = cur.a22 + d, A22 = cur.a11 + d;
-        const float det = A11 * A22 - cur.a12 * cur.a12;
-        c.i11 = A11 / det;
-        c.i22 = A22 / det;
-        c.i12 = cur.a12 / (-det);
-        ring[u] = c;
-        prev_sh = cur.sh;
-        prev_sv = cur.sv;
+        if (has_bot) d = d + c.sv;
+        const float A11 = c.a22 + d, A22 = c.a11 + d;
+        const float det = A11 * A22 - c.a12 * c.a12;
+        c.a11 = A11 / det;
+        c.a22 = A22 / det;
+        c.a12 = c.a12 / (-det);
       }
       // ---------------- all sweeps advance one pixel
       float nu[NS], nv[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const int i = t - j - 2 * s;
-        const SorCoef& c = ring[(u - 2 * s + 2 * RING) % RING];
+        const SorSlot& c = ring[(u - 2 * s + 2 * RS) % RS];
         // own / right / bottom: values of the previous sweep (the initial du,dv for sweep 0)
         float ou, ov, rgu, rgv, bu, bv;
         if (s == 0) {
-          ou = own_u; ov = own_v;
-          rgu = cur.dur; rgv = cur.dvr;
-          bu = wave_from_next(cur.dur);  // lane j+1 is at column i-1: its "right" is (j+1, i)
-          bv = wave_from_next(cur.dvr);
+          const SorSlot& p = ring[(u + RS - 1) % RS];
+          ou = p.dur; ov = p.dvr;        // what was "right" one step ago
+          rgu = c.dur; rgv = c.dvr;
+          bu = wave_from_next(c.dur);    // lane j+1 is at column i-1: its "right" is (j+1, i)
+          bv = wave_from_next(c.dvr);
         } else {
           ou = ru2[s - 1]; ov = rv2[s - 1];
           rgu = ru[s - 1]; rgv = rv[s - 1];
@@ -133,39 +141,37 @@ __global__ __launch_bounds__(256) void sor_wave_kernel(const SorArgs a, const in
         // top / left: values of this sweep
         const float tu = wave_from_prev(ru[s]), tv = wave_from_prev(rv[s]);
         const float lu = ru[s], lv = rv[s];
-        float s1 = c.hr * rgu, s2 = c.hr * rgv;
+        float s1 = c.sh * rgu, s2 = c.sh * rgv;
         if (has_top) { s1 = s1 + c.vt * tu; s2 = s2 + c.vt * tv; }
-        if (has_bot) { s1 = s1 + c.vb * bu; s2 = s2 + c.vb * bv; }
+        if (has_bot) { s1 = s1 + c.sv * bu; s2 = s2 + c.sv * bv; }
         s1 = s1 + c.b1;
         s2 = s2 + c.b2;
         float B1 = s1, B2 = s2;
         if (i > 0) { B1 = c.hl * lu + s1; B2 = c.hl * lv + s2; }
-        nu[s] = ou + omega * (c.i11 * B1 + c.i12 * B2 - ou);
-        nv[s] = ov + omega * (c.i12 * B1 + c.i22 * B2 - ov);
+        nu[s] = ou + omega * (c.a11 * B1 + c.a12 * B2 - ou);
+        nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
       }
       // last sweep's pixel is final
       {
         const int i = t - j - 2 * (NS - 1);
         if (row_ok && i >= 0 && i < w) {
-          dur_[i] = nu[NS - 1];
-          dvr_[i] = nv[NS - 1];
+          duf[srow * h] = nu[NS - 1];
+          dvf[srow * h] = nv[NS - 1];
         }
+        srow = next_row(srow);
       }
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         ru2[s] = ru[s]; rv2[s] = rv[s];
         ru[s] = nu[s]; rv[s] = nv[s];
       }
-      own_u = cur.dur;
-      own_v = cur.dvr;
-      cur = nxt;
     }
   }
 }
 
 // Fallback for shapes the wavefront kernel does not cover (h > 64, more than 4 sweeps, degenerate
-// sizes): one thread per frame walks the image in raster order.  Correct for every input the
-// reference accepts, slow; only large-image configurations reach it.
+// sizes): one thread per frame walks the image in raster order (diag-layout operands).  Correct for
+// every input the reference accepts, slow; only large-image configurations reach it.
 __global__ void sor_serial_kernel(const SorArgs a) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= a.t.nframes) return;
@@ -175,16 +181,17 @@ __global__ void sor_serial_kernel(const SorArgs a) {
   float* du = a.du + (size_t)f * npx;
   float* dv = a.dv + (size_t)f * npx;
   const float omega = a.omega;
+#define DG(i, j) diag_index((i), (j), w, h)
   if (w < 2 || h < 2 || a.iterations < 1) {  // solver.c:80-83 -> sor_coupled_slow_but_readable (solver.c:19-72)
     for (int iter = 0; iter < a.iterations; ++iter)
       for (int j = 0; j < h; ++j)
         for (int i = 0; i < w; ++i) {
-          const int o = j * w + i;
+          const int o = DG(i, j);
           float sigma_u = 0.0f, sigma_v = 0.0f, sum_dpsis = 0.0f;
-          if (j > 0) { sigma_u -= sv[o - w] * du[o - w]; sigma_v -= sv[o - w] * dv[o - w]; sum_dpsis += sv[o - w]; }
-          if (i > 0) { sigma_u -= sh[o - 1] * du[o - 1]; sigma_v -= sh[o - 1] * dv[o - 1]; sum_dpsis += sh[o - 1]; }
-          if (j < h - 1) { sigma_u -= sv[o] * du[o + w]; sigma_v -= sv[o] * dv[o + w]; sum_dpsis += sv[o]; }
-          if (i < w - 1) { sigma_u -= sh[o] * du[o + 1]; sigma_v -= sh[o] * dv[o + 1]; sum_dpsis += sh[o]; }
+          if (j > 0) { const int q = DG(i, j - 1); sigma_u -= sv[q] * du[q]; sigma_v -= sv[q] * dv[q]; sum_dpsis += sv[q]; }
+          if (i > 0) { const int q = DG(i - 1, j); sigma_u -= sh[q] * du[q]; sigma_v -= sh[q] * dv[q]; sum_dpsis += sh[q]; }
+          if (j < h - 1) { const int q = DG(i, j + 1); sigma_u -= sv[o] * du[q]; sigma_v -= sv[o] * dv[q]; sum_dpsis += sv[o]; }
+          if (i < w - 1) { const int q = DG(i + 1, j); sigma_u -= sh[o] * du[q]; sigma_v -= sh[o] * dv[q]; sum_dpsis += sh[o]; }
           const float A11 = a11[o] + sum_dpsis, A12 = a12[o], A22 = a22[o] + sum_dpsis;
           const float B1 = b1[o] - sigma_u, B2 = b2[o] - sigma_v;
           du[o] = (1.0f - omega) * du[o] + omega / A11 * (B1 - A12 * dv[o]);
@@ -195,40 +202,44 @@ __global__ void sor_serial_kernel(const SorArgs a) {
   for (int iter = 0; iter < a.iterations; ++iter)
     for (int j = 0; j < h; ++j)
       for (int i = 0; i < w; ++i) {
-        const int o = j * w + i;
-        const float hl = (i > 0) ? sh[o - 1] : 0.0f, hr = sh[o];
-        const float rgu = (i < w - 1) ? du[o + 1] : 0.0f, rgv = (i < w - 1) ? dv[o + 1] : 0.0f;
+        const int o = DG(i, j);
+        const int ol = DG(i > 0 ? i - 1 : 0, j), orr = DG(i < w - 1 ? i + 1 : i, j);
+        const int ot = DG(i, j > 0 ? j - 1 : 0), ob = DG(i, j < h - 1 ? j + 1 : j);
+        const float hl = (i > 0) ? sh[ol] : 0.0f, hr = sh[o];
+        const float rgu = (i < w - 1) ? du[orr] : 0.0f, rgv = (i < w - 1) ? dv[orr] : 0.0f;
         float d = hl + hr;
-        if (j > 0) d = d + sv[o - w];
+        if (j > 0) d = d + sv[ot];
         if (j < h - 1) d = d + sv[o];
         const float A11 = a22[o] + d, A22 = a11[o] + d;
         const float det = A11 * A22 - a12[o] * a12[o];
         const float i11 = A11 / det, i22 = A22 / det, i12 = a12[o] / (-det);
         float s1 = hr * rgu, s2 = hr * rgv;
-        if (j > 0) { s1 = s1 + sv[o - w] * du[o - w]; s2 = s2 + sv[o - w] * dv[o - w]; }
-        if (j < h - 1) { s1 = s1 + sv[o] * du[o + w]; s2 = s2 + sv[o] * dv[o + w]; }
+        if (j > 0) { s1 = s1 + sv[ot] * du[ot]; s2 = s2 + sv[ot] * dv[ot]; }
+        if (j < h - 1) { s1 = s1 + sv[o] * du[ob]; s2 = s2 + sv[o] * dv[ob]; }
         s1 = s1 + b1[o];
         s2 = s2 + b2[o];
         float B1 = s1, B2 = s2;
-        if (i > 0) { B1 = hl * du[o - 1] + s1; B2 = hl * dv[o - 1] + s2; }
+        if (i > 0) { B1 = hl * du[ol] + s1; B2 = hl * dv[ol] + s2; }
         const float u0 = du[o], v0 = dv[o];
         du[o] = u0 + omega * (i11 * B1 + i12 * B2 - u0);
         dv[o] = v0 + omega * (i12 * B1 + i22 * B2 - v0);
       }
+#undef DG
 }
 
 hipError_t launch_sor(const SorArgs& a, hipStream_t s) {
   const int w = a.t.w, h = a.t.h;
+  constexpr int PD = 3;
   if (w >= 2 && h >= 2 && h <= 64 && a.iterations >= 1 && a.iterations <= 4) {
     const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
     const int G = 64 / R;
     const int waves = (a.t.nframes + G - 1) / G;
     const int blocks = (waves + 3) / 4;
     switch (a.iterations) {
-      case 1: hipLaunchKernelGGL(sor_wave_kernel<1>, dim3(blocks), dim3(256), 0, s, a, R); break;
-      case 2: hipLaunchKernelGGL(sor_wave_kernel<2>, dim3(blocks), dim3(256), 0, s, a, R); break;
-      case 3: hipLaunchKernelGGL(sor_wave_kernel<3>, dim3(blocks), dim3(256), 0, s, a, R); break;
-      default: hipLaunchKernelGGL(sor_wave_kernel<4>, dim3(blocks), dim3(256), 0, s, a, R); break;
+      case 1: hipLaunchKernelGGL((sor_wave_kernel<1, PD>), dim3(blocks), dim3(256), 0, s, a, R); break;
+      case 2: hipLaunchKernelGGL((sor_wave_kernel<2, PD>), dim3(blocks), dim3(256), 0, s, a, R); break;
+      case 3: hipLaunchKernelGGL((sor_wave_kernel<3, PD>), dim3(blocks), dim3(256), 0, s, a, R); break;
+      default: hipLaunchKernelGGL((sor_wave_kernel<4, PD>), dim3(blocks), dim3(256), 0, s, a, R); break;
     }
   } else {
     hipLaunchKernelGGL(sor_serial_kernel, dim3((a.t.nframes + 63) / 64), dim3(64), 0, s, a);

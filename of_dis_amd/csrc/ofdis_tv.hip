@@ -180,20 +180,10 @@ hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s) {
 #define EPS_GRAD (0.001f * 0.001f)
 #define DATANORM (0.1f * 0.1f)
 
-constexpr int ST_W = 32, ST_H = 16;
-constexpr int SU_W = ST_W + 4, SU_H = ST_H + 4;  // uu/vv/wx/wy tile (halo 2)
+constexpr int ST_W = 32, ST_H = 32;              // output tile (4 pixels per thread)
+constexpr int SU_W = ST_W + 4, SU_H = ST_H + 4;  // wx/wy/du/dv tile (halo 2)
 constexpr int SS_W = ST_W + 2, SS_H = ST_H + 2;  // smoothness tile (halo 1)
-
-__device__ __forceinline__ float v3(const float* t, int pitch, int qy, int qx, int j, int h) {
-  const float* r = t + qy * pitch + qx;
-  if (j == 0) return (D3_C0 + D3_C1) * r[0] + D3_C2 * r[pitch];
-  if (j == h - 1) return D3_C0 * r[-pitch] + (D3_C1 + D3_C2) * r[0];
-  return D3_C0 * r[-pitch] + D3_C1 * r[0] + D3_C2 * r[pitch];
-}
-__device__ __forceinline__ float h3(const float* t, int pitch, int qy, int qx) {
-  const float* r = t + qy * pitch + qx;
-  return D3_C0 * r[-1] + D3_C1 * r[0] + D3_C2 * r[1];
-}
+constexpr int ST_PIX = ST_W * ST_H / 256;        // pixels per thread
 
 // data term of one pixel (opticalflow_aux.c:342-427).  D(k,c): derivative plane k, channel c.
 template <typename DF>
@@ -276,12 +266,19 @@ __device__ __forceinline__ void data_term(DF D, int noc, float m, float u, float
   }
 }
 
+// One 32x32 image tile per block.  du/dv arrive in the solver's diag layout and the seven outputs
+// leave in it; both transpositions go through LDS with a "rotated" enumeration (consecutive lanes
+// walk an anti-diagonal of the tile: x-1, y+1), which makes the global side contiguous runs of up
+// to 32 floats and the LDS side conflict-free (pitch even => (pitch-1) odd).
 __global__ __launch_bounds__(256) void tv_system_kernel(const SystemArgs a) {
-  __shared__ float uu_t[SU_H * SU_W];
-  __shared__ float vv_t[SU_H * SU_W];
-  __shared__ float wx_t[SU_H * SU_W];
-  __shared__ float wy_t[SU_H * SU_W];
-  __shared__ float s_t[SS_H * SS_W];
+  constexpr int IN_FLOATS = 4 * SU_H * SU_W + SS_H * SS_W;
+  constexpr int OUT_FLOATS = 7 * ST_H * ST_W;
+  __shared__ float lds[IN_FLOATS > OUT_FLOATS ? IN_FLOATS : OUT_FLOATS];
+  float* du_t = lds;
+  float* dv_t = du_t + SU_H * SU_W;
+  float* wx_t = dv_t + SU_H * SU_W;
+  float* wy_t = wx_t + SU_H * SU_W;
+  float* s_t = wy_t + SU_H * SU_W;
   const int w = a.t.w, h = a.t.h, noc = a.t.noc;
   const int npx = w * h;
   const int tiles_x = (w + ST_W - 1) / ST_W;
@@ -291,28 +288,49 @@ __global__ __launch_bounds__(256) void tv_system_kernel(const SystemArgs a) {
   const int tid = threadIdx.x;
   const size_t fo = (size_t)frame * npx;
 
-  // stage 0: uu = wx + du, vv = wy + dv (refine_variational.cpp:210-216) on tile + halo 2, clamped
+  // stage 0a: wx, wy (row-major) on tile + halo 2 at border-clamped coordinates
   for (int n = tid; n < SU_H * SU_W; n += 256) {
     const int qy = n / SU_W, qx = n - qy * SU_W;
     const int y = clampi(y0 + qy - 2, 0, h - 1), x = clampi(x0 + qx - 2, 0, w - 1);
     const size_t o = fo + y * w + x;
-    const float fx = a.wx[o], fy = a.wy[o];
-    wx_t[n] = fx;
-    wy_t[n] = fy;
-    uu_t[n] = fx + a.du[o];
-    vv_t[n] = fy + a.dv[o];
+    wx_t[n] = a.wx[o];
+    wy_t[n] = a.wy[o];
+  }
+  // stage 0b: du, dv (diag layout) on the same region, rotated enumeration
+  for (int n = tid; n < SU_H * SU_W; n += 256) {
+    const int qy = n % SU_H, r = n / SU_H;
+    int qx = r - qy;
+    if (qx < 0) qx += SU_W;
+    const int y = clampi(y0 + qy - 2, 0, h - 1), x = clampi(x0 + qx - 2, 0, w - 1);
+    const size_t o = fo + diag_index(x, y, w, h);
+    du_t[qy * SU_W + qx] = a.du[o];
+    dv_t[qy * SU_W + qx] = a.dv[o];
   }
   __syncthreads();
-  // stage 1: smoothness = quarter_alpha / sqrt(|grad uu|^2 + |grad vv|^2 + eps) on tile + halo 1
-  // (opticalflow_aux.c:128-140); only in-image entries are ever read back.
+  // stage 1: smoothness = quarter_alpha / sqrt(|grad uu|^2 + |grad vv|^2 + eps) on tile + halo 1 with
+  // uu = wx + du, vv = wy + dv (refine_variational.cpp:210-216; opticalflow_aux.c:128-140).
+  // Only in-image entries are ever read back.
   for (int n = tid; n < SS_H * SS_W; n += 256) {
     const int qy = n / SS_W, qx = n - qy * SS_W;
     const int y = y0 + qy - 1, x = x0 + qx - 1;
     float sval = 0.0f;
     if (y >= 0 && y < h && x >= 0 && x < w) {
-      const int uy_ = qy + 1, ux_ = qx + 1;  // position in the uu tile
-      const float ux = h3(uu_t, SU_W, uy_, ux_), vx = h3(vv_t, SU_W, uy_, ux_);
-      const float uy = v3(uu_t, SU_W, uy_, ux_, y, h), vy = v3(vv_t, SU_W, uy_, ux_, y, h);
+      const int c = (qy + 1) * SU_W + qx + 1;  // position in the halo-2 tiles
+      auto uu = [&](int o) { return wx_t[c + o] + du_t[c + o]; };
+      auto vv = [&](int o) { return wy_t[c + o] + dv_t[c + o]; };
+      const float ux = D3_C0 * uu(-1) + D3_C1 * uu(0) + D3_C2 * uu(1);   // image.c:436-464
+      const float vx = D3_C0 * vv(-1) + D3_C1 * vv(0) + D3_C2 * vv(1);
+      float uy, vy;                                                    // image.c:376-399
+      if (y == 0) {
+        uy = (D3_C0 + D3_C1) * uu(0) + D3_C2 * uu(SU_W);
+        vy = (D3_C0 + D3_C1) * vv(0) + D3_C2 * vv(SU_W);
+      } else if (y == h - 1) {
+        uy = D3_C0 * uu(-SU_W) + (D3_C1 + D3_C2) * uu(0);
+        vy = D3_C0 * vv(-SU_W) + (D3_C1 + D3_C2) * vv(0);
+      } else {
+        uy = D3_C0 * uu(-SU_W) + D3_C1 * uu(0) + D3_C2 * uu(SU_W);
+        vy = D3_C0 * vv(-SU_W) + D3_C1 * vv(0) + D3_C2 * vv(SU_W);
+      }
       sval = a.quarter_alpha / sqrtf(ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH);
     }
     s_t[n] = sval;
@@ -320,48 +338,65 @@ __global__ __launch_bounds__(256) void tv_system_kernel(const SystemArgs a) {
   __syncthreads();
   // stage 2: per pixel -- data term, then the Laplacian of the CURRENT flow (wx, wy) subtracted from
   // the right-hand side in the reference's scatter order: -left, +right, -top, +bottom
-  // (opticalflow_aux.c:172-199).
+  // (opticalflow_aux.c:172-199).  Results stay in registers until the input tiles are dead.
+  float res[ST_PIX][7];
   const int qx = tid % ST_W;
-  for (int ry = tid / ST_W; ry < ST_H; ry += 256 / ST_W) {
+#pragma unroll
+  for (int k = 0; k < ST_PIX; ++k) {
+    const int ry = tid / ST_W + k * (256 / ST_W);
     const int y = y0 + ry, x = x0 + qx;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) res[k][q] = 0.0f;
     if (y >= h || x >= w) continue;
     const size_t o = fo + y * w + x;
     const int sy = ry + 1, sx = qx + 1;  // in s tile
-    const int uy_ = ry + 2, ux_ = qx + 2;  // in wx tile
+    const int uc = (ry + 2) * SU_W + qx + 2;  // in halo-2 tiles
     const float sc = s_t[sy * SS_W + sx];
     const float sh_c = (x < w - 1) ? sc + s_t[sy * SS_W + sx + 1] : 0.0f;      // opticalflow_aux.c:150-154
     const float sv_c = (y < h - 1) ? sc + s_t[(sy + 1) * SS_W + sx] : 0.0f;    // :158-163
     float a11, a12, a22, b1, b2;
     const float* dbase = a.derivs + (size_t)frame * 8 * noc * npx + (size_t)y * w + x;
-    auto D = [&](int k, int c) { return dbase[((size_t)k * noc + c) * npx]; };
-    data_term(D, noc, a.mask[o], a.du[o], a.dv[o], a.half_delta_over3, a.half_gamma_over3, a11, a12, a22, b1, b2);
-    const float wxc = wx_t[uy_ * SU_W + ux_], wyc = wy_t[uy_ * SU_W + ux_];
+    auto D = [&](int kk, int c) { return dbase[((size_t)kk * noc + c) * npx]; };
+    data_term(D, noc, a.mask[o], du_t[uc], dv_t[uc], a.half_delta_over3, a.half_gamma_over3, a11, a12, a22, b1, b2);
+    const float wxc = wx_t[uc], wyc = wy_t[uc];
     if (x > 0) {
       const float sh_l = s_t[sy * SS_W + sx - 1] + sc;
-      b1 -= sh_l * (wxc - wx_t[uy_ * SU_W + ux_ - 1]);
-      b2 -= sh_l * (wyc - wy_t[uy_ * SU_W + ux_ - 1]);
+      b1 -= sh_l * (wxc - wx_t[uc - 1]);
+      b2 -= sh_l * (wyc - wy_t[uc - 1]);
     }
     if (x < w - 1) {
-      b1 += sh_c * (wx_t[uy_ * SU_W + ux_ + 1] - wxc);
-      b2 += sh_c * (wy_t[uy_ * SU_W + ux_ + 1] - wyc);
+      b1 += sh_c * (wx_t[uc + 1] - wxc);
+      b2 += sh_c * (wy_t[uc + 1] - wyc);
     }
     if (y > 0) {
       const float sv_t = s_t[(sy - 1) * SS_W + sx] + sc;
-      b1 -= sv_t * (wxc - wx_t[(uy_ - 1) * SU_W + ux_]);
-      b2 -= sv_t * (wyc - wy_t[(uy_ - 1) * SU_W + ux_]);
+      b1 -= sv_t * (wxc - wx_t[uc - SU_W]);
+      b2 -= sv_t * (wyc - wy_t[uc - SU_W]);
     }
     if (y < h - 1) {
-      b1 += sv_c * (wx_t[(uy_ + 1) * SU_W + ux_] - wxc);
-      b2 += sv_c * (wy_t[(uy_ + 1) * SU_W + ux_] - wyc);
+      b1 += sv_c * (wx_t[uc + SU_W] - wxc);
+      b2 += sv_c * (wy_t[uc + SU_W] - wyc);
     }
-    float* out = a.sys + (size_t)frame * 7 * npx + (size_t)y * w + x;
-    out[0 * (size_t)npx] = a11;
-    out[1 * (size_t)npx] = a12;
-    out[2 * (size_t)npx] = a22;
-    out[3 * (size_t)npx] = b1;
-    out[4 * (size_t)npx] = b2;
-    out[5 * (size_t)npx] = sh_c;
-    out[6 * (size_t)npx] = sv_c;
+    res[k][0] = a11; res[k][1] = a12; res[k][2] = a22; res[k][3] = b1; res[k][4] = b2; res[k][5] = sh_c; res[k][6] = sv_c;
+  }
+  __syncthreads();  // input tiles dead: reuse the LDS as the output staging area [plane][ry][qx]
+#pragma unroll
+  for (int k = 0; k < ST_PIX; ++k) {
+    const int ry = tid / ST_W + k * (256 / ST_W);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) lds[(q * ST_H + ry) * ST_W + qx] = res[k][q];
+  }
+  __syncthreads();
+  // stage 3: write the seven planes in diag layout, rotated enumeration (lane -> x-1, y+1)
+  for (int n = tid; n < ST_H * ST_W; n += 256) {
+    const int ry = n % ST_H, r = n / ST_H;
+    const int rx = (r - ry) & (ST_W - 1);
+    const int y = y0 + ry, x = x0 + rx;
+    if (y < h && x < w) {
+      float* out = a.sys + (size_t)frame * 7 * npx + diag_index(x, y, w, h);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) out[(size_t)q * npx] = lds[(q * ST_H + ry) * ST_W + rx];
+    }
   }
 }
 
@@ -372,18 +407,51 @@ hipError_t launch_tv_system(const SystemArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------ finish / split
-__global__ __launch_bounds__(256) void tv_finish_kernel(long long total, const float* wx, const float* wy,
+__global__ __launch_bounds__(256) void tv_finish_kernel(int w, int h, int nframes, const float* wx, const float* wy,
                                                         const float* du, const float* dv, float2* flow) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
-    flow[i] = make_float2(wx[i] + du[i], wy[i] + dv[i]);
+  const int npx = w * h;
+  const long long total = (long long)npx * nframes;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int frame = (int)(i / npx);
+    const int o = (int)(i - (long long)frame * npx);
+    const int y = o / w, x = o - y * w;
+    const size_t dg = (size_t)frame * npx + diag_index(x, y, w, h);
+    flow[i] = make_float2(wx[i] + du[dg], wy[i] + dv[dg]);
+  }
 }
 hipError_t launch_tv_finish(const TvGeom& t, const float* wx, const float* wy, const float* du, const float* dv,
                             float* flow_aos, hipStream_t s) {
   const long long total = (long long)t.w * t.h * t.nframes;
   long long blocks = (total + 255) / 256;
   if (blocks > (1 << 20)) blocks = 1 << 20;
-  hipLaunchKernelGGL(tv_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, total, wx, wy, du, dv,
+  hipLaunchKernelGGL(tv_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t.w, t.h, t.nframes, wx, wy, du, dv,
                      reinterpret_cast<float2*>(flow_aos));
+  return hipGetLastError();
+}
+
+// row-major <-> diag conversion of whole planes (per-function entry points / tests only)
+template <bool TO_DIAG>
+__global__ __launch_bounds__(256) void diag_convert_kernel(const float* src, float* dst, int w, int h, long long nplanes) {
+  const int npx = w * h;
+  const long long total = (long long)npx * nplanes;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pl = i / npx;
+    const int o = (int)(i - pl * npx);
+    const int y = o / w, x = o - y * w;
+    const size_t dg = (size_t)pl * npx + diag_index(x, y, w, h);
+    if (TO_DIAG) dst[dg] = src[i]; else dst[i] = src[dg];
+  }
+}
+hipError_t launch_to_diag(const float* src_rm, float* dst_diag, int w, int h, long long nplanes, hipStream_t s) {
+  long long blocks = ((long long)w * h * nplanes + 255) / 256;
+  if (blocks > (1 << 20)) blocks = 1 << 20;
+  hipLaunchKernelGGL(diag_convert_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, src_rm, dst_diag, w, h, nplanes);
+  return hipGetLastError();
+}
+hipError_t launch_from_diag(const float* src_diag, float* dst_rm, int w, int h, long long nplanes, hipStream_t s) {
+  long long blocks = ((long long)w * h * nplanes + 255) / 256;
+  if (blocks > (1 << 20)) blocks = 1 << 20;
+  hipLaunchKernelGGL(diag_convert_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, src_diag, dst_rm, w, h, nplanes);
   return hipGetLastError();
 }
 
