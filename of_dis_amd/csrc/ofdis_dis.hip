@@ -27,26 +27,60 @@ __device__ __forceinline__ void xcd_frame_map(int n, int blocks_per_frame, int& 
   blk = m % blocks_per_frame;
 }
 
-template <int M>
-__device__ __forceinline__ float lane_partial(const float (&x)[M], const bool (&valid)[M]) {
-  // lane l accumulates x[l], x[l+64], ... sequentially, starting FROM the first element
-  float s = valid[0] ? x[0] : 0.0f;
+// Sum over one patch vector in the documented 64-lane butterfly order (ofdis_dev.h: lane partials over
+// entries l, l+64, ...; then pairs at lane distance 1,2,4,8,16,32).
+//
+// LPP = physical lanes per patch (64, 32 or 16): 64/LPP patches share one wavefront.  Entry k of a
+// patch belongs to virtual lane l = k % 64 (round m = k / 64); physical lane pl = l % LPP holds the
+// Q = 64/LPP virtual lanes pl, pl+LPP, ... as separate accumulation chains.  Butterfly distances below
+// LPP run inside the patch's lanes on every chain (DPP row operations; one v_permlane16_swap for LPP=32),
+// the remaining distances (LPP .. 32) combine the chains pairwise -- operand for operand the same
+// additions as the 64-lane butterfly, so the result is bit-identical for every LPP.
+template <int M, int LPP>
+__device__ __forceinline__ float patch_sum(const float (&x)[M * (64 / LPP)], const bool (&valid)[M * (64 / LPP)]) {
+  constexpr int Q = 64 / LPP;
+  float c[Q];
 #pragma unroll
-  for (int m = 1; m < M; ++m)
-    if (valid[m]) s = s + x[m];
-  return s;
+  for (int q = 0; q < Q; ++q) {
+    c[q] = valid[q] ? x[q] : 0.0f;  // starts FROM the first element (never "0 + x")
+#pragma unroll
+    for (int m = 1; m < M; ++m)
+      if (valid[m * Q + q]) c[q] = c[q] + x[m * Q + q];
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0xB1>(c[q]);   // distance 1
+#pragma unroll
+  for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0x4E>(c[q]);   // 2
+#pragma unroll
+  for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0x141>(c[q]);  // 4
+#pragma unroll
+  for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0x140>(c[q]);  // 8
+  if constexpr (LPP == 64) {
+    return swap32_sum(swap16_sum(c[0]));
+  } else if constexpr (LPP == 32) {
+    return swap16_sum(c[0]) + swap16_sum(c[1]);       // 16 inside the half, then low + high (32)
+  } else {
+    return (c[0] + c[1]) + (c[2] + c[3]);             // 16: chains {0,1},{2,3}; 32: the two pairs
+  }
 }
 
-template <int M>
+template <int M, int LPP>
 __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
+  constexpr int Q = 64 / LPP;  // patches per wavefront == accumulation chains per lane
+  constexpr int E = M * Q;     // patch entries per lane
   const LevelGeom& g = a.g;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int blocks_per_frame = (g.nop + 3) >> 2;
+  const int blocks_per_frame = (g.nop + 4 * Q - 1) / (4 * Q);
   int frame, blk;
   xcd_frame_map(blockIdx.x, blocks_per_frame, frame, blk);
-  const int ip = blk * 4 + wave;
-  if (frame >= a.nframes || ip >= g.nop) return;  // wave-uniform
+  if (frame >= a.nframes) return;  // block-uniform
+  const int sub = lane / LPP;
+  const int pl = lane % LPP;
+  int ip = (blk * 4 + wave) * Q + sub;
+  const bool live = ip < g.nop;  // uniform per patch
+  if (Q == 1 && !live) return;
+  if (!live) ip = g.nop - 1;     // idle lane group: shadows the last patch, never stores
 
   const int noc = g.noc, P = g.P, tw = g.tmp_w, nv = g.novals;
   const int lb = -P / 2;
@@ -61,34 +95,41 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   const float rx = (float)(gx * g.steps + g.offw), ry = (float)(gy * g.steps + g.offh);
 
   // per-lane entry offsets relative to the patch centre in the padded, interleaved plane
-  int off[M];
-  bool valid[M];
+  int off[E], kidx[E];
+  bool valid[E];
 #pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const int k = lane + 64 * m;
-    valid[m] = k < nv;
-    const int kk = valid[m] ? k : 0;
+  for (int e = 0; e < E; ++e) {
+    const int k = (e / Q) * 64 + (e % Q) * LPP + pl;
+    kidx[e] = k;
+    valid[e] = k < nv;
+    const int kk = valid[e] ? k : 0;
     const int c = kk % noc, q = kk / noc;
     const int col = q % P, row = q / P;
-    off[m] = ((row + lb) * tw + (col + lb)) * noc + c;
+    off[e] = ((row + lb) * tw + (col + lb)) * noc + c;
   }
+  // x / novals: when novals is a power of two the product with its reciprocal is the same correctly
+  // rounded value as the reference's division (both round the same real number), at 1/10 the cost
   const float fnv = (float)nv;
+  const bool nv_pow2 = (nv & (nv - 1)) == 0;
+  const float inv_nv = 1.0f / fnv;
+  auto div_nv = [&](float x) { return nv_pow2 ? x * inv_nv : x / fnv; };
 
   // ---- InitializePatch: template + gradients at the integer reference position (patch.cpp:287-332)
-  float T[M], Tx[M], Ty[M];
+  float T[E], Tx[E], Ty[E];
   {
     const int px = (int)roundf(rx) + g.pad, py = (int)roundf(ry) + g.pad;
     const int base = (py * tw + px) * noc;
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      T[m] = valid[m] ? imA[base + off[m]] : 0.0f;
-      Tx[m] = valid[m] ? imAx[base + off[m]] : 0.0f;
-      Ty[m] = valid[m] ? imAy[base + off[m]] : 0.0f;
+    for (int e = 0; e < E; ++e) {
+      const unsigned o = (unsigned)(base + off[e]);
+      T[e] = valid[e] ? imA[o] : 0.0f;
+      Tx[e] = valid[e] ? imAx[o] : 0.0f;
+      Ty[e] = valid[e] ? imAy[o] : 0.0f;
     }
     if (a.patnorm > 0) {
-      const float mean = wave_sum(lane_partial<M>(T, valid)) / fnv;
+      const float mean = div_nv(patch_sum<M, LPP>(T, valid));
 #pragma unroll
-      for (int m = 0; m < M; ++m) T[m] -= mean;
+      for (int e = 0; e < E; ++e) T[e] -= mean;
     }
   }
   // ---- ComputeHessian (patch.cpp:71-88) and its Cholesky factor (Eigen LLT, call site patch.cpp:184;
@@ -96,16 +137,16 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   //      factor is computed once instead of once per iteration.
   float l00, l10, l11;
   {
-    float pxx[M], pxy[M], pyy[M];
+    float pxx[E], pxy[E], pyy[E];
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      pxx[m] = Tx[m] * Tx[m];
-      pxy[m] = Tx[m] * Ty[m];
-      pyy[m] = Ty[m] * Ty[m];
+    for (int e = 0; e < E; ++e) {
+      pxx[e] = Tx[e] * Tx[e];
+      pxy[e] = Tx[e] * Ty[e];
+      pyy[e] = Ty[e] * Ty[e];
     }
-    float H00 = wave_sum(lane_partial<M>(pxx, valid));
-    const float H01 = wave_sum(lane_partial<M>(pxy, valid));
-    float H11 = wave_sum(lane_partial<M>(pyy, valid));
+    float H00 = patch_sum<M, LPP>(pxx, valid);
+    const float H01 = patch_sum<M, LPP>(pxy, valid);
+    float H11 = patch_sum<M, LPP>(pyy, valid);
     if (H00 * H11 - H01 * H01 == 0.0f) {  // float += double literal in the reference
       H00 = (float)((double)H00 + 1e-10);
       H11 = (float)((double)H11 + 1e-10);
@@ -129,7 +170,9 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     pin1 = fp[2 * i + 1] * 2;
   }
 
-  // ---- OptimizeIter (patch.cpp:159-212)
+  // ---- OptimizeIter (patch.cpp:159-212).  All state below is uniform per patch; the lane groups of a
+  //      wave diverge like ordinary SIMT branches (every cross-lane operation used here stays inside
+  //      the LPP lanes of one patch).
   float p0 = pin0, p1 = pin1;
   float ptx = rx + p0, pty = ry + p1;
   const float stx = ptx, sty = pty;
@@ -137,9 +180,9 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   float dpsq = 1e-10f, dpsq_init = 1e-10f, mares = 1e20f, mares_old = 1e20f;
   int cnt = 0;
   bool converged = false;
-  float pdiff[M], pw[M];
+  float pdiff[E], pw[E];
 #pragma unroll
-  for (int m = 0; m < M; ++m) { pdiff[m] = 0.0f; pw[m] = 0.0f; }  // pw = 0: the reference's never-written pweight
+  for (int e = 0; e < E; ++e) { pdiff[e] = 0.0f; pw[e] = 0.0f; }  // pw = 0: the reference's never-written pweight
 
   // OptimizeComputeErrImg (patch.cpp:264-284) = getPatchStaticBil (335-402) + LossComputeErrorImage (223-262)
   auto compute_err = [&]() {
@@ -150,39 +193,40 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     pos0 += g.pad;
     pos1 += g.pad;
     const int base = (pos1 * tw + pos0) * noc;
-    const int up = tw * noc;
-    float v[M];
+    const unsigned up = (unsigned)(tw * noc);
+    float v[E];
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const int o = base + off[m];
+    for (int e = 0; e < E; ++e) {
+      const unsigned o = (unsigned)(base + off[e]);  // >= up + noc for every in-bounds position
       const float ta = imB[o], tb = imB[o - noc], tc = imB[o - up], td = imB[o - up - noc];
-      v[m] = valid[m] ? (we0 * ta + we1 * tb + we2 * tc + we3 * td) : 0.0f;
+      v[e] = valid[e] ? (we0 * ta + we1 * tb + we2 * tc + we3 * td) : 0.0f;
     }
     if (a.patnorm > 0) {
-      const float mean = wave_sum(lane_partial<M>(v, valid)) / fnv;
+      const float mean = div_nv(patch_sum<M, LPP>(v, valid));
 #pragma unroll
-      for (int m = 0; m < M; ++m) v[m] -= mean;
+      for (int e = 0; e < E; ++e) v[e] -= mean;
     }
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      float d = v[m] - T[m];
+    for (int e = 0; e < E; ++e) {
+      float d = v[e] - T[e];
       if (a.costfct == 1) {
         d = copysignf(sqrtf(fabsf(d)), d);
       } else if (a.costfct == 2) {
         const float bsq = 5.0f * 5.0f, bsq2 = bsq * 2.0f;
         d = copysignf(sqrtf((sqrtf(1.0f + (d * d) / bsq) - 1.0f) * bsq2), d);
       }
-      pdiff[m] = valid[m] ? d : 0.0f;
-      pw[m] = fabsf(pdiff[m]);
+      pdiff[e] = valid[e] ? d : 0.0f;
+      pw[e] = fabsf(pdiff[e]);
     }
     dpsq = dp0 * dp0 + dp1 * dp1;
     if (cnt == 1) dpsq_init = dpsq;
     mares_old = mares;
-    mares = wave_sum(lane_partial<M>(pw, valid)) / fnv;
-    if (!((cnt < a.max_iter) & (mares > a.res_thresh) &
-          ((cnt < a.min_iter) | (dpsq / dpsq_init >= a.dp_thresh_sq)) &
-          ((cnt < a.min_iter) | (mares / mares_old <= a.dr_thresh))))
-      converged = true;
+    mares = div_nv(patch_sum<M, LPP>(pw, valid));
+    // patch.cpp:279-282.  The reference evaluates all terms with bitwise &,|; the two ratios have no
+    // side effects, so they are only computed where they can decide (min_iter <= cnt < max_iter).
+    bool go = (cnt < a.max_iter) && (mares > a.res_thresh);
+    if (go && cnt >= a.min_iter) go = (dpsq / dpsq_init >= a.dp_thresh_sq) && (mares / mares_old <= a.dr_thresh);
+    if (!go) converged = true;
   };
   auto oob = [&](float x, float y) { return x < g.lb || y < g.lb || x > g.ubw || y > g.ubh; };
 
@@ -195,14 +239,14 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   }
   while (!converged) {
     cnt++;
-    float gxr[M], gyr[M];
+    float gxr[E], gyr[E];
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      gxr[m] = Tx[m] * pdiff[m];
-      gyr[m] = Ty[m] * pdiff[m];
+    for (int e = 0; e < E; ++e) {
+      gxr[e] = Tx[e] * pdiff[e];
+      gyr[e] = Ty[e] * pdiff[e];
     }
-    const float b0 = wave_sum(lane_partial<M>(gxr, valid));
-    const float b1 = wave_sum(lane_partial<M>(gyr, valid));
+    const float b0 = patch_sum<M, LPP>(gxr, valid);
+    const float b1 = patch_sum<M, LPP>(gyr, valid);
     // delta_p = LLT(H).solve(b)
     const float y0 = b0 / l00;
     const float y1 = (b1 - l10 * y0) / l11;
@@ -225,29 +269,32 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     compute_err();
   }
 
-  float* pout = a.p_out + ((size_t)frame * g.nop + ip) * 2;
-  if (lane == 0) {
-    pout[0] = p0;
-    pout[1] = p1;
-  }
-  float* pwout = a.pweight + ((size_t)frame * g.nop + ip) * nv;
+  if (live) {
+    float* pout = a.p_out + ((size_t)frame * g.nop + ip) * 2;
+    if (pl == 0) {
+      pout[0] = p0;
+      pout[1] = p1;
+    }
+    float* pwout = a.pweight + ((size_t)frame * g.nop + ip) * nv;
 #pragma unroll
-  for (int m = 0; m < M; ++m)
-    if (valid[m]) pwout[lane + 64 * m] = pw[m];
+    for (int e = 0; e < E; ++e)
+      if (valid[e]) pwout[kidx[e]] = pw[e];
+  }
 }
 
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
-  const int blocks_per_frame = (a.g.nop + 3) / 4;
-  const int grid = ((a.nframes + 7) / 8) * 8 * blocks_per_frame;
   const int M = (a.g.novals + 63) / 64;
+  const int ppb = (M <= 1) ? 16 : 4;  // patches per 256-thread block
+  const int blocks_per_frame = (a.g.nop + ppb - 1) / ppb;
+  const int grid = ((a.nframes + 7) / 8) * 8 * blocks_per_frame;
   if (M <= 1)
-    hipLaunchKernelGGL(patch_optimize_kernel<1>, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 16>), dim3(grid), dim3(256), 0, s, a);
   else if (M <= 3)
-    hipLaunchKernelGGL(patch_optimize_kernel<3>, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<3, 64>), dim3(grid), dim3(256), 0, s, a);
   else if (M <= 7)
-    hipLaunchKernelGGL(patch_optimize_kernel<7>, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<7, 64>), dim3(grid), dim3(256), 0, s, a);
   else if (M <= 12)
-    hipLaunchKernelGGL(patch_optimize_kernel<12>, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<12, 64>), dim3(grid), dim3(256), 0, s, a);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
