@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=2048, help="frame pairs per GPU per step")
     ap.add_argument("--tv", choices=["on", "off"], default="on")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
@@ -162,9 +162,8 @@ def main():
     from of_dis_amd import capi
     from of_dis_amd.params import oppoint
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from of_dis_amd import shard
+    rank, world, local_rank = shard.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -178,15 +177,13 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        shard.barrier(dist, torch.cuda.synchronize)
 
     tv = args.tv == "on"
     p = oppoint(2, WIDTH, HEIGHT, noc=1, usetvref=tv, verbosity=0)
     B = args.batch
-    ia, ib = synth_frames_torch(B, WIDTH, HEIGHT, 1234 + rank * 100003, dev)
+    # weak scaling: rank r owns global frames [r*B, (r+1)*B); its generator is seeded by its first frame
+    ia, ib = synth_frames_torch(B, WIDTH, HEIGHT, shard.frame_seed(1234, rank * B), dev)
     stream = torch.cuda.current_stream().cuda_stream
     batch = capi.Batch(p, B)
     batch.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
@@ -200,11 +197,8 @@ def main():
         batch.run(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    fps = world * B * args.steps / elapsed
+    elapsed = shard.max_over_ranks(elapsed, dist, dev)
+    fps = shard.throughput([B] * world, args.steps, elapsed)
 
     result = None
     if rank == 0:

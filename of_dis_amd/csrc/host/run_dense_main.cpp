@@ -1,0 +1,161 @@
+// run_OF_INT / run_OF_RGB -- the reference's command line (run_dense.cpp:185-431, README.md:48-88) on top of
+// the C ABI (include/ofdis.h).  Compile with -DOFDIS_NOC=1 (run_OF_INT) or 3 (run_OF_RGB), mirroring the
+// reference's per-binary SELECTCHANNEL.
+//
+//   run_OF_INT img1 img2 out.flo                      operating point 2
+//   run_OF_INT img1 img2 out.flo X                    operating point X in 1..4
+//   run_OF_INT img1 img2 out.flo p1 .. p20            the 20 explicit parameters
+//
+// Pipeline: read 8-bit images -> upload -> on-device padding, pyramid, Sobel (ofdis_batch_build_pyramids_u8)
+// -> hot path (ofdis_batch_run) -> download the (w>>lv_l x h>>lv_l) flow -> x2^lv_l, bilinear upsample, crop
+// (run_dense.cpp:406-414, cv::resize INTER_LINEAR restated) -> Middlebury .flo.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "image_io.h"
+#include "ofdis.h"
+
+#ifndef OFDIS_NOC
+#define OFDIS_NOC 1
+#endif
+
+static double now_ms() {
+  struct timeval tv;
+  gettimeofday(&tv, nullptr);
+  return tv.tv_sec * 1000.0 + tv.tv_usec / 1000.0;
+}
+
+// flowout *= 2^lv_l; cv::resize(x 2^lv_l, INTER_LINEAR); crop (run_dense.cpp:406-414)
+static void upsample_crop(const ofdis_params& p, const float* flow, int width_org, int height_org, float* out) {
+  const int s = 1 << p.sc_l;
+  const int sw = p.width >> p.sc_l, sh = p.height >> p.sc_l;
+  const int left = (p.width - width_org) / 2, top = (p.height - height_org) / 2;
+  const float scf = (float)s;
+  const double inv = 1.0 / (double)s;
+  for (int y = 0; y < height_org; ++y) {
+    float fy = (float)((y + top + 0.5) * inv - 0.5);
+    int sy = (int)floor(fy);
+    fy -= sy;
+    if (sy < 0) { sy = 0; fy = 0; }
+    if (sy >= sh - 1) { sy = sh - 1; fy = 0; }
+    const int sy1 = std::min(sy + 1, sh - 1);
+    for (int x = 0; x < width_org; ++x) {
+      float fx = (float)((x + left + 0.5) * inv - 0.5);
+      int sx = (int)floor(fx);
+      fx -= sx;
+      if (sx < 0) { sx = 0; fx = 0; }
+      if (sx >= sw - 1) { sx = sw - 1; fx = 0; }
+      const int sx1 = std::min(sx + 1, sw - 1);
+      for (int c = 0; c < 2; ++c) {
+        const float v00 = flow[2 * (sy * sw + sx) + c] * scf, v01 = flow[2 * (sy * sw + sx1) + c] * scf;
+        const float v10 = flow[2 * (sy1 * sw + sx) + c] * scf, v11 = flow[2 * (sy1 * sw + sx1) + c] * scf;
+        const float r0 = v00 * (1.0f - fx) + v01 * fx, r1 = v10 * (1.0f - fx) + v11 * fx;
+        out[2 * ((size_t)y * width_org + x) + c] = r0 * (1.0f - fy) + r1 * fy;
+      }
+    }
+  }
+}
+
+int main(int argc, char** argv) {
+  const double t_start = now_ms();
+  if (argc < 4) {
+    fprintf(stderr, "usage: %s img1 img2 out.flo [oppoint 1-4 | lv_f lv_l maxiter miniter mindprate mindrrate minimgerr "
+                    "patchsz poverl usefbcon patnorm costfct usetvref tv_alpha tv_gamma tv_delta tv_innerit tv_solverit "
+                    "tv_sor verbosity]\n", argv[0]);
+    return 2;
+  }
+  const char* f_a = argv[1];
+  const char* f_b = argv[2];
+  const char* f_out = argv[3];
+  ofdis_host::Image8 ia, ib;
+  std::string err;
+  if (!ofdis_host::read_image(f_a, OFDIS_NOC, &ia, &err) || !ofdis_host::read_image(f_b, OFDIS_NOC, &ib, &err)) {
+    fprintf(stderr, "%s\n", err.c_str());
+    return 1;
+  }
+  if (ia.width != ib.width || ia.height != ib.height) {
+    fprintf(stderr, "image sizes differ\n");
+    return 1;
+  }
+  const int width_org = ia.width, height_org = ia.height;
+
+  // *** parameters (run_dense.cpp:225-294)
+  ofdis_params p;
+  if (argc <= 5) {
+    const int op = (argc == 5) ? atoi(argv[4]) : 2;
+    if (ofdis_params_oppoint(&p, op, width_org, OFDIS_NOC) != OFDIS_OK) {
+      fprintf(stderr, "%s\n", ofdis_last_error());
+      return 1;
+    }
+  } else {
+    if (argc < 24) {
+      fprintf(stderr, "need all 20 parameters (README.md:57-88), got %d\n", argc - 4);
+      return 2;
+    }
+    ofdis_params_oppoint(&p, 2, width_org, OFDIS_NOC);
+    int k = 4;
+    p.sc_f = atoi(argv[k++]); p.sc_l = atoi(argv[k++]);
+    p.max_iter = atoi(argv[k++]); p.min_iter = atoi(argv[k++]);
+    p.dp_thresh = (float)atof(argv[k++]); p.dr_thresh = (float)atof(argv[k++]); p.res_thresh = (float)atof(argv[k++]);
+    p.p_samp_s = atoi(argv[k++]); p.patove = (float)atof(argv[k++]);
+    p.usefbcon = atoi(argv[k++]); p.patnorm = atoi(argv[k++]); p.costfct = atoi(argv[k++]); p.usetvref = atoi(argv[k++]);
+    p.tv_alpha = (float)atof(argv[k++]); p.tv_gamma = (float)atof(argv[k++]); p.tv_delta = (float)atof(argv[k++]);
+    p.tv_innerit = atoi(argv[k++]); p.tv_solverit = atoi(argv[k++]); p.tv_sor = (float)atof(argv[k++]);
+    p.verbosity = atoi(argv[k++]);
+    p.imgpadding = p.p_samp_s;
+  }
+  // *** pad to a multiple of 2^lv_f (run_dense.cpp:298-311)
+  const int scfct = 1 << p.sc_f;
+  p.width = width_org + (scfct - width_org % scfct) % scfct;
+  p.height = height_org + (scfct - height_org % scfct) % scfct;
+  const int verbosity = p.verbosity;
+  if (verbosity > 1) printf("TIME (Image loading     ) (ms): %3g\n", now_ms() - t_start);
+
+  double t0 = now_ms();
+  ofdis_batch* b = nullptr;
+  if (ofdis_batch_create(&b, &p, 1) != OFDIS_OK) {
+    fprintf(stderr, "%s\n", ofdis_last_error());
+    return 1;
+  }
+  const size_t nbytes = (size_t)width_org * height_org * OFDIS_NOC;
+  void* da = ofdis_dev_alloc(nbytes);
+  void* db = ofdis_dev_alloc(nbytes);
+  int rc = (da && db) ? OFDIS_OK : OFDIS_ERR_NOMEM;
+  if (!rc) rc = ofdis_memcpy_h2d(da, ia.data.data(), nbytes);
+  if (!rc) rc = ofdis_memcpy_h2d(db, ib.data.data(), nbytes);
+  if (!rc) rc = ofdis_batch_build_pyramids_u8(b, (const uint8_t*)da, (const uint8_t*)db, width_org, height_org, nullptr);
+  if (!rc) rc = ofdis_sync(nullptr);
+  if (rc) {
+    fprintf(stderr, "%s\n", ofdis_last_error());
+    return 1;
+  }
+  if (verbosity > 1) printf("TIME (Pyramide+Gradients) (ms): %3g\n", now_ms() - t0);
+
+  // *** the hot path (prints the reference's per-level TIME lines itself when verbosity > 1)
+  rc = ofdis_batch_run(b, nullptr);
+  const int sw = p.width >> p.sc_l, sh = p.height >> p.sc_l;
+  std::vector<float> flow((size_t)2 * sw * sh);
+  if (!rc) rc = ofdis_batch_download(b, 0, flow.data(), nullptr);
+  if (rc) {
+    fprintf(stderr, "%s\n", ofdis_last_error());
+    return 1;
+  }
+  t0 = now_ms();
+  std::vector<float> full((size_t)2 * width_org * height_org);
+  upsample_crop(p, flow.data(), width_org, height_org, full.data());
+  if (!ofdis_host::write_flo(f_out, full.data(), width_org, height_org, &err)) {
+    printf("%s\n", err.c_str());  // the reference reports and carries on (run_dense.cpp:24-25)
+  }
+  if (verbosity > 1) printf("TIME (Saving flow file  ) (ms): %3g\n", now_ms() - t0);
+  ofdis_dev_free(da);
+  ofdis_dev_free(db);
+  ofdis_batch_destroy(b);
+  return 0;
+}

@@ -11,58 +11,101 @@
 // row-major [frame][...][h][w].  The stencil kernels stage a tile plus halo in LDS; the border
 // rules of the reference (replicated columns, folded coefficients on the first/last rows) are
 // applied per stage exactly as the reference applies them per convolution call.
+#include <stdlib.h>
+
 #include "ofdis_kernels.h"
 
 namespace ofdis {
 
 // ------------------------------------------------------------------------------------------ warp
+// image_warp (opticalflow_aux.c:18-60).  HBM-streaming kernel: per pixel it reads wx, wy, writes the
+// warped value(s) and the mask; the four bilinear taps come from the frame's own padded plane, which is
+// L2-resident (41 KB at op-point 2).  VEC = pixels per thread: 4 consecutive x (16-byte loads/stores of
+// wx, wy, dst, mask) when w % 4 == 0, else 1.
 template <bool PADDED>
+__device__ __forceinline__ void warp_pixel(const WarpArgs& a, int frame, int i, int j, float fx, float fy, float& m,
+                                           float* out /*[noc]*/) {
+  const int w = a.t.w, h = a.t.h, noc = a.t.noc;
+  const float xx = i + fx;
+  const float yy = j + fy;
+  const int x = (int)floorf(xx), y = (int)floorf(yy);
+  const float dx = xx - (float)x, dy = yy - (float)y;
+  m = (xx >= 0 && xx <= (float)(w - 1) && yy >= 0 && yy <= (float)(h - 1)) ? 1.0f : 0.0f;
+  const int x1 = clampi(x, 0, w - 1), x2 = clampi(x + 1, 0, w - 1);
+  const int y1 = clampi(y, 0, h - 1), y2 = clampi(y + 1, 0, h - 1);
+  for (int c = 0; c < noc; ++c) {
+    float s11, s12, s21, s22;
+    if (PADDED) {
+      const float* s = a.src + (size_t)frame * a.tmp_w * a.tmp_h * noc;
+      s11 = s[((y1 + a.pad) * a.tmp_w + x1 + a.pad) * noc + c];
+      s12 = s[((y1 + a.pad) * a.tmp_w + x2 + a.pad) * noc + c];
+      s21 = s[((y2 + a.pad) * a.tmp_w + x1 + a.pad) * noc + c];
+      s22 = s[((y2 + a.pad) * a.tmp_w + x2 + a.pad) * noc + c];
+    } else {
+      const float* s = a.src + ((size_t)frame * noc + c) * w * h;
+      s11 = s[y1 * w + x1];
+      s12 = s[y1 * w + x2];
+      s21 = s[y2 * w + x1];
+      s22 = s[y2 * w + x2];
+    }
+    out[c] = s11 * (1.0f - dx) * (1.0f - dy) + s12 * dx * (1.0f - dy) + s21 * (1.0f - dx) * dy + s22 * dx * dy;
+  }
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+#ifdef OFDIS_WARP_NT
+__device__ __forceinline__ f4 nt_load(const f4* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void nt_store(f4 v, f4* p) { __builtin_nontemporal_store(v, p); }
+#else
+__device__ __forceinline__ f4 nt_load(const f4* p) { return *p; }
+__device__ __forceinline__ void nt_store(f4 v, f4* p) { *p = v; }
+#endif
+template <bool PADDED, int VEC>
 __global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a) {
   const int w = a.t.w, h = a.t.h, noc = a.t.noc;
   const int npx = w * h;
-  const long long total = (long long)npx * a.t.nframes;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  const long long total = (long long)npx * a.t.nframes / VEC;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+    const long long idx = q * VEC;
     const int frame = (int)(idx / npx);
     const int o = (int)(idx - (long long)frame * npx);
     const int j = o / w, i = o - j * w;
-    const float xx = i + a.wx[idx];
-    const float yy = j + a.wy[idx];
-    const float fxf = floorf(xx), fyf = floorf(yy);
-    const int x = (int)fxf, y = (int)fyf;
-    const float dx = xx - (float)x, dy = yy - (float)y;
-    a.mask[idx] = (xx >= 0 && xx <= (float)(w - 1) && yy >= 0 && yy <= (float)(h - 1)) ? 1.0f : 0.0f;
-    const int x1 = clampi(x, 0, w - 1), x2 = clampi(x + 1, 0, w - 1);
-    const int y1 = clampi(y, 0, h - 1), y2 = clampi(y + 1, 0, h - 1);
-    for (int c = 0; c < noc; ++c) {
-      float s11, s12, s21, s22;
-      if (PADDED) {
-        const float* s = a.src + (size_t)frame * a.tmp_w * a.tmp_h * noc;
-        s11 = s[((y1 + a.pad) * a.tmp_w + x1 + a.pad) * noc + c];
-        s12 = s[((y1 + a.pad) * a.tmp_w + x2 + a.pad) * noc + c];
-        s21 = s[((y2 + a.pad) * a.tmp_w + x1 + a.pad) * noc + c];
-        s22 = s[((y2 + a.pad) * a.tmp_w + x2 + a.pad) * noc + c];
-      } else {
-        const float* s = a.src + ((size_t)frame * noc + c) * npx;
-        s11 = s[y1 * w + x1];
-        s12 = s[y1 * w + x2];
-        s21 = s[y2 * w + x1];
-        s22 = s[y2 * w + x2];
-      }
-      a.dst[((size_t)frame * noc + c) * npx + o] =
-          s11 * (1.0f - dx) * (1.0f - dy) + s12 * dx * (1.0f - dy) + s21 * (1.0f - dx) * dy + s22 * dx * dy;
+    if constexpr (VEC == 4) {
+      const f4 fxv = nt_load(reinterpret_cast<const f4*>(a.wx + idx));
+      const f4 fyv = nt_load(reinterpret_cast<const f4*>(a.wy + idx));
+      const float4 fx = make_float4(fxv.x, fxv.y, fxv.z, fxv.w), fy = make_float4(fyv.x, fyv.y, fyv.z, fyv.w);
+      float4 m;
+      float r0[3], r1[3], r2[3], r3[3];
+      warp_pixel<PADDED>(a, frame, i + 0, j, fx.x, fy.x, m.x, r0);
+      warp_pixel<PADDED>(a, frame, i + 1, j, fx.y, fy.y, m.y, r1);
+      warp_pixel<PADDED>(a, frame, i + 2, j, fx.z, fy.z, m.z, r2);
+      warp_pixel<PADDED>(a, frame, i + 3, j, fx.w, fy.w, m.w, r3);
+      nt_store((f4){m.x, m.y, m.z, m.w}, reinterpret_cast<f4*>(a.mask + idx));
+      for (int c = 0; c < noc; ++c)
+        nt_store((f4){r0[c], r1[c], r2[c], r3[c]}, reinterpret_cast<f4*>(a.dst + ((size_t)frame * noc + c) * npx + o));
+    } else {
+      float m, r[3];
+      warp_pixel<PADDED>(a, frame, i, j, a.wx[idx], a.wy[idx], m, r);
+      a.mask[idx] = m;
+      for (int c = 0; c < noc; ++c) a.dst[((size_t)frame * noc + c) * npx + o] = r[c];
     }
   }
 }
 
 hipError_t launch_warp(const WarpArgs& a, hipStream_t s) {
-  const long long total = (long long)a.t.w * a.t.h * a.t.nframes;
+  const bool v4 = (a.t.w % 4) == 0;
+  const long long total = (long long)a.t.w * a.t.h * a.t.nframes / (v4 ? 4 : 1);
   long long blocks = (total + 255) / 256;
-  if (blocks > (1 << 20)) blocks = 1 << 20;
-  if (a.src_padded)
-    hipLaunchKernelGGL(warp_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(warp_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  static const long long cap = getenv("OFDIS_WARP_GRID") ? atoll(getenv("OFDIS_WARP_GRID")) : 4096;  // 256 CUs x 16
+  if (blocks > cap) blocks = cap;  // grid-stride beyond that: several 16-byte loads in flight per thread
+  const dim3 g((unsigned)blocks), b(256);
+  if (a.src_padded) {
+    if (v4) hipLaunchKernelGGL((warp_kernel<true, 4>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((warp_kernel<true, 1>), g, b, 0, s, a);
+  } else {
+    if (v4) hipLaunchKernelGGL((warp_kernel<false, 4>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((warp_kernel<false, 1>), g, b, 0, s, a);
+  }
   return hipGetLastError();
 }
 
@@ -407,24 +450,44 @@ hipError_t launch_tv_system(const SystemArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------ finish / split
-__global__ __launch_bounds__(256) void tv_finish_kernel(int w, int h, int nframes, const float* wx, const float* wy,
+// uu = wx + du, vv = wy + dv -> AoS flow.  du/dv live in the solver's diag layout: a 32x32 tile is
+// gathered through LDS with the rotated enumeration (contiguous runs on the global side), then
+// written row-major as float2.
+__global__ __launch_bounds__(256) void tv_finish_kernel(int w, int h, const float* wx, const float* wy,
                                                         const float* du, const float* dv, float2* flow) {
+  constexpr int TW = 32, TH = 32;
+  __shared__ float du_t[TH * TW];
+  __shared__ float dv_t[TH * TW];
   const int npx = w * h;
-  const long long total = (long long)npx * nframes;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int frame = (int)(i / npx);
-    const int o = (int)(i - (long long)frame * npx);
-    const int y = o / w, x = o - y * w;
-    const size_t dg = (size_t)frame * npx + diag_index(x, y, w, h);
-    flow[i] = make_float2(wx[i] + du[dg], wy[i] + dv[dg]);
+  const int tiles_x = (w + TW - 1) / TW;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int frame = blockIdx.y;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const size_t fo = (size_t)frame * npx;
+  for (int n = threadIdx.x; n < TH * TW; n += 256) {
+    const int ry = n % TH, r = n / TH;
+    const int rx = (r - ry) & (TW - 1);
+    const int y = y0 + ry, x = x0 + rx;
+    if (y < h && x < w) {
+      const size_t o = fo + diag_index(x, y, w, h);
+      du_t[ry * TW + rx] = du[o];
+      dv_t[ry * TW + rx] = dv[o];
+    }
+  }
+  __syncthreads();
+  const int qx = threadIdx.x % TW;
+  for (int ry = threadIdx.x / TW; ry < TH; ry += 256 / TW) {
+    const int y = y0 + ry, x = x0 + qx;
+    if (y < h && x < w) {
+      const size_t o = fo + (size_t)y * w + x;
+      flow[o] = make_float2(wx[o] + du_t[ry * TW + qx], wy[o] + dv_t[ry * TW + qx]);
+    }
   }
 }
 hipError_t launch_tv_finish(const TvGeom& t, const float* wx, const float* wy, const float* du, const float* dv,
                             float* flow_aos, hipStream_t s) {
-  const long long total = (long long)t.w * t.h * t.nframes;
-  long long blocks = (total + 255) / 256;
-  if (blocks > (1 << 20)) blocks = 1 << 20;
-  hipLaunchKernelGGL(tv_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t.w, t.h, t.nframes, wx, wy, du, dv,
+  const int tiles = ((t.w + 31) / 32) * ((t.h + 31) / 32);
+  hipLaunchKernelGGL(tv_finish_kernel, dim3(tiles, t.nframes), dim3(256), 0, s, t.w, t.h, wx, wy, du, dv,
                      reinterpret_cast<float2*>(flow_aos));
   return hipGetLastError();
 }
