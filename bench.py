@@ -40,15 +40,12 @@ def synth_frames_torch(n, w, h, seed, device):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
 
-    def blur(x, sigma):
-        r = int(3 * sigma + 0.5)
-        k = torch.arange(-r, r + 1, device=device, dtype=torch.float32)
-        k = torch.exp(-0.5 * (k / sigma) ** 2)
-        k = (k / k.sum()).view(1, 1, -1)
-        x = F.pad(x, (r, r, 0, 0), mode="circular")
-        x = F.conv2d(x, k.view(1, 1, 1, -1))
-        x = F.pad(x, (0, 0, r, r), mode="circular")
-        return F.conv2d(x, k.view(1, 1, -1, 1))
+    # Gaussian filtering as a product in the Fourier domain (periodic, like scipy's mode="wrap")
+    fy = torch.fft.fftfreq(H, device=device).view(H, 1)
+    fx = torch.fft.rfftfreq(W, device=device).view(1, W // 2 + 1)
+    f2 = fy * fy + fx * fx
+    transfer = sum(amp * sigma * torch.exp(-2.0 * math.pi ** 2 * sigma ** 2 * f2)
+                   for sigma, amp in ((3.0, 1.0), (8.0, 1.5), (20.0, 2.0)))
 
     out_a, out_b = [], []
     ys, xs = torch.meshgrid(torch.arange(h, device=device, dtype=torch.float32),
@@ -61,9 +58,10 @@ def synth_frames_torch(n, w, h, seed, device):
     chunk = 32
     for i in range(0, n, chunk):
         m = min(chunk, n - i)
-        tex = torch.zeros(m, 1, H, W, device=device)
-        for sigma, amp in ((3.0, 1.0), (8.0, 1.5), (20.0, 2.0)):
-            tex += amp * sigma * blur(torch.randn(m, 1, H, W, device=device, generator=g), sigma)
+        # (one noise field filtered by the sum of the three Gaussians: same spectrum family as the numpy
+        # recipe's sum of three independently filtered fields; band-limited, |flow| <= 12 px)
+        noise = torch.randn(m, 1, H, W, device=device, generator=g)
+        tex = torch.fft.irfft2(torch.fft.rfft2(noise) * transfer, s=(H, W))
         tex = (tex - tex.mean((2, 3), keepdim=True)) / tex.std((2, 3), keepdim=True) * 45.0 + 128.0
         a = tex[:, :, M:M + h, M:M + w]
         b = F.grid_sample(tex, grid.expand(m, -1, -1, -1), mode="bicubic", padding_mode="border", align_corners=True)

@@ -14,6 +14,8 @@
 // no LDS is used.  The bilinear taps are plain global loads from the padded level image, which is
 // 41 KB at op-point 2 and therefore L1/L2 resident; blocks are mapped so that all patches of a
 // frame run on one XCD (its L2 then holds that frame's four planes once).
+#include <stdlib.h>
+
 #include "ofdis_kernels.h"
 
 namespace ofdis {
@@ -47,21 +49,31 @@ __device__ __forceinline__ float patch_sum(const float (&x)[M * (64 / LPP)], con
     for (int m = 1; m < M; ++m)
       if (valid[m * Q + q]) c[q] = c[q] + x[m * Q + q];
   }
+  // butterfly distances below LPP: inside the patch's lanes, every chain
 #pragma unroll
-  for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0xB1>(c[q]);   // distance 1
+  for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0xB1>(c[q]);   // 1
 #pragma unroll
   for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0x4E>(c[q]);   // 2
+  if constexpr (LPP >= 8) {
 #pragma unroll
-  for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0x141>(c[q]);  // 4
-#pragma unroll
-  for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0x140>(c[q]);  // 8
-  if constexpr (LPP == 64) {
-    return swap32_sum(swap16_sum(c[0]));
-  } else if constexpr (LPP == 32) {
-    return swap16_sum(c[0]) + swap16_sum(c[1]);       // 16 inside the half, then low + high (32)
-  } else {
-    return (c[0] + c[1]) + (c[2] + c[3]);             // 16: chains {0,1},{2,3}; 32: the two pairs
+    for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0x141>(c[q]);  // 4
   }
+  if constexpr (LPP >= 16) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0x140>(c[q]);  // 8
+  }
+  if constexpr (LPP >= 32) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) c[q] = swap16_sum(c[q]);             // 16
+  }
+  if constexpr (LPP >= 64) c[0] = swap32_sum(c[0]);                  // 32
+  // distances LPP .. 32: the chains are the virtual lanes q*LPP + pl, combine them pairwise
+#pragma unroll
+  for (int o = 1; o < Q; o <<= 1) {
+#pragma unroll
+    for (int q = 0; q < Q; q += 2 * o) c[q] = c[q] + c[q + o];
+  }
+  return c[0];
 }
 
 template <int M, int LPP>
@@ -284,11 +296,19 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
 
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   const int M = (a.g.novals + 63) / 64;
-  const int ppb = (M <= 1) ? 16 : 4;  // patches per 256-thread block
+  static const int lpp_env = getenv("OFDIS_PATCH_LPP") ? atoi(getenv("OFDIS_PATCH_LPP")) : 16;
+  const int lpp = (M <= 1) ? lpp_env : 64;  // lanes per patch
+  const int ppb = 4 * (64 / lpp);           // patches per 256-thread block
   const int blocks_per_frame = (a.g.nop + ppb - 1) / ppb;
   const int grid = ((a.nframes + 7) / 8) * 8 * blocks_per_frame;
-  if (M <= 1)
+  if (M <= 1 && lpp == 16)
     hipLaunchKernelGGL((patch_optimize_kernel<1, 16>), dim3(grid), dim3(256), 0, s, a);
+  else if (M <= 1 && lpp == 8)
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 8>), dim3(grid), dim3(256), 0, s, a);
+  else if (M <= 1 && lpp == 4)
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 4>), dim3(grid), dim3(256), 0, s, a);
+  else if (M <= 1)
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 32>), dim3(grid), dim3(256), 0, s, a);
   else if (M <= 3)
     hipLaunchKernelGGL((patch_optimize_kernel<3, 64>), dim3(grid), dim3(256), 0, s, a);
   else if (M <= 7)
