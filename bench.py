@@ -70,11 +70,11 @@ def synth_frames_torch(n, w, h, seed, device):
     return torch.cat(out_a).contiguous(), torch.cat(out_b).contiguous()
 
 
-def algorithmic_bytes(p, nframes):
+def algorithmic_bytes(p, nframes, fused_tv=True):
     """ALGORITHMIC (compulsory) HBM bytes of ONE step per kernel class, summed over its launches
     (SURVEY.md 8d per-pixel figures; fused kernels: inputs read once + outputs written once)."""
     noc = p.noc
-    out = {k: 0.0 for k in ("warp", "derivatives", "tv_system", "sor", "tv_finish", "patch_optimize", "densify")}
+    out = {k: 0.0 for k in ("warp", "derivatives", "tv_system", "sor", "tv_finish", "patch_optimize", "densify", "tv_fused")}
     launches = dict.fromkeys(out, 0)
     for l in range(p.sc_l, p.sc_f + 1):
         w, h = p.level_size(l)
@@ -92,13 +92,18 @@ def algorithmic_bytes(p, nframes):
             n_inner = p.tv_innerit * (l + 1)
             out["warp"] += (8 + 4 * noc + 4 * noc + 4) * npx          # wx,wy + src once + dst + mask
             out["derivatives"] += 40 * noc * npx                      # I0,I1w in, 8 planes out
-            out["tv_system"] += n_inner * (20 + 32 * noc + 28) * npx  # mask,wx,wy,du,dv + derivs in, 7 planes out
-            out["sor"] += n_inner * 44 * npx                          # 7 planes + du,dv in, du,dv out (3 sweeps fused)
+            fused = fused_tv and noc == 1 and h <= 64 and w >= 8 and p.tv_solverit <= 3
+            if fused:   # system + SOR in one kernel: derivs, mask, wx, wy, du, dv in; du, dv out
+                out["tv_fused"] += n_inner * (32 * noc + 20 + 8) * npx
+                launches["tv_fused"] += n_inner
+            else:
+                out["tv_system"] += n_inner * (20 + 32 * noc + 28) * npx  # mask,wx,wy,du,dv + derivs in, 7 planes out
+                out["sor"] += n_inner * 44 * npx                          # 7 planes + du,dv in, du,dv out (3 sweeps fused)
+                launches["tv_system"] += n_inner
+                launches["sor"] += n_inner
             out["tv_finish"] += 24 * npx
             launches["warp"] += 1
             launches["derivatives"] += 1
-            launches["tv_system"] += n_inner
-            launches["sor"] += n_inner
             launches["tv_finish"] += 1
     return out, launches
 
@@ -182,8 +187,12 @@ def main():
     B = args.batch
     # weak scaling: rank r owns global frames [r*B, (r+1)*B); its generator is seeded by its first frame
     ia, ib = synth_frames_torch(B, WIDTH, HEIGHT, shard.frame_seed(1234, rank * B), dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # a dedicated (non-default) stream: launches on HIP's legacy null stream carry implicit cross-stream
+    # synchronisation and measure ~30 us slower per launch on this stack
+    tstream = torch.cuda.Stream(device=dev)
+    stream = tstream.cuda_stream
     batch = capi.Batch(p, B)
+    torch.cuda.synchronize()  # frames were generated on torch's default stream
     batch.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
     torch.cuda.synchronize()
 
@@ -206,7 +215,7 @@ def main():
         for _ in range(nrep):
             batch.run(stream)
         torch.cuda.synchronize()
-        abytes, _ = algorithmic_bytes(p, B)
+        abytes, _ = algorithmic_bytes(p, B, fused_tv=not os.environ.get("OFDIS_NO_FUSED"))
         kernels = {}
         for k, name in enumerate(capi.K_NAMES):
             ms, n = batch.kernel_time(k)

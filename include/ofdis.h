@@ -124,7 +124,7 @@ int ofdis_batch_download(ofdis_batch* b, int frame, float* outflow_host, void* s
  * the named kernel class with hipEvents on `stream`; ofdis_batch_kernel_time returns the summed
  * milliseconds and launch count since the last reset (synchronises the events). */
 enum { OFDIS_K_WARP = 0, OFDIS_K_DERIV = 1, OFDIS_K_SYSTEM = 2, OFDIS_K_SOR = 3, OFDIS_K_PATCH = 4,
-       OFDIS_K_DENSIFY = 5, OFDIS_K_UPDATE = 6, OFDIS_K_COUNT = 7 };
+       OFDIS_K_DENSIFY = 5, OFDIS_K_UPDATE = 6, OFDIS_K_FUSED = 7, OFDIS_K_COUNT = 8 };
 int ofdis_batch_timing(ofdis_batch* b, int enable);
 int ofdis_batch_kernel_time(ofdis_batch* b, int kernel_class, double* ms_sum, long* launches);
 

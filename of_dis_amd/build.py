@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 ROOT = os.path.dirname(HERE)
 
-HIP_SOURCES = ["ofdis_dis.hip", "ofdis_tv.hip", "ofdis_sor.hip", "ofdis_pyr.hip", "ofdis_capi.hip"]
+HIP_SOURCES = ["ofdis_dis.hip", "ofdis_tv.hip", "ofdis_sor.hip", "ofdis_fused.hip", "ofdis_pyr.hip", "ofdis_capi.hip"]
 # -ffp-contract=off: every fp32 operation separately rounded, like the reference's SSE path.
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
             "-Wall", "-Wno-unused-function"]

@@ -18,8 +18,8 @@ _f32 = np.float32
 FP = C.POINTER(C.c_float)
 VP = C.c_void_p
 
-K_WARP, K_DERIV, K_SYSTEM, K_SOR, K_PATCH, K_DENSIFY, K_UPDATE, K_COUNT = range(8)
-K_NAMES = ["warp", "derivatives", "tv_system", "sor", "patch_optimize", "densify", "tv_finish"]
+K_WARP, K_DERIV, K_SYSTEM, K_SOR, K_PATCH, K_DENSIFY, K_UPDATE, K_FUSED, K_COUNT = range(9)
+K_NAMES = ["warp", "derivatives", "tv_system", "sor", "patch_optimize", "densify", "tv_finish", "tv_fused"]
 
 # every symbol include/ofdis.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [

@@ -3,6 +3,7 @@
 // (oflow.cpp:184-337) and the per-function entry points used for parity testing.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/time.h>
 
@@ -101,6 +102,7 @@ struct ofdis_batch {
   float *pvec = nullptr, *pweight = nullptr;
   float *wx = nullptr, *wy = nullptr, *du = nullptr, *dv = nullptr, *mask = nullptr;
   float *w_im2 = nullptr, *derivs = nullptr, *sys = nullptr;
+  float *wx_d = nullptr, *wy_d = nullptr, *mask_d = nullptr;  // diag-layout copies for the fused TV kernel
   std::vector<float*> pyr_tmp;       // unpadded level images (ofdis_batch_build_pyramids_u8), lazily allocated
   std::vector<void*> allocs;
   // timing
@@ -172,7 +174,12 @@ TvConsts tv_consts(float alpha, float gamma, float delta) {  // refine_variation
 }
 
 // VarRefClass for one level, all frames (refine_variational.cpp:25-241).  wx/wy hold the dense flow
-// (planar) on entry; the refined flow is written AoS to flow_out.
+// (planar, row-major; plus diag copies in wx_d/wy_d when the fused kernel is used) on entry; the refined
+// flow is written AoS to flow_out.
+bool use_fused(const ofdis_batch* b, const LevelGeom& g) {
+  return b->wx_d && tv_fused_supported(TvGeom{g.w, g.h, g.noc, b->nframes}, b->p.tv_solverit);
+}
+
 int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow_out,
                hipStream_t s) {
   const ofdis_params& p = b->p;
@@ -180,19 +187,32 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
   const size_t npx = (size_t)g.w * g.h;
   const int n_inner = p.tv_innerit * (g.level + 1);  // :36
   const TvConsts c = tv_consts(p.tv_alpha, p.tv_gamma, p.tv_delta);
+  const bool fused = use_fused(b, g);
   {
     KTimer kt(b, OFDIS_K_WARP, s);
-    WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx, b->wy, b->w_im2, b->mask};
-    HIPCHK(launch_warp(wa, s));
+    if (fused) {  // wx_d, wy_d in, mask_d out (diag); the warped image stays row-major
+      WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx_d, b->wy_d, b->w_im2, b->mask_d};
+      HIPCHK(launch_warp_diag(wa, s));
+    } else {
+      WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx, b->wy, b->w_im2, b->mask};
+      HIPCHK(launch_warp(wa, s));
+    }
   }
   {
     KTimer kt(b, OFDIS_K_DERIV, s);
-    DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs};
+    DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs, fused ? 1 : 0, nullptr, nullptr};
     HIPCHK(launch_derivatives(da, s));
   }
   HIPCHK(hipMemsetAsync(b->du, 0, npx * b->nframes * sizeof(float), s));  // image_erase :186-187
   HIPCHK(hipMemsetAsync(b->dv, 0, npx * b->nframes * sizeof(float), s));
   for (int it = 0; it < n_inner; ++it) {
+    if (fused) {
+      KTimer kt(b, OFDIS_K_FUSED, s);
+      FusedArgs fa{t, b->derivs, b->mask_d, b->wx_d, b->wy_d, b->du, b->dv, c.quarter_alpha, c.half_delta_over3,
+                   c.half_gamma_over3, p.tv_solverit, p.tv_sor};
+      HIPCHK(launch_tv_fused(fa, s));
+      continue;
+    }
     {
       KTimer kt(b, OFDIS_K_SYSTEM, s);
       SystemArgs sa{t, b->mask, b->wx, b->wy, b->du, b->dv, b->derivs, c.quarter_alpha, c.half_delta_over3,
@@ -207,7 +227,10 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
   }
   {
     KTimer kt(b, OFDIS_K_UPDATE, s);
-    HIPCHK(launch_tv_finish(t, b->wx, b->wy, b->du, b->dv, flow_out, s));
+    if (fused)
+      HIPCHK(launch_tv_finish(t, b->wx_d, b->wy_d, b->du, b->dv, flow_out, 1, s));
+    else
+      HIPCHK(launch_tv_finish(t, b->wx, b->wy, b->du, b->dv, flow_out, 0, s));
   }
   return OFDIS_OK;
 }
@@ -295,6 +318,11 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
     if (!rc) rc = dalloc(b, &b->w_im2, npx * p->noc);
     if (!rc) rc = dalloc(b, &b->derivs, npx * 8 * p->noc);
     if (!rc) rc = dalloc(b, &b->sys, npx * 7);
+    if (!rc && p->noc == 1 && !getenv("OFDIS_NO_FUSED")) {
+      rc = dalloc(b, &b->wx_d, npx);
+      if (!rc) rc = dalloc(b, &b->wy_d, npx);
+      if (!rc) rc = dalloc(b, &b->mask_d, npx);
+    }
   }
   if (rc) {
     ofdis_batch_destroy(b);
@@ -419,7 +447,12 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
       d.nframes = b->nframes;
       d.p = b->pvec;
       d.pweight = b->pweight;
-      if (p.usetvref) { d.wx = b->wx; d.wy = b->wy; } else d.flow_aos = b->flow[ii];
+      if (p.usetvref) {
+        if (use_fused(b, g)) { d.wx_diag = b->wx_d; d.wy_diag = b->wy_d; }  // diag only
+        else { d.wx = b->wx; d.wy = b->wy; }
+      } else {
+        d.flow_aos = b->flow[ii];
+      }
       HIPCHK(launch_densify(d, s));
     }
     if (verbose > 1) { (void)hipStreamSynchronize(s); tt[3] = now_ms() - t0; t0 = now_ms(); }
@@ -509,7 +542,7 @@ int ofdis_image_warp(float* dst, float* mask, const float* src, const float* wx,
 int ofdis_get_derivatives(float* out, const float* im1, const float* im2w, int w, int h, int noc, int nframes,
                           void* stream) {
   if (!out || !im1 || !im2w || w < 1 || h < 4 || nframes < 1) return fail(OFDIS_ERR_INVALID, "bad arguments (need h >= 4)");
-  DerivArgs a{TvGeom{w, h, noc, nframes}, im1, 0, 0, 0, 0, im2w, out};
+  DerivArgs a{TvGeom{w, h, noc, nframes}, im1, 0, 0, 0, 0, im2w, out, 0, nullptr, nullptr};
   HIPCHK(launch_derivatives(a, (hipStream_t)stream));
   return OFDIS_OK;
 }
@@ -620,9 +653,18 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   if (!rc) rc = dalloc(&b, &b.w_im2, npx * p->noc);
   if (!rc) rc = dalloc(&b, &b.derivs, npx * 8 * p->noc);
   if (!rc) rc = dalloc(&b, &b.sys, npx * 7);
+  const bool want_fused = p->noc == 1 && !getenv("OFDIS_NO_FUSED") &&
+                          tv_fused_supported(TvGeom{g.w, g.h, g.noc, nframes}, p->tv_solverit);
+  if (!rc && want_fused) {
+    rc = dalloc(&b, &b.wx_d, npx);
+    if (!rc) rc = dalloc(&b, &b.wy_d, npx);
+    if (!rc) rc = dalloc(&b, &b.mask_d, npx);
+  }
   if (!rc) {
     TvGeom t{g.w, g.h, g.noc, nframes};
     hipError_t e = launch_flow_split(t, flow, b.wx, b.wy, s);
+    if (e == hipSuccess && want_fused) e = launch_to_diag(b.wx, b.wx_d, g.w, g.h, nframes, s);
+    if (e == hipSuccess && want_fused) e = launch_to_diag(b.wy, b.wy_d, g.w, g.h, nframes, s);
     if (e != hipSuccess) rc = hipfail(e, "flow_split");
   }
   if (!rc) rc = run_varref(&b, g, im_a, im_b, flow, s);

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
 
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   const int M = (a.g.novals + 63) / 64;
-  static const int lpp_env = getenv("OFDIS_PATCH_LPP") ? atoi(getenv("OFDIS_PATCH_LPP")) : 16;
+  static const int lpp_env = getenv("OFDIS_PATCH_LPP") ? atoi(getenv("OFDIS_PATCH_LPP")) : 8;
   const int lpp = (M <= 1) ? lpp_env : 64;  // lanes per patch
   const int ppb = 4 * (64 / lpp);           // patches per 256-thread block
   const int blocks_per_frame = (a.g.nop + ppb - 1) / ppb;
@@ -335,7 +335,16 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
        idx += (long long)gridDim.x * blockDim.x) {
     const int frame = (int)(idx / npx);
     const int i = (int)(idx - (long long)frame * npx);
-    const int y = i / g.w, x = i - y * g.w;
+    int y, x;
+    if (PLANAR && a.wx == nullptr) {  // diag-only output: enumerate pixels in diag order (coalesced stores)
+      const int d = i / g.h;
+      y = i - d * g.h;
+      x = d - y;
+      if (x < 0) x += g.w * ((-x + g.w - 1) / g.w);
+    } else {
+      y = i / g.w;
+      x = i - y * g.w;
+    }
     const int P = g.P, lb = -P / 2, ub = P / 2 - 1, st = g.steps, noc = g.noc;
     // rx + lb <= x <= rx + ub, rx = gx*st + offw
     int gx_lo = (x - ub - g.offw + st - 1);
@@ -387,8 +396,18 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
       fv /= we;
     }
     if (PLANAR) {
-      a.wx[idx] = fu;
-      a.wy[idx] = fv;
+      if (a.wx) {
+        a.wx[idx] = fu;
+        a.wy[idx] = fv;
+        if (a.wx_diag) {
+          const size_t dg = (size_t)frame * npx + diag_index(x, y, g.w, g.h);
+          a.wx_diag[dg] = fu;
+          a.wy_diag[dg] = fv;
+        }
+      } else {  // idx IS the diag-linear index
+        a.wx_diag[idx] = fu;
+        a.wy_diag[idx] = fv;
+      }
     } else {
       reinterpret_cast<float2*>(a.flow_aos)[idx] = make_float2(fu, fv);
     }

@@ -30,8 +30,10 @@ struct DensifyArgs {
   const float* p;        // [B][nop][2]
   const float* pweight;  // [B][nop][novals]
   float* flow_aos;       // if non-null: AoS output
-  float* wx;             // else planar outputs
+  float* wx;             // else planar outputs (row-major)
   float* wy;
+  float* wx_diag;        // optional second copy in the solver's diag layout (fused TV path)
+  float* wy_diag;
 };
 // PatGridClass::AggregateFlowDense as an order-preserving gather
 hipError_t launch_densify(const DensifyArgs& a, hipStream_t s);
@@ -52,6 +54,9 @@ struct WarpArgs {
   float* mask;
 };
 hipError_t launch_warp(const WarpArgs& a, hipStream_t s);
+// same computation with wx, wy read from and mask written to the solver's diag layout (fused TV path);
+// src must be the padded pyramid plane, dst stays row-major (the derivative stencils read it)
+hipError_t launch_warp_diag(const WarpArgs& a, hipStream_t s);
 
 // get_derivatives.  im1 as for WarpArgs.src; im2w packed planar [B][noc][h][w].
 // out [B][8][noc][h][w]
@@ -60,7 +65,10 @@ struct DerivArgs {
   const float* im1;
   int im1_padded, pad, tmp_w, tmp_h;
   const float* im2w;
-  float* out;
+  float* out;            // [B][8][noc][h][w] row-major, or [B][8][noc][w*h] diag when out_diag
+  int out_diag;
+  const float* mask_rm;  // with out_diag: row-major mask to be copied ...
+  float* mask_diag;      // ... into diag layout (may be null)
 };
 hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s);
 
@@ -89,6 +97,24 @@ struct SorArgs {
 };
 hipError_t launch_sor(const SorArgs& a, hipStream_t s);
 
+// One TV fixed-point iteration fused: compute_smoothness + compute_data + 2x sub_laplacian produce each
+// anti-diagonal's system coefficients in registers, immediately consumed by the wavefront SOR of
+// ofdis_sor.hip (h <= 64, gray).  Every plane in diag layout.
+struct FusedArgs {
+  TvGeom t;
+  const float* derivs;  // [B][8][w*h]
+  const float* mask;    // [B][w*h]
+  const float* wx;      // [B][w*h]
+  const float* wy;
+  float* du;            // in/out
+  float* dv;
+  float quarter_alpha, half_delta_over3, half_gamma_over3;
+  int iterations;
+  float omega;
+};
+bool tv_fused_supported(const TvGeom& t, int iterations);
+hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s);
+
 // layout conversion of `nplanes` planes of w x h (row-major <-> diag); used by the per-function entry
 // points, whose public interface is row-major
 hipError_t launch_to_diag(const float* src_rm, float* dst_diag, int w, int h, long long nplanes, hipStream_t s);
@@ -96,7 +122,7 @@ hipError_t launch_from_diag(const float* src_diag, float* dst_rm, int w, int h, 
 
 // uu=wx+du, vv=wy+dv -> AoS flow (refine_variational.cpp:209-221, 92-99); wx,wy row-major, du,dv DIAG
 hipError_t launch_tv_finish(const TvGeom& t, const float* wx, const float* wy, const float* du, const float* dv,
-                            float* flow_aos, hipStream_t s);
+                            float* flow_aos, int wxy_diag, hipStream_t s);
 // AoS flow -> planar wx, wy (refine_variational.cpp:56-68)
 hipError_t launch_flow_split(const TvGeom& t, const float* flow_aos, float* wx, float* wy, hipStream_t s);
 

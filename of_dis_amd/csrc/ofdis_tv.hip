@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "ofdis_kernels.h"
+#include "ofdis_tvmath.h"
 
 namespace ofdis {
 
@@ -109,6 +110,81 @@ hipError_t launch_warp(const WarpArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Tile variant for the fused TV path: wx, wy arrive in the diag layout (written by the densify kernel) and
+// the mask leaves in it.  A 32x32 tile is gathered through LDS with the rotated enumeration (contiguous runs
+// on the global side, conflict-free on the LDS side), processed row-major 4 px per thread so that the
+// bilinear taps stay local and the warped image is stored with 16-byte writes, and the mask is
+// transposed back through LDS.
+__global__ __launch_bounds__(256) void warp_diag_kernel(const WarpArgs a) {
+  constexpr int TW = 32, TH = 32;
+  __shared__ __attribute__((aligned(16))) float wx_t[TH * TW];
+  __shared__ __attribute__((aligned(16))) float wy_t[TH * TW];
+  __shared__ __attribute__((aligned(16))) float m_t[TH * TW];
+  const int w = a.t.w, h = a.t.h, noc = a.t.noc;
+  const int npx = w * h;
+  const int tiles_x = (w + TW - 1) / TW;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int frame = blockIdx.y;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const size_t fo = (size_t)frame * npx;
+  for (int n = threadIdx.x; n < TH * TW; n += 256) {
+    const int ry = n % TH, r = n / TH;
+    const int rx = (r - ry) & (TW - 1);
+    const int y = y0 + ry, x = x0 + rx;
+    float fx = 0.0f, fy = 0.0f;
+    if (y < h && x < w) {
+      const size_t o = fo + diag_index(x, y, w, h);
+      fx = a.wx[o];
+      fy = a.wy[o];
+    }
+    wx_t[ry * TW + rx] = fx;
+    wy_t[ry * TW + rx] = fy;
+  }
+  __syncthreads();
+  {
+    const int ry = threadIdx.x >> 3, q4 = (threadIdx.x & 7) * 4;
+    const int y = y0 + ry, x = x0 + q4;
+    if (y < h && x < w) {
+      const float4 fx = *reinterpret_cast<const float4*>(&wx_t[ry * TW + q4]);
+      const float4 fy = *reinterpret_cast<const float4*>(&wy_t[ry * TW + q4]);
+      const float fxs[4] = {fx.x, fx.y, fx.z, fx.w}, fys[4] = {fy.x, fy.y, fy.z, fy.w};
+      float m[4], r[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        m[k] = 0.0f;
+        r[k][0] = r[k][1] = r[k][2] = 0.0f;
+        if (x + k < w) warp_pixel<true>(a, frame, x + k, y, fxs[k], fys[k], m[k], r[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m_t[ry * TW + q4 + k] = m[k];
+      for (int c = 0; c < noc; ++c) {
+        float* d = a.dst + ((size_t)frame * noc + c) * npx + (size_t)y * w + x;
+        if (x + 3 < w && (w & 3) == 0) {
+          *reinterpret_cast<float4*>(d) = make_float4(r[0][c], r[1][c], r[2][c], r[3][c]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (x + k < w) d[k] = r[k][c];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < TH * TW; n += 256) {
+    const int ry = n % TH, r = n / TH;
+    const int rx = (r - ry) & (TW - 1);
+    const int y = y0 + ry, x = x0 + rx;
+    if (y < h && x < w) a.mask[fo + diag_index(x, y, w, h)] = m_t[ry * TW + rx];
+  }
+}
+
+hipError_t launch_warp_diag(const WarpArgs& a, hipStream_t s) {
+  if (!a.src_padded) return hipErrorInvalidValue;
+  const int tiles = ((a.t.w + 31) / 32) * ((a.t.h + 31) / 32);
+  hipLaunchKernelGGL(warp_diag_kernel, dim3(tiles, a.t.nframes), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------ derivatives
 // 5-tap derivative filter of refine_variational.cpp:45-46 through convolve_extract_coeffs(even=0)
 // (image.c:338-349): coeffs = { 1/12, -8/12, -0, 8/12, -1/12 }
@@ -139,12 +215,15 @@ __device__ __forceinline__ float v5(const float* t, int pitch, int qy, int qx, i
   return D5_C0 * m2 + D5_C1 * m1 + D5_C2 * s0 + D5_C3 * p1 + D5_C4 * p2;
 }
 
-template <bool PADDED>
+template <bool PADDED, bool DIAG>
 __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
-  __shared__ float avg_t[DA_H * DA_W];
-  __shared__ float iz_t[DA_H * DA_W];
-  __shared__ float ix_t[DX_H * DX_W];
-  __shared__ float iy_t[DX_H * DX_W];
+  constexpr int IN_FLOATS = 2 * DA_H * DA_W + 2 * DX_H * DX_W;
+  constexpr int OUT_FLOATS = DIAG ? 9 * DT_H * DT_W : 0;  // staging for the diag transposition (8 planes + mask)
+  __shared__ float lds[IN_FLOATS > OUT_FLOATS ? IN_FLOATS : OUT_FLOATS];
+  float* avg_t = lds;
+  float* iz_t = avg_t + DA_H * DA_W;
+  float* ix_t = iz_t + DA_H * DA_W;
+  float* iy_t = ix_t + DX_H * DX_W;
   const int w = a.t.w, h = a.t.h, noc = a.t.noc;
   const int npx = w * h;
   const int tiles_x = (w + DT_W - 1) / DT_W;
@@ -178,136 +257,92 @@ __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
       iy_t[n] = v5(avg_t, DA_W, ay, ax, y, h);
     }
     __syncthreads();
-    // stage 2: outputs
-    {
-      const int qy = tid / DT_W, qx = tid - qy * DT_W;
-      for (int ry = qy; ry < DT_H; ry += 256 / DT_W) {
+    // stage 2: the eight derivative values of this thread's (two) pixels
+    constexpr int NPIX = DT_W * DT_H / 256;
+    float res[NPIX][8];
+    const int qx = tid % DT_W;
+#pragma unroll
+    for (int k = 0; k < NPIX; ++k) {
+      const int ry = tid / DT_W + k * (256 / DT_W);
+      const int y = clampi(y0 + ry, 0, h - 1);   // rows/columns beyond the image are computed on clamped
+      const int ey = ry + 2, ex = qx + 2;        // coordinates and never stored
+      const int ay = ry + 4, ax = qx + 4;
+      res[k][0] = ix_t[ey * DX_W + ex];
+      res[k][1] = iy_t[ey * DX_W + ex];
+      res[k][2] = iz_t[ay * DA_W + ax];
+      res[k][3] = h5(ix_t, DX_W, ey, ex);
+      res[k][4] = v5(ix_t, DX_W, ey, ex, y, h);
+      res[k][5] = v5(iy_t, DX_W, ey, ex, y, h);
+      res[k][6] = h5(iz_t, DA_W, ay, ax);
+      res[k][7] = v5(iz_t, DA_W, ay, ax, y, h);
+    }
+    if (!DIAG) {
+#pragma unroll
+      for (int k = 0; k < NPIX; ++k) {
+        const int ry = tid / DT_W + k * (256 / DT_W);
         const int y = y0 + ry, x = x0 + qx;
         if (y < h && x < w) {
-          const int ey = ry + 2, ex = qx + 2;    // in Ix/Iy tile
-          const int ay = ry + 4, ax = qx + 4;    // in avg/Iz tile
           float* out = a.out + ((size_t)frame * 8 * noc + c) * npx + y * w + x;
           const size_t ks = (size_t)noc * npx;
-          out[0 * ks] = ix_t[ey * DX_W + ex];
-          out[1 * ks] = iy_t[ey * DX_W + ex];
-          out[2 * ks] = iz_t[ay * DA_W + ax];
-          out[3 * ks] = h5(ix_t, DX_W, ey, ex);
-          out[4 * ks] = v5(ix_t, DX_W, ey, ex, y, h);
-          out[5 * ks] = v5(iy_t, DX_W, ey, ex, y, h);
-          out[6 * ks] = h5(iz_t, DA_W, ay, ax);
-          out[7 * ks] = v5(iz_t, DA_W, ay, ax, y, h);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) out[q * ks] = res[k][q];
         }
       }
+      __syncthreads();
+    } else {
+      __syncthreads();  // input tiles dead: the LDS becomes the staging area [plane][ry][qx]
+#pragma unroll
+      for (int k = 0; k < NPIX; ++k) {
+        const int ry = tid / DT_W + k * (256 / DT_W);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lds[(q * DT_H + ry) * DT_W + qx] = res[k][q];
+        if (c == 0 && a.mask_diag) {
+          const int y = y0 + ry, x = x0 + qx;
+          lds[(8 * DT_H + ry) * DT_W + qx] = (y < h && x < w) ? a.mask_rm[(size_t)frame * npx + y * w + x] : 0.0f;
+        }
+      }
+      __syncthreads();
+      // rotated enumeration: consecutive lanes walk an anti-diagonal of the tile = a contiguous diag run
+      for (int n = tid; n < DT_H * DT_W; n += 256) {
+        const int ry = n % DT_H, r = n / DT_H;
+        const int rx = (r - ry) & (DT_W - 1);
+        const int y = y0 + ry, x = x0 + rx;
+        if (y < h && x < w) {
+          const size_t dg = diag_index(x, y, w, h);
+          float* out = a.out + ((size_t)frame * 8 * noc + c) * npx + dg;
+          const size_t ks = (size_t)noc * npx;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) out[q * ks] = lds[(q * DT_H + ry) * DT_W + rx];
+          if (c == 0 && a.mask_diag) a.mask_diag[(size_t)frame * npx + dg] = lds[(8 * DT_H + ry) * DT_W + rx];
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
 hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s) {
   if (a.t.h < 4) return hipErrorInvalidValue;  // the reference's vertical filter reads rows 0..3
   const int tiles = ((a.t.w + DT_W - 1) / DT_W) * ((a.t.h + DT_H - 1) / DT_H);
-  if (a.im1_padded)
-    hipLaunchKernelGGL(derivatives_kernel<true>, dim3(tiles, a.t.nframes), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(derivatives_kernel<false>, dim3(tiles, a.t.nframes), dim3(256), 0, s, a);
+  const dim3 g(tiles, a.t.nframes), b(256);
+  if (a.out_diag) {
+    if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((derivatives_kernel<false, true>), g, b, 0, s, a);
+  } else {
+    if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true, false>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((derivatives_kernel<false, false>), g, b, 0, s, a);
+  }
   return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------ TV system
-// 3-tap flow derivative of refine_variational.cpp:47-48: coeffs = { -0.5, -0, 0.5 }
-#define D3_C0 (-0.5f)
-#define D3_C1 (-0.0f)
-#define D3_C2 (0.5f)
-#define EPS_SMOOTH (0.001f * 0.001f)
-#define EPS_COLOR (0.001f * 0.001f)
-#define EPS_GRAD (0.001f * 0.001f)
-#define DATANORM (0.1f * 0.1f)
-
-constexpr int ST_W = 32, ST_H = 32;              // output tile (4 pixels per thread)
+#ifndef OFDIS_ST_H
+#define OFDIS_ST_H 32
+#endif
+constexpr int ST_W = 32, ST_H = OFDIS_ST_H;       // output tile
 constexpr int SU_W = ST_W + 4, SU_H = ST_H + 4;  // wx/wy/du/dv tile (halo 2)
 constexpr int SS_W = ST_W + 2, SS_H = ST_H + 2;  // smoothness tile (halo 1)
 constexpr int ST_PIX = ST_W * ST_H / 256;        // pixels per thread
-
-// data term of one pixel (opticalflow_aux.c:342-427).  D(k,c): derivative plane k, channel c.
-template <typename DF>
-__device__ __forceinline__ void data_term(DF D, int noc, float m, float u, float v, float hd3, float hg3, float& a11,
-                                          float& a12, float& a22, float& b1, float& b2) {
-  a11 = 0.0f; a12 = 0.0f; a22 = 0.0f; b1 = 0.0f; b2 = 0.0f;
-  if (noc == 1) {
-    const float ix = D(0, 0), iy = D(1, 0), iz = D(2, 0), ixx = D(3, 0), ixy = D(4, 0), iyy = D(5, 0), ixz = D(6, 0),
-                iyz = D(7, 0);
-    float tmp, tmp2, n1, n2;
-    if (hd3 != 0.0f) {
-      tmp = iz + ix * u + iy * v;
-      n1 = ix * ix + iy * iy + DATANORM;
-      tmp = m * hd3 / sqrtf(3 * tmp * tmp / n1 + EPS_COLOR);
-      tmp /= n1;
-      a11 += tmp * ix * ix;
-      a12 += tmp * ix * iy;
-      a22 += tmp * iy * iy;
-      b1 -= tmp * iz * ix;
-      b2 -= tmp * iz * iy;
-    }
-    n1 = ixx * ixx + ixy * ixy + DATANORM;
-    n2 = iyy * iyy + ixy * ixy + DATANORM;
-    tmp = ixz + ixx * u + ixy * v;
-    tmp2 = iyz + ixy * u + iyy * v;
-    tmp = m * hg3 / sqrtf(3 * tmp * tmp / n1 + 3 * tmp2 * tmp2 / n2 + EPS_GRAD);
-    tmp2 = tmp / n2;
-    tmp /= n1;
-    a11 += tmp * ixx * ixx + tmp2 * ixy * ixy;
-    a12 += tmp * ixx * ixy + tmp2 * ixy * iyy;
-    a22 += tmp2 * iyy * iyy + tmp * ixy * ixy;
-    b1 -= tmp * ixx * ixz + tmp2 * ixy * iyz;
-    b2 -= tmp2 * iyy * iyz + tmp * ixy * ixz;
-    a11 *= 3; a12 *= 3; a22 *= 3; b1 *= 3; b2 *= 3;
-  } else {
-    float ix[3], iy[3], iz[3], ixx[3], ixy[3], iyy[3], ixz[3], iyz[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      ix[c] = D(0, c); iy[c] = D(1, c); iz[c] = D(2, c); ixx[c] = D(3, c);
-      ixy[c] = D(4, c); iyy[c] = D(5, c); ixz[c] = D(6, c); iyz[c] = D(7, c);
-    }
-    if (hd3 != 0.0f) {
-      float t[3], nn[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        t[c] = iz[c] + ix[c] * u + iy[c] * v;
-        nn[c] = ix[c] * ix[c] + iy[c] * iy[c] + DATANORM;
-      }
-      float tmp = m * hd3 / sqrtf(t[0] * t[0] / nn[0] + t[1] * t[1] / nn[1] + t[2] * t[2] / nn[2] + EPS_COLOR);
-      const float tt[3] = {tmp / nn[0], tmp / nn[1], tmp / nn[2]};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        a11 += tt[c] * ix[c] * ix[c];
-        a12 += tt[c] * ix[c] * iy[c];
-        a22 += tt[c] * iy[c] * iy[c];
-        b1 -= tt[c] * iz[c] * ix[c];
-        b2 -= tt[c] * iz[c] * iy[c];
-      }
-    }
-    float n1[3], n2[3], t1[3], t2[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      n1[c] = ixx[c] * ixx[c] + ixy[c] * ixy[c] + DATANORM;
-      n2[c] = iyy[c] * iyy[c] + ixy[c] * ixy[c] + DATANORM;
-      t1[c] = ixz[c] + ixx[c] * u + ixy[c] * v;
-      t2[c] = iyz[c] + ixy[c] * u + iyy[c] * v;
-    }
-    const float tmp = m * hg3 /
-                      sqrtf(t1[0] * t1[0] / n1[0] + t2[0] * t2[0] / n2[0] + t1[1] * t1[1] / n1[1] +
-                            t2[1] * t2[1] / n2[1] + t1[2] * t1[2] / n1[2] + t2[2] * t2[2] / n2[2] + EPS_GRAD);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float w1 = tmp / n1[c], w2 = tmp / n2[c];
-      a11 += w1 * ixx[c] * ixx[c] + w2 * ixy[c] * ixy[c];
-      a12 += w1 * ixx[c] * ixy[c] + w2 * ixy[c] * iyy[c];
-      a22 += w2 * iyy[c] * iyy[c] + w1 * ixy[c] * ixy[c];
-      b1 -= w1 * ixx[c] * ixz[c] + w2 * ixy[c] * iyz[c];
-      b2 -= w2 * iyy[c] * iyz[c] + w1 * ixy[c] * ixz[c];
-    }
-  }
-}
 
 // One 32x32 image tile per block.  du/dv arrive in the solver's diag layout and the seven outputs
 // leave in it; both transpositions go through LDS with a "rotated" enumeration (consecutive lanes
@@ -453,6 +488,7 @@ hipError_t launch_tv_system(const SystemArgs& a, hipStream_t s) {
 // uu = wx + du, vv = wy + dv -> AoS flow.  du/dv live in the solver's diag layout: a 32x32 tile is
 // gathered through LDS with the rotated enumeration (contiguous runs on the global side), then
 // written row-major as float2.
+template <bool WXY_DIAG>
 __global__ __launch_bounds__(256) void tv_finish_kernel(int w, int h, const float* wx, const float* wy,
                                                         const float* du, const float* dv, float2* flow) {
   constexpr int TW = 32, TH = 32;
@@ -470,8 +506,13 @@ __global__ __launch_bounds__(256) void tv_finish_kernel(int w, int h, const floa
     const int y = y0 + ry, x = x0 + rx;
     if (y < h && x < w) {
       const size_t o = fo + diag_index(x, y, w, h);
-      du_t[ry * TW + rx] = du[o];
-      dv_t[ry * TW + rx] = dv[o];
+      if (WXY_DIAG) {  // the sum is formed here, where all four operands are contiguous runs
+        du_t[ry * TW + rx] = wx[o] + du[o];
+        dv_t[ry * TW + rx] = wy[o] + dv[o];
+      } else {
+        du_t[ry * TW + rx] = du[o];
+        dv_t[ry * TW + rx] = dv[o];
+      }
     }
   }
   __syncthreads();
@@ -480,15 +521,22 @@ __global__ __launch_bounds__(256) void tv_finish_kernel(int w, int h, const floa
     const int y = y0 + ry, x = x0 + qx;
     if (y < h && x < w) {
       const size_t o = fo + (size_t)y * w + x;
-      flow[o] = make_float2(wx[o] + du_t[ry * TW + qx], wy[o] + dv_t[ry * TW + qx]);
+      if (WXY_DIAG)
+        flow[o] = make_float2(du_t[ry * TW + qx], dv_t[ry * TW + qx]);
+      else
+        flow[o] = make_float2(wx[o] + du_t[ry * TW + qx], wy[o] + dv_t[ry * TW + qx]);
     }
   }
 }
 hipError_t launch_tv_finish(const TvGeom& t, const float* wx, const float* wy, const float* du, const float* dv,
-                            float* flow_aos, hipStream_t s) {
+                            float* flow_aos, int wxy_diag, hipStream_t s) {
   const int tiles = ((t.w + 31) / 32) * ((t.h + 31) / 32);
-  hipLaunchKernelGGL(tv_finish_kernel, dim3(tiles, t.nframes), dim3(256), 0, s, t.w, t.h, wx, wy, du, dv,
-                     reinterpret_cast<float2*>(flow_aos));
+  if (wxy_diag)
+    hipLaunchKernelGGL(tv_finish_kernel<true>, dim3(tiles, t.nframes), dim3(256), 0, s, t.w, t.h, wx, wy, du, dv,
+                       reinterpret_cast<float2*>(flow_aos));
+  else
+    hipLaunchKernelGGL(tv_finish_kernel<false>, dim3(tiles, t.nframes), dim3(256), 0, s, t.w, t.h, wx, wy, du, dv,
+                       reinterpret_cast<float2*>(flow_aos));
   return hipGetLastError();
 }
 
