@@ -22,6 +22,11 @@ HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "
             "-Wall", "-Wno-unused-function"]
 
 
+# ofdis_dis.hip: the SLP vectoriser pairs the independent reduction chains into v_pk_add_f32 fed by
+# separate v_mov_b32_dpp (2.5 instructions per chain step); without it every step is one v_add_f32_dpp.
+PER_FILE_FLAGS = {"ofdis_dis.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc():
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -62,7 +67,7 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         if force or _newer(obj, [sp] + headers):
-            _run([hipcc] + HIPFLAGS + ["-c", sp, "-o", obj], verbose)
+            _run([hipcc] + HIPFLAGS + PER_FILE_FLAGS.get(src, []) + ["-c", sp, "-o", obj], verbose)
         objs.append(obj)
     so = lib_path()
     if force or _newer(so, objs):

@@ -31,9 +31,14 @@ __device__ __forceinline__ float dpp_mov(float x, float old = 0.0f) {
   return __builtin_bit_cast(
       float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
 }
+// same, lanes without a source read 0 (bound_ctrl): no "old" register has to be prepared
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov0(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
 // lane l <- lane l-1 (lane 0 keeps `old`); lane l <- lane l+1 (lane 63 keeps `old`)
-__device__ __forceinline__ float wave_from_prev(float x, float old = 0.0f) { return dpp_mov<0x138>(x, old); }  // wave_shr:1
-__device__ __forceinline__ float wave_from_next(float x, float old = 0.0f) { return dpp_mov<0x130>(x, old); }  // wave_shl:1
+__device__ __forceinline__ float wave_from_prev(float x) { return dpp_mov0<0x138>(x); }  // wave_shr:1, lane 0 <- 0
+__device__ __forceinline__ float wave_from_next(float x) { return dpp_mov0<0x130>(x); }  // wave_shl:1, lane 63 <- 0
 
 // 64-lane butterfly all-reduce.  Order of the additions (this IS the documented reduction order,
 // mirrored by oracle/eigen_shim -DOFDIS_SHIM_WAVE64 and oracle_set_reduce_order(1)):

@@ -76,10 +76,13 @@ __device__ __forceinline__ float patch_sum(const float (&x)[M * (64 / LPP)], con
   return c[0];
 }
 
-template <int M, int LPP>
+// FULL: novals == 64*M, every entry slot is a real patch entry (the validity selects fold away);
+// COST: the cost function as a compile-time constant, or -1 to read it from the arguments.
+template <int M, int LPP, bool FULL, int COST>
 __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   constexpr int Q = 64 / LPP;  // patches per wavefront == accumulation chains per lane
   constexpr int E = M * Q;     // patch entries per lane
+  const int costfct = COST >= 0 ? COST : a.costfct;
   const LevelGeom& g = a.g;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   for (int e = 0; e < E; ++e) {
     const int k = (e / Q) * 64 + (e % Q) * LPP + pl;
     kidx[e] = k;
-    valid[e] = k < nv;
+    valid[e] = FULL ? true : (k < nv);
     const int kk = valid[e] ? k : 0;
     const int c = kk % noc, q = kk / noc;
     const int col = q % P, row = q / P;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   // x / novals: when novals is a power of two the product with its reciprocal is the same correctly
   // rounded value as the reference's division (both round the same real number), at 1/10 the cost
   const float fnv = (float)nv;
-  const bool nv_pow2 = (nv & (nv - 1)) == 0;
+  const bool nv_pow2 = FULL ? ((M & (M - 1)) == 0) : ((nv & (nv - 1)) == 0);
   const float inv_nv = 1.0f / fnv;
   auto div_nv = [&](float x) { return nv_pow2 ? x * inv_nv : x / fnv; };
 
@@ -221,9 +224,9 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       float d = v[e] - T[e];
-      if (a.costfct == 1) {
+      if (costfct == 1) {
         d = copysignf(sqrtf(fabsf(d)), d);
-      } else if (a.costfct == 2) {
+      } else if (costfct == 2) {
         const float bsq = 5.0f * 5.0f, bsq2 = bsq * 2.0f;
         d = copysignf(sqrtf((sqrtf(1.0f + (d * d) / bsq) - 1.0f) * bsq2), d);
       }
@@ -294,6 +297,206 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------ gray 8x8 fast path
+// Specialisation of patch_optimize_kernel<1, 8, true, COST> for the gray operating points 1 and 2
+// (noc = 1, P = 8, novals = 64): same arithmetic, same reduction order, bit-identical results; what
+// changes is how the target patch is fetched.  A lane owns one COLUMN of its patch (entries q*8 + pl,
+// q = row), and the four bilinear taps of row q are
+//     a = I[row q][col]   b = I[row q][col-1]   c = I[row q-1][col]   d = I[row q-1][col-1]
+// so c,d of a row are a,b of the row above: 9 rows x 2 loads per lane instead of 8 x 4.  The loads are
+// buffer loads: one per-lane byte offset for the whole patch (computed once per iteration), the row
+// stride as a wave-uniform SGPR offset and the column shift in the instruction's immediate field, i.e.
+// no per-load address arithmetic.
+template <int COST>
+__global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs a) {
+  constexpr int M = 1, LPP = 8, Q = 8, E = 8;
+  const int costfct = COST >= 0 ? COST : a.costfct;
+  const LevelGeom& g = a.g;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int blocks_per_frame = (g.nop + 4 * Q - 1) / (4 * Q);
+  int frame, blk;
+  xcd_frame_map(blockIdx.x, blocks_per_frame, frame, blk);
+  if (frame >= a.nframes) return;  // block-uniform
+  const int sub = lane / LPP;
+  const int pl = lane % LPP;
+  int ip = (blk * 4 + wave) * Q + sub;
+  const bool live = ip < g.nop;
+  if (!live) ip = g.nop - 1;  // idle lane group: shadows the last patch, never stores
+
+  const int tw = g.tmp_w;
+  const size_t plane = g.plane_elems;
+  const float* __restrict__ imA = a.im_a + (size_t)frame * plane;
+  const float* __restrict__ imAx = a.im_a_dx + (size_t)frame * plane;
+  const float* __restrict__ imAy = a.im_a_dy + (size_t)frame * plane;
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.im_b + (size_t)frame * plane), 0, (int)(plane * sizeof(float)), 0x00020000);
+  const int row_bytes = tw * 4;
+
+  const int gx = ip / g.noph, gy = ip - gx * g.noph;
+  const float rx = (float)(gx * g.steps + g.offw), ry = (float)(gy * g.steps + g.offh);
+  bool valid[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) valid[e] = true;
+  const float inv_nv = 1.0f / 64.0f;  // x/64 == x*(1/64): both round the same real number
+
+  // ---- InitializePatch (patch.cpp:287-332): entry q = row q of this lane's column
+  float T[E], Tx[E], Ty[E];
+  {
+    const int px = (int)roundf(rx) + g.pad, py = (int)roundf(ry) + g.pad;
+    const unsigned base = (unsigned)((py - 4) * tw + px - 4 + pl);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const unsigned o = base + (unsigned)(e * tw);
+      T[e] = imA[o];
+      Tx[e] = imAx[o];
+      Ty[e] = imAy[o];
+    }
+    if (a.patnorm > 0) {
+      const float mean = patch_sum<M, LPP>(T, valid) * inv_nv;
+#pragma unroll
+      for (int e = 0; e < E; ++e) T[e] -= mean;
+    }
+  }
+  // ---- ComputeHessian + Cholesky factor (patch.cpp:71-88, Eigen LLT as in oracle/eigen_shim)
+  float l00, l10, l11;
+  {
+    float pxx[E], pxy[E], pyy[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      pxx[e] = Tx[e] * Tx[e];
+      pxy[e] = Tx[e] * Ty[e];
+      pyy[e] = Ty[e] * Ty[e];
+    }
+    float H00 = patch_sum<M, LPP>(pxx, valid);
+    const float H01 = patch_sum<M, LPP>(pxy, valid);
+    float H11 = patch_sum<M, LPP>(pyy, valid);
+    if (H00 * H11 - H01 * H01 == 0.0f) {
+      H00 = (float)((double)H00 + 1e-10);
+      H11 = (float)((double)H11 + 1e-10);
+    }
+    l00 = H00; l10 = H01; l11 = H11;
+    if (!(l00 <= 0.0f)) {
+      l00 = sqrtf(l00);
+      l10 = l10 / l00;
+      const float x = l11 - l10 * l10;
+      if (!(x <= 0.0f)) l11 = sqrtf(x);
+    }
+  }
+  // ---- InitializeFromCoarserOF (patchgrid.cpp:195-211)
+  float pin0 = 0.0f, pin1 = 0.0f;
+  if (a.flow_prev) {
+    const int x = (int)floorf(rx / 2), y = (int)floorf(ry / 2);
+    const int i = y * (g.w / 2) + x;
+    const float* fp = a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2) * 2;
+    pin0 = fp[2 * i] * 2;
+    pin1 = fp[2 * i + 1] * 2;
+  }
+  // ---- OptimizeIter (patch.cpp:159-212)
+  float p0 = pin0, p1 = pin1;
+  float ptx = rx + p0, pty = ry + p1;
+  const float stx = ptx, sty = pty;
+  float dp0 = 0.0f, dp1 = 0.0f;
+  float dpsq = 1e-10f, dpsq_init = 1e-10f, mares = 1e20f, mares_old = 1e20f;
+  int cnt = 0;
+  bool converged = false;
+  float pdiff[E], pw[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { pdiff[e] = 0.0f; pw[e] = 0.0f; }
+
+  auto compute_err = [&]() {  // patch.cpp:264-284, 335-402, 223-262
+    int pos0 = (int)ceilf(ptx + .00001f), pos1 = (int)ceilf(pty + .00001f);
+    const int pos2 = (int)floorf(ptx), pos3 = (int)floorf(pty);
+    const float r0 = ptx - (float)pos2, r1 = pty - (float)pos3;
+    const float we0 = r0 * r1, we1 = (1 - r0) * r1, we2 = r0 * (1 - r1), we3 = (1 - r0) * (1 - r1);
+    pos0 += g.pad;
+    pos1 += g.pad;
+    // byte offset of (row pos1-5, column pos0-5+pl): rows rr = 0..8 follow at rr*row_bytes, the
+    // lane's own column (tap a / c) is +4 bytes, its left neighbour (tap b / d) +0
+    const int voff = ((pos1 - 5) * tw + pos0 - 5 + pl) * 4;
+    float A[9], Bn[9];
+#pragma unroll
+    for (int rr = 0; rr < 9; ++rr) {
+      A[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voff + 4, rr * row_bytes, 0));
+      Bn[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voff, rr * row_bytes, 0));
+    }
+    float v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = we0 * A[e + 1] + we1 * Bn[e + 1] + we2 * A[e] + we3 * Bn[e];
+    if (a.patnorm > 0) {
+      const float mean = patch_sum<M, LPP>(v, valid) * inv_nv;
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] -= mean;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float d = v[e] - T[e];
+      if (costfct == 1) {
+        d = copysignf(sqrtf(fabsf(d)), d);
+      } else if (costfct == 2) {
+        const float bsq = 5.0f * 5.0f, bsq2 = bsq * 2.0f;
+        d = copysignf(sqrtf((sqrtf(1.0f + (d * d) / bsq) - 1.0f) * bsq2), d);
+      }
+      pdiff[e] = d;
+      pw[e] = fabsf(d);
+    }
+    dpsq = dp0 * dp0 + dp1 * dp1;
+    if (cnt == 1) dpsq_init = dpsq;
+    mares_old = mares;
+    mares = patch_sum<M, LPP>(pw, valid) * inv_nv;
+    bool go = (cnt < a.max_iter) && (mares > a.res_thresh);
+    if (go && cnt >= a.min_iter) go = (dpsq / dpsq_init >= a.dp_thresh_sq) && (mares / mares_old <= a.dr_thresh);
+    if (!go) converged = true;
+  };
+  auto oob = [&](float x, float y) { return x < g.lb || y < g.lb || x > g.ubw || y > g.ubh; };
+
+  if (oob(ptx, pty) || !(isfinite(ptx) && isfinite(pty))) {
+    converged = true;
+  } else {
+    cnt = 0; dpsq = 1e-10f; dpsq_init = 1e-10f; mares = 1e5f; mares_old = 1e20f;
+    compute_err();
+  }
+  while (!converged) {
+    cnt++;
+    float gxr[E], gyr[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      gxr[e] = Tx[e] * pdiff[e];
+      gyr[e] = Ty[e] * pdiff[e];
+    }
+    const float b0 = patch_sum<M, LPP>(gxr, valid);
+    const float b1 = patch_sum<M, LPP>(gyr, valid);
+    const float y0 = b0 / l00;
+    const float y1 = (b1 - l10 * y0) / l11;
+    dp1 = y1 / l11;
+    dp0 = (y0 - l10 * dp1) / l00;
+    p0 -= dp0;
+    p1 -= dp1;
+    ptx = rx + p0;
+    pty = ry + p1;
+    const float ex = stx - ptx, ey = sty - pty;
+    if (sqrtf(ex * ex + ey * ey) > a.outlierthresh || oob(ptx, pty) || !(isfinite(ptx) && isfinite(pty))) {
+      p0 = pin0;
+      p1 = pin1;
+      ptx = rx + p0;
+      pty = ry + p1;
+      converged = true;
+    }
+    compute_err();
+  }
+
+  if (live) {
+    float* pout = a.p_out + ((size_t)frame * g.nop + ip) * 2;
+    if (pl == 0) {
+      pout[0] = p0;
+      pout[1] = p1;
+    }
+    float* pwout = a.pweight + ((size_t)frame * g.nop + ip) * 64;
+#pragma unroll
+    for (int e = 0; e < E; ++e) pwout[e * 8 + pl] = pw[e];
+  }
+}
+
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   const int M = (a.g.novals + 63) / 64;
   static const int lpp_env = getenv("OFDIS_PATCH_LPP") ? atoi(getenv("OFDIS_PATCH_LPP")) : 8;
@@ -301,20 +504,31 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   const int ppb = 4 * (64 / lpp);           // patches per 256-thread block
   const int blocks_per_frame = (a.g.nop + ppb - 1) / ppb;
   const int grid = ((a.nframes + 7) / 8) * 8 * blocks_per_frame;
-  if (M <= 1 && lpp == 16)
-    hipLaunchKernelGGL((patch_optimize_kernel<1, 16>), dim3(grid), dim3(256), 0, s, a);
+  const dim3 gd(grid), bd(256);
+  const bool full = a.g.novals == 64 * M;
+  const bool gray8 = a.g.noc == 1 && a.g.P == 8 && !getenv("OFDIS_NO_GRAY8");
+  if (M <= 1 && lpp == 8 && gray8 && a.costfct == 0)
+    hipLaunchKernelGGL((patch_optimize_gray8_kernel<0>), gd, bd, 0, s, a);
+  else if (M <= 1 && lpp == 8 && gray8)
+    hipLaunchKernelGGL((patch_optimize_gray8_kernel<-1>), gd, bd, 0, s, a);
+  else if (M <= 1 && lpp == 8 && full && a.costfct == 0)
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 8, true, 0>), gd, bd, 0, s, a);
+  else if (M <= 1 && lpp == 8 && full)
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 8, true, -1>), gd, bd, 0, s, a);
   else if (M <= 1 && lpp == 8)
-    hipLaunchKernelGGL((patch_optimize_kernel<1, 8>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 8, false, -1>), gd, bd, 0, s, a);
+  else if (M <= 1 && lpp == 16)
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 16, false, -1>), gd, bd, 0, s, a);
   else if (M <= 1 && lpp == 4)
-    hipLaunchKernelGGL((patch_optimize_kernel<1, 4>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 4, false, -1>), gd, bd, 0, s, a);
   else if (M <= 1)
-    hipLaunchKernelGGL((patch_optimize_kernel<1, 32>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 32, false, -1>), gd, bd, 0, s, a);
   else if (M <= 3)
-    hipLaunchKernelGGL((patch_optimize_kernel<3, 64>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<3, 64, false, -1>), gd, bd, 0, s, a);
   else if (M <= 7)
-    hipLaunchKernelGGL((patch_optimize_kernel<7, 64>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<7, 64, false, -1>), gd, bd, 0, s, a);
   else if (M <= 12)
-    hipLaunchKernelGGL((patch_optimize_kernel<12, 64>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<12, 64, false, -1>), gd, bd, 0, s, a);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
