@@ -92,10 +92,10 @@ def algorithmic_bytes(p, nframes, fused_tv=True):
             n_inner = p.tv_innerit * (l + 1)
             out["warp"] += (8 + 4 * noc + 4 * noc + 4) * npx          # wx,wy + src once + dst + mask
             out["derivatives"] += 40 * noc * npx                      # I0,I1w in, 8 planes out
-            fused = fused_tv and noc == 1 and h <= 64 and w >= 8 and p.tv_solverit <= 3
+            fused = fused_tv and noc == 1 and h <= 64 and w >= 16 and p.tv_solverit <= 3
             if fused:   # system + SOR in one kernel: derivs, mask, wx, wy, du, dv in; du, dv out
                 out["tv_fused"] += n_inner * (32 * noc + 20 + 8) * npx
-                launches["tv_fused"] += n_inner
+                launches["tv_fused"] += 1
             else:
                 out["tv_system"] += n_inner * (20 + 32 * noc + 28) * npx  # mask,wx,wy,du,dv + derivs in, 7 planes out
                 out["sor"] += n_inner * 44 * npx                          # 7 planes + du,dv in, du,dv out (3 sweeps fused)

@@ -205,14 +205,13 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
   }
   HIPCHK(hipMemsetAsync(b->du, 0, npx * b->nframes * sizeof(float), s));  // image_erase :186-187
   HIPCHK(hipMemsetAsync(b->dv, 0, npx * b->nframes * sizeof(float), s));
-  for (int it = 0; it < n_inner; ++it) {
-    if (fused) {
-      KTimer kt(b, OFDIS_K_FUSED, s);
-      FusedArgs fa{t, b->derivs, b->mask_d, b->wx_d, b->wy_d, b->du, b->dv, c.quarter_alpha, c.half_delta_over3,
-                   c.half_gamma_over3, p.tv_solverit, p.tv_sor};
-      HIPCHK(launch_tv_fused(fa, s));
-      continue;
-    }
+  if (fused && n_inner > 0) {  // every fixed-point iteration of this level in one launch
+    KTimer kt(b, OFDIS_K_FUSED, s);
+    FusedArgs fa{t, b->derivs, b->mask_d, b->wx_d, b->wy_d, b->du, b->dv, c.quarter_alpha, c.half_delta_over3,
+                 c.half_gamma_over3, p.tv_solverit, p.tv_sor, n_inner};
+    HIPCHK(launch_tv_fused(fa, s));
+  }
+  for (int it = 0; it < n_inner && !fused; ++it) {
     {
       KTimer kt(b, OFDIS_K_SYSTEM, s);
       SystemArgs sa{t, b->mask, b->wx, b->wy, b->du, b->dv, b->derivs, c.quarter_alpha, c.half_delta_over3,

@@ -21,6 +21,13 @@
 //     slot (system of the pixel row t+1, consumed by the sweeps at t+1, t+3, t+5)  ring 6
 // du/dv are read (old values, rows >= t+1) strictly ahead of where the last sweep stores (row t-4).
 //
+// All n_inner fixed-point iterations of a level run inside ONE launch, back to back per lane: the diag rows
+// wrap (row = t mod w), so when a lane has finished column w-1 of iteration k it continues with column 0 of
+// iteration k+1 on the next step.  That is legal because everything iteration k+1 needs around a pixel
+// (du of iteration k within a radius of two pixels) was finalised w-9 or more steps earlier, and it removes
+// the fill/drain bubble of the skewed sweep from every iteration but the first and last:
+// n_inner*w + h steps instead of n_inner*(w + h).
+//
 // Border rules: horizontal neighbours are clamped exactly as the reference's shifted row copies
 // (image.c:436-464); for the 3-tap vertical filter the clamped form c0*s0 + c1*s0 + c2*s1 has the same
 // value as the reference's folded (c0+c1)*s0 + c2*s1 because c1 = -0 (image.c:376-399).
@@ -108,7 +115,8 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
   int srow = wrap(-3 - 2 * (NS - 1));  // row finished by the last sweep at step t = -3
   int xq = wrap(-3 - j);               // this lane's x on diag row t (per lane)
 
-  const int tend = (w - 1) + (h - 1) + 2 * (NS - 1);
+  const int wtot = a.n_inner * w;  // columns per lane over all iterations
+  const int tend = (wtot - 1) + (h - 1) + 2 * (NS - 1);
   for (int k0 = 0; k0 <= tend + 3; k0 += U) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -184,10 +192,9 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
       }
       // ---- (5) SOR step t (ofdis_sor.hip): sweep 0 reaches pixel (j, t - j)
       {
-        const int i0 = t - j;
         FSlot& c = slot[u % 6];
         const FSlot& p = slot[(u + 5) % 6];
-        c.hl = (i0 > 0) ? p.sh : 0.0f;
+        c.hl = (xq > 0) ? p.sh : 0.0f;  // xq = this lane's column on diag row t
         c.vt = wave_from_prev(p.sv);
         float d = c.hl + c.sh;
         if (has_top) d = d + c.vt;
@@ -201,7 +208,8 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
       float nu[NS], nv[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const int i = t - j - 2 * s;
+        int i = xq - 2 * s;  // column of sweep s (wrapped: the lane may already be in the next iteration)
+        if (i < 0) i += w;
         const FSlot& c = slot[(u - 2 * s + 12) % 6];
         float ou, ov, rgu, rgv, bu, bv;
         if (s == 0) {
@@ -230,8 +238,8 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
         nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
       }
       {
-        const int i = t - j - 2 * (NS - 1);
-        if (row_ok && i >= 0 && i < w) {
+        const int ig = t - j - 2 * (NS - 1);  // global column index over all iterations
+        if (row_ok && ig >= 0 && ig < wtot) {
           dup[srow * h] = nu[NS - 1];
           dvp[srow * h] = nv[NS - 1];
         }
@@ -248,11 +256,11 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
 }
 
 bool tv_fused_supported(const TvGeom& t, int iterations) {
-  return t.noc == 1 && t.h >= 2 && t.h <= 64 && t.w >= 8 && iterations >= 1 && iterations <= 3;
+  return t.noc == 1 && t.h >= 2 && t.h <= 64 && t.w >= 16 && iterations >= 1 && iterations <= 3;
 }
 
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s) {
-  if (!tv_fused_supported(a.t, a.iterations)) return hipErrorInvalidValue;
+  if (!tv_fused_supported(a.t, a.iterations) || a.n_inner < 1) return hipErrorInvalidValue;
   const int h = a.t.h;
   const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
   const int G = 64 / R;

@@ -109,8 +109,9 @@ struct FusedArgs {
   float* du;            // in/out
   float* dv;
   float quarter_alpha, half_delta_over3, half_gamma_over3;
-  int iterations;
+  int iterations;  // SOR sweeps per fixed-point iteration (tv_solverit)
   float omega;
+  int n_inner;     // fixed-point iterations run back to back inside one launch
 };
 bool tv_fused_supported(const TvGeom& t, int iterations);
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s);
