@@ -152,9 +152,9 @@ def cpu_baseline(p, batch, nsample, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=2048, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=4096, help="frame pairs per GPU per step")
     ap.add_argument("--tv", choices=["on", "off"], default="on")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
@@ -228,11 +228,26 @@ def main():
                              "algorithmic_MB_per_step": round(abytes[name] / 1e6, 2),
                              "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
         batch.timing(False)
+        # HBM traffic per step from the PMC counters (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, calibrated in
+        # profiles/r01_pmc_calibration.txt), collected by tools/pmc_traffic.py for this batch size
+        traffic = {}
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj.get("batch") == B and tj.get("tv") == args.tv:
+                traffic = tj["bytes_per_step"]
+        except Exception:
+            pass
+        for name, k in kernels.items():
+            if name in traffic:
+                k["pmc_traffic_MB_per_step"] = round(traffic[name] / 1e6, 2)
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": None,
+                    "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"],
+                    "traffic": traffic.get(dom),
                     "note": "achieved = algorithmic bytes of all launches of this kernel class in one step / their "
-                            "summed HIP-event time; PMC traffic: see profiles/"}
+                            "summed HIP-event time (bytes/s); traffic = PMC HBM bytes of the same launches per step "
+                            "(profiles/traffic.json). The two dominant kernels (tv_fused, patch_optimize) are VALU-issue "
+                            "bound (PMC: profiles/*pmc_sq*), not HBM bound; see DESIGN.md section 4"}
         result = {
             "metric": "frames/sec at 1024x436 op-point-2 (INT)", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

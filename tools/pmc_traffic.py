@@ -1,0 +1,41 @@
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE; WRITE_SIZE) of `bench.py --steps 1 --warmup 0` into
+profiles/traffic.json: HBM bytes per step per kernel class.
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <batch> <tv> <nrun_steps>
+
+Corrections (MI355X_MICROARCH.md "HBM", re-measured in profiles/r01_pmc_calibration.txt on known byte counts):
+FETCH_SIZE is in KiB and reports exactly half of the bytes read (4 B/lane and 16 B/lane alike); WRITE_SIZE is in
+KiB and exact.  bench.py runs `nrun_steps` = warmup + steps + 3 timing passes of the pipeline; counters are
+summed over all dispatches of a kernel class and divided by that number.
+"""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+CLASS = {"warp": "warp", "derivatives": "derivatives", "tv_system": "tv_system", "sor_": "sor", "tv_fused": "tv_fused",
+         "patch_optimize": "patch_optimize", "densify": "densify", "tv_finish": "tv_finish"}
+
+
+def collect(path, counter, scale):
+    acc = defaultdict(float)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r.get("Kernel_Name", "")
+        for key, cls in CLASS.items():
+            if "ofdis::" + key in name:
+                acc[cls] += float(r["Counter_Value"]) * scale
+    return acc
+
+
+fetch = collect(sys.argv[1], "FETCH_SIZE", 2 * 1024.0)
+write = collect(sys.argv[2], "WRITE_SIZE", 1024.0)
+batch, tv, nsteps = int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
+out = {"batch": batch, "tv": tv, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 (calibrated)",
+       "bytes_per_step": {k: (fetch[k] + write[k]) / nsteps for k in sorted(set(fetch) | set(write))},
+       "read_bytes_per_step": {k: fetch[k] / nsteps for k in sorted(fetch)},
+       "write_bytes_per_step": {k: write[k] / nsteps for k in sorted(write)}}
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps(out["bytes_per_step"], indent=1))
