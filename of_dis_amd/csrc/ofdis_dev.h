@@ -82,4 +82,14 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // one such row per step (ofdis_sor.hip).
 __host__ __device__ __forceinline__ int diag_index(int x, int y, int w, int h) { return ((x + y) % w) * h + y; }
 
+// Blocks of one frame stay on one XCD: the dispatcher places block n on XCD n % 8 (observed, used for L2
+// affinity only -- correctness does not depend on it), so block n works on frame (n/8/bpf)*8 + n%8.
+// Launch ((nframes+7)/8)*8*blocks_per_frame blocks and skip frame >= nframes.
+__device__ __forceinline__ void xcd_frame_map(int n, int blocks_per_frame, int& frame, int& blk) {
+  const int xcd = n & 7;
+  const int m = n >> 3;
+  frame = (m / blocks_per_frame) * 8 + xcd;
+  blk = m % blocks_per_frame;
+}
+
 }  // namespace ofdis

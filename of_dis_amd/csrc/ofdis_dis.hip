@@ -20,15 +20,6 @@
 
 namespace ofdis {
 
-// blocks of one frame stay on one XCD: the dispatcher places block n on XCD n%8 (observed, used
-// for L2 affinity only -- correctness does not depend on it).
-__device__ __forceinline__ void xcd_frame_map(int n, int blocks_per_frame, int& frame, int& blk) {
-  const int xcd = n & 7;
-  const int m = n >> 3;
-  frame = (m / blocks_per_frame) * 8 + xcd;
-  blk = m % blocks_per_frame;
-}
-
 // Sum over one patch vector in the documented 64-lane butterfly order (ofdis_dev.h: lane partials over
 // entries l, l+64, ...; then pairs at lane distance 1,2,4,8,16,32).
 //
@@ -544,11 +535,14 @@ template <bool PLANAR>
 __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
   const LevelGeom& g = a.g;
   const int npx = g.w * g.h;
-  const long long total = (long long)npx * a.nframes;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int frame = (int)(idx / npx);
-    const int i = (int)(idx - (long long)frame * npx);
+  const int blocks_per_frame = (npx + 255) / 256;
+  int frame, blk;
+  xcd_frame_map(blockIdx.x, blocks_per_frame, frame, blk);  // a frame's blocks share one XCD's L2
+  if (frame >= a.nframes) return;
+  {
+    const int i = blk * 256 + threadIdx.x;
+    if (i >= npx) return;
+    const long long idx = (long long)frame * npx + i;
     int y, x;
     if (PLANAR && a.wx == nullptr) {  // diag-only output: enumerate pixels in diag order (coalesced stores)
       const int d = i / g.h;
@@ -629,9 +623,8 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
 }
 
 hipError_t launch_densify(const DensifyArgs& a, hipStream_t s) {
-  const long long total = (long long)a.g.w * a.g.h * a.nframes;
-  long long blocks = (total + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
+  const int blocks_per_frame = (a.g.w * a.g.h + 255) / 256;
+  const long long blocks = (long long)((a.nframes + 7) / 8) * 8 * blocks_per_frame;
   if (a.flow_aos)
     hipLaunchKernelGGL(densify_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   else

@@ -123,8 +123,10 @@ __global__ __launch_bounds__(256) void warp_diag_kernel(const WarpArgs a) {
   const int w = a.t.w, h = a.t.h, noc = a.t.noc;
   const int npx = w * h;
   const int tiles_x = (w + TW - 1) / TW;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int frame = blockIdx.y;
+  int frame, tile;
+  xcd_frame_map(blockIdx.x, tiles_x * ((h + TH - 1) / TH), frame, tile);
+  if (frame >= a.t.nframes) return;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x0 = tx * TW, y0 = ty * TH;
   const size_t fo = (size_t)frame * npx;
   for (int n = threadIdx.x; n < TH * TW; n += 256) {
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void warp_diag_kernel(const WarpArgs a) {
 hipError_t launch_warp_diag(const WarpArgs& a, hipStream_t s) {
   if (!a.src_padded) return hipErrorInvalidValue;
   const int tiles = ((a.t.w + 31) / 32) * ((a.t.h + 31) / 32);
-  hipLaunchKernelGGL(warp_diag_kernel, dim3(tiles, a.t.nframes), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(warp_diag_kernel, dim3(((a.t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -227,8 +229,10 @@ __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
   const int w = a.t.w, h = a.t.h, noc = a.t.noc;
   const int npx = w * h;
   const int tiles_x = (w + DT_W - 1) / DT_W;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int frame = blockIdx.y;
+  int frame, tile;
+  xcd_frame_map(blockIdx.x, tiles_x * ((h + DT_H - 1) / DT_H), frame, tile);
+  if (frame >= a.t.nframes) return;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x0 = tx * DT_W, y0 = ty * DT_H;
   const int tid = threadIdx.x;
 
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
 hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s) {
   if (a.t.h < 4) return hipErrorInvalidValue;  // the reference's vertical filter reads rows 0..3
   const int tiles = ((a.t.w + DT_W - 1) / DT_W) * ((a.t.h + DT_H - 1) / DT_H);
-  const dim3 g(tiles, a.t.nframes), b(256);
+  const dim3 g(((a.t.nframes + 7) / 8) * 8 * tiles), b(256);
   if (a.out_diag) {
     if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true, true>), g, b, 0, s, a);
     else hipLaunchKernelGGL((derivatives_kernel<false, true>), g, b, 0, s, a);
@@ -360,8 +364,10 @@ __global__ __launch_bounds__(256) void tv_system_kernel(const SystemArgs a) {
   const int w = a.t.w, h = a.t.h, noc = a.t.noc;
   const int npx = w * h;
   const int tiles_x = (w + ST_W - 1) / ST_W;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int frame = blockIdx.y;
+  int frame, tile;
+  xcd_frame_map(blockIdx.x, tiles_x * ((h + ST_H - 1) / ST_H), frame, tile);
+  if (frame >= a.t.nframes) return;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x0 = tx * ST_W, y0 = ty * ST_H;
   const int tid = threadIdx.x;
   const size_t fo = (size_t)frame * npx;
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(256) void tv_system_kernel(const SystemArgs a) {
 
 hipError_t launch_tv_system(const SystemArgs& a, hipStream_t s) {
   const int tiles = ((a.t.w + ST_W - 1) / ST_W) * ((a.t.h + ST_H - 1) / ST_H);
-  hipLaunchKernelGGL(tv_system_kernel, dim3(tiles, a.t.nframes), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(tv_system_kernel, dim3(((a.t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -489,15 +495,17 @@ hipError_t launch_tv_system(const SystemArgs& a, hipStream_t s) {
 // gathered through LDS with the rotated enumeration (contiguous runs on the global side), then
 // written row-major as float2.
 template <bool WXY_DIAG>
-__global__ __launch_bounds__(256) void tv_finish_kernel(int w, int h, const float* wx, const float* wy,
+__global__ __launch_bounds__(256) void tv_finish_kernel(int w, int h, int nframes, const float* wx, const float* wy,
                                                         const float* du, const float* dv, float2* flow) {
   constexpr int TW = 32, TH = 32;
   __shared__ float du_t[TH * TW];
   __shared__ float dv_t[TH * TW];
   const int npx = w * h;
   const int tiles_x = (w + TW - 1) / TW;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int frame = blockIdx.y;
+  int frame, tile;
+  xcd_frame_map(blockIdx.x, tiles_x * ((h + TH - 1) / TH), frame, tile);
+  if (frame >= nframes) return;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x0 = tx * TW, y0 = ty * TH;
   const size_t fo = (size_t)frame * npx;
   for (int n = threadIdx.x; n < TH * TW; n += 256) {
@@ -532,10 +540,10 @@ hipError_t launch_tv_finish(const TvGeom& t, const float* wx, const float* wy, c
                             float* flow_aos, int wxy_diag, hipStream_t s) {
   const int tiles = ((t.w + 31) / 32) * ((t.h + 31) / 32);
   if (wxy_diag)
-    hipLaunchKernelGGL(tv_finish_kernel<true>, dim3(tiles, t.nframes), dim3(256), 0, s, t.w, t.h, wx, wy, du, dv,
+    hipLaunchKernelGGL(tv_finish_kernel<true>, dim3(((t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, t.w, t.h, t.nframes, wx, wy, du, dv,
                        reinterpret_cast<float2*>(flow_aos));
   else
-    hipLaunchKernelGGL(tv_finish_kernel<false>, dim3(tiles, t.nframes), dim3(256), 0, s, t.w, t.h, wx, wy, du, dv,
+    hipLaunchKernelGGL(tv_finish_kernel<false>, dim3(((t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, t.w, t.h, t.nframes, wx, wy, du, dv,
                        reinterpret_cast<float2*>(flow_aos));
   return hipGetLastError();
 }
