@@ -169,7 +169,184 @@ __global__ __launch_bounds__(256) void sor_wave_kernel(const SorArgs a, const in
   }
 }
 
-// Fallback for shapes the wavefront kernel does not cover (h > 64, more than 4 sweeps, degenerate
+// Level heights above 64 rows: one WORKGROUP per frame, wave k owns rows 64k..64k+63, all waves advance in
+// lock step (one barrier per step).  The neighbour values that cross a wave boundary -- the row above lane 0
+// and the row below lane 63 -- travel through a double-buffered LDS mailbox written at the end of a step and
+// read at the start of the next; everything else is the single-wave kernel.  Up to 16 waves (h <= 1024).
+template <int NS, int PD, int MAXT>
+__global__ __launch_bounds__(MAXT) void sor_block_kernel(const SorArgs a) {
+  constexpr int LIFE = (2 * (NS - 1) > 1) ? 2 * (NS - 1) : 1;
+  constexpr int RS = PD + LIFE + 1;
+  constexpr int NV = 2 * NS + 2;  // mailbox floats per direction
+  __shared__ float mail_top[2][16][NV];  // published by lane 63 of wave k for lane 0 of wave k+1
+  __shared__ float mail_bot[2][16][NV];  // published by lane 0 of wave k for lane 63 of wave k-1
+  const int w = a.t.w, h = a.t.h;
+  const int npx = w * h;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nwaves = blockDim.x >> 6;
+  const int f = blockIdx.x;
+  const int jr = threadIdx.x;
+  const bool row_ok = jr < h;
+  const int j = jr < h ? jr : h - 1;
+  const bool has_top = j > 0, has_bot = j < h - 1;
+  const bool first_lane = lane == 0 && wave > 0, last_lane = lane == 63 && wave + 1 < nwaves;
+  const float omega = a.omega;
+
+  const float* __restrict__ sysf = a.sys + (size_t)f * 7 * npx + j;
+  float* __restrict__ duf = a.du + (size_t)f * npx + j;
+  float* __restrict__ dvf = a.dv + (size_t)f * npx + j;
+
+  SorSlot ring[RS];
+#pragma unroll
+  for (int r = 0; r < RS; ++r) ring[r] = SorSlot{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float ru[NS], rv[NS], ru2[NS], rv2[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { ru[s] = rv[s] = ru2[s] = rv2[s] = 0.0f; }
+
+  auto load_slot = [&](SorSlot& sl, int drow, int drow1) {
+    const int o = drow * h;
+    sl.a11 = sysf[0 * (size_t)npx + o];
+    sl.a12 = sysf[1 * (size_t)npx + o];
+    sl.a22 = sysf[2 * (size_t)npx + o];
+    sl.b1 = sysf[3 * (size_t)npx + o];
+    sl.b2 = sysf[4 * (size_t)npx + o];
+    sl.sh = sysf[5 * (size_t)npx + o];
+    sl.sv = sysf[6 * (size_t)npx + o];
+    sl.dur = duf[drow1 * h];
+    sl.dvr = dvf[drow1 * h];
+  };
+  auto next_row = [&](int r) { return (r + 1 == w) ? 0 : r + 1; };
+
+  int lrow = 0;
+#pragma unroll
+  for (int q = 0; q < PD; ++q) {
+    load_slot(ring[q], lrow, next_row(lrow));
+    lrow = next_row(lrow);
+  }
+  ring[RS - 1].dur = duf[0];
+  ring[RS - 1].dvr = dvf[0];
+  int srow = (w - ((2 * (NS - 1)) % w)) % w;
+
+  // mailbox for step 0: nothing has been computed yet (all neighbours' columns are out of range), but
+  // sweep 0's "bottom old" of lane 63 is lane 0-of-next-wave's right value of step 0, which is loaded
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) mail_bot[1][wave][q] = 0.0f;
+    mail_bot[1][wave][0] = ring[0].dur;
+    mail_bot[1][wave][1] = ring[0].dvr;
+  }
+  if (lane == 63) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) mail_top[1][wave][q] = 0.0f;
+  }
+  __syncthreads();
+
+  const int tend = (w - 1) + (h - 1) + 2 * (NS - 1);
+  for (int t0 = 0; t0 <= tend; t0 += RS) {
+#pragma unroll
+    for (int u = 0; u < RS; ++u) {
+      const int t = t0 + u;
+      const int rd = (t + 1) & 1;  // mailbox written at the end of step t-1
+      load_slot(ring[(u + PD) % RS], lrow, next_row(lrow));
+      lrow = next_row(lrow);
+      // neighbour values from the adjacent waves (published at the end of the previous step)
+      float top_sv = 0.0f, top_u[NS], top_v[NS], bot_u[NS], bot_v[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { top_u[s] = top_v[s] = bot_u[s] = bot_v[s] = 0.0f; }
+      if (first_lane) {
+        top_sv = mail_top[rd][wave - 1][2 * NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { top_u[s] = mail_top[rd][wave - 1][s]; top_v[s] = mail_top[rd][wave - 1][NS + s]; }
+      }
+      if (last_lane) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { bot_u[s] = mail_bot[rd][wave + 1][2 * s]; bot_v[s] = mail_bot[rd][wave + 1][2 * s + 1]; }
+      }
+      {
+        const int i0 = t - j;
+        SorSlot& c = ring[u];
+        const SorSlot& p = ring[(u + RS - 1) % RS];
+        c.hl = (i0 > 0) ? p.sh : 0.0f;
+        c.vt = wave_from_prev(p.sv);
+        if (first_lane) c.vt = top_sv;
+        float d = c.hl + c.sh;
+        if (has_top) d = d + c.vt;
+        if (has_bot) d = d + c.sv;
+        const float A11 = c.a22 + d, A22 = c.a11 + d;
+        const float det = A11 * A22 - c.a12 * c.a12;
+        c.a11 = A11 / det;
+        c.a22 = A22 / det;
+        c.a12 = c.a12 / (-det);
+      }
+      float nu[NS], nv[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int i = t - j - 2 * s;
+        const SorSlot& c = ring[(u - 2 * s + 2 * RS) % RS];
+        float ou, ov, rgu, rgv, bu, bv;
+        if (s == 0) {
+          const SorSlot& p = ring[(u + RS - 1) % RS];
+          ou = p.dur; ov = p.dvr;
+          rgu = c.dur; rgv = c.dvr;
+          bu = wave_from_next(c.dur);
+          bv = wave_from_next(c.dvr);
+        } else {
+          ou = ru2[s - 1]; ov = rv2[s - 1];
+          rgu = ru[s - 1]; rgv = rv[s - 1];
+          bu = wave_from_next(ru[s - 1]);
+          bv = wave_from_next(rv[s - 1]);
+        }
+        if (last_lane) { bu = bot_u[s]; bv = bot_v[s]; }
+        if (!(i < w - 1)) { rgu = 0.0f; rgv = 0.0f; }
+        float tu = wave_from_prev(ru[s]), tv = wave_from_prev(rv[s]);
+        if (first_lane) { tu = top_u[s]; tv = top_v[s]; }
+        const float lu = ru[s], lv = rv[s];
+        float s1 = c.sh * rgu, s2 = c.sh * rgv;
+        if (has_top) { s1 = s1 + c.vt * tu; s2 = s2 + c.vt * tv; }
+        if (has_bot) { s1 = s1 + c.sv * bu; s2 = s2 + c.sv * bv; }
+        s1 = s1 + c.b1;
+        s2 = s2 + c.b2;
+        float B1 = s1, B2 = s2;
+        if (i > 0) { B1 = c.hl * lu + s1; B2 = c.hl * lv + s2; }
+        nu[s] = ou + omega * (c.a11 * B1 + c.a12 * B2 - ou);
+        nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
+      }
+      {
+        const int i = t - j - 2 * (NS - 1);
+        if (row_ok && i >= 0 && i < w) {
+          duf[srow * h] = nu[NS - 1];
+          dvf[srow * h] = nv[NS - 1];
+        }
+        srow = next_row(srow);
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        ru2[s] = ru[s]; rv2[s] = rv[s];
+        ru[s] = nu[s]; rv[s] = nv[s];
+      }
+      // publish for step t+1 (buffer t & 1)
+      const int wr = t & 1;
+      if (lane == 63) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { mail_top[wr][wave][s] = ru[s]; mail_top[wr][wave][NS + s] = rv[s]; }
+        mail_top[wr][wave][2 * NS] = ring[u].sv;  // slot of step t: the next step's top weight
+      }
+      if (lane == 0) {
+        // bottom-old of sweep s at step t+1: sweep 0 -> this lane's right value of step t+1; sweep s>0 -> its
+        // sweep s-1 result of step t
+        const SorSlot& nx = ring[(u + 1) % RS];
+        mail_bot[wr][wave][0] = nx.dur;
+        mail_bot[wr][wave][1] = nx.dvr;
+#pragma unroll
+        for (int s = 1; s < NS; ++s) { mail_bot[wr][wave][2 * s] = ru[s - 1]; mail_bot[wr][wave][2 * s + 1] = rv[s - 1]; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Fallback for shapes neither wavefront kernel covers (h > 1024, more sweeps than they pipeline, degenerate
 // sizes): one thread per frame walks the image in raster order (diag-layout operands).  Correct for
 // every input the reference accepts, slow; only large-image configurations reach it.
 __global__ void sor_serial_kernel(const SorArgs a) {
@@ -240,6 +417,23 @@ hipError_t launch_sor(const SorArgs& a, hipStream_t s) {
       case 2: hipLaunchKernelGGL((sor_wave_kernel<2, PD>), dim3(blocks), dim3(256), 0, s, a, R); break;
       case 3: hipLaunchKernelGGL((sor_wave_kernel<3, PD>), dim3(blocks), dim3(256), 0, s, a, R); break;
       default: hipLaunchKernelGGL((sor_wave_kernel<4, PD>), dim3(blocks), dim3(256), 0, s, a, R); break;
+    }
+  } else if (w >= 2 && h > 64 && h <= 1024 && a.iterations >= 1 && a.iterations <= 3) {
+    const int threads = ((h + 63) / 64) * 64;
+    // <= 640 threads leave 170 VGPRs per lane (no spills); taller levels take the 1024-thread build
+    const dim3 g(a.t.nframes), b(threads);
+    if (threads <= 640) {
+      switch (a.iterations) {
+        case 1: hipLaunchKernelGGL((sor_block_kernel<1, PD, 640>), g, b, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((sor_block_kernel<2, PD, 640>), g, b, 0, s, a); break;
+        default: hipLaunchKernelGGL((sor_block_kernel<3, PD, 640>), g, b, 0, s, a); break;
+      }
+    } else {
+      switch (a.iterations) {
+        case 1: hipLaunchKernelGGL((sor_block_kernel<1, PD, 1024>), g, b, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((sor_block_kernel<2, PD, 1024>), g, b, 0, s, a); break;
+        default: hipLaunchKernelGGL((sor_block_kernel<3, PD, 1024>), g, b, 0, s, a); break;
+      }
     }
   } else {
     hipLaunchKernelGGL(sor_serial_kernel, dim3((a.t.nframes + 63) / 64), dim3(64), 0, s, a);

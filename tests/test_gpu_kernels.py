@@ -102,7 +102,8 @@ def _spd_system(rng, B, h, w):
 
 @pytest.mark.parametrize("w,h,iters", [(128, 56, 3), (64, 28, 3), (32, 14, 3), (20, 15, 3), (40, 30, 1), (80, 60, 2),
                                         (128, 64, 4), (7, 5, 3), (2, 2, 3), (1, 5, 2), (30, 17, 5), (16, 70, 3),
-                                        (33, 3, 3)])
+                                        (33, 3, 3), (120, 68, 3), (37, 129, 2), (50, 300, 3), (24, 700, 1),
+                                        (12, 1030, 2)])
 def test_sor_coupled(gpu, orc, w, h, iters):
     rng = np.random.default_rng(4)
     B = 5
