@@ -20,51 +20,41 @@
 
 namespace ofdis {
 
-// Sum over one patch vector in the documented 64-lane butterfly order (ofdis_dev.h: lane partials over
-// entries l, l+64, ...; then pairs at lane distance 1,2,4,8,16,32).
+// Sum over one patch vector in the documented reduction order (DESIGN.md "reduction order"; mirrored by
+// oracle/eigen_shim -DOFDIS_SHIM_WAVE64 and oracle_set_reduce_order(1)).
 //
-// LPP = physical lanes per patch (64, 32 or 16): 64/LPP patches share one wavefront.  Entry k of a
-// patch belongs to virtual lane l = k % 64 (round m = k / 64); physical lane pl = l % LPP holds the
-// Q = 64/LPP virtual lanes pl, pl+LPP, ... as separate accumulation chains.  Butterfly distances below
-// LPP run inside the patch's lanes on every chain (DPP row operations; one v_permlane16_swap for LPP=32),
-// the remaining distances (LPP .. 32) combine the chains pairwise -- operand for operand the same
-// additions as the 64-lane butterfly, so the result is bit-identical for every LPP.
+//  novals > 64 (LPP = 64, one patch per wavefront): lane l accumulates entries l, l+64, ... sequentially,
+//     then the 64-lane butterfly of ofdis_dev.h (distances 1,2,4,8,16,32).
+//  novals <= 64 (LPP = 8, eight patches per wavefront): lane pl of the patch's 8 lanes owns entries
+//     pl, pl+8, ..., pl+56 (for an 8x8 gray patch: one patch column) and accumulates them sequentially IN
+//     THE LANE -- 7 plain adds, no cross-lane traffic -- then the 8 partials are combined at lane distance
+//     4, 1, 2.  This is the shape of Eigen's own SSE reduction (two 4-wide accumulators = 8 stride-8 partial
+//     sums, their sum, two horizontal adds) and costs 12 instructions instead of 31 for the butterfly over
+//     64 virtual lanes.
 template <int M, int LPP>
 __device__ __forceinline__ float patch_sum(const float (&x)[M * (64 / LPP)], const bool (&valid)[M * (64 / LPP)]) {
-  constexpr int Q = 64 / LPP;
-  float c[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    c[q] = valid[q] ? x[q] : 0.0f;  // starts FROM the first element (never "0 + x")
+  if constexpr (LPP == 64) {
+    float c = valid[0] ? x[0] : 0.0f;  // starts FROM the first element (never "0 + x")
 #pragma unroll
     for (int m = 1; m < M; ++m)
-      if (valid[m * Q + q]) c[q] = c[q] + x[m * Q + q];
+      if (valid[m]) c = c + x[m];
+    return wave_sum(c);
+  } else {
+    static_assert(LPP == 8 && M == 1, "novals <= 64 uses 8 lanes per patch");
+    float c = valid[0] ? x[0] : 0.0f;
+#pragma unroll
+    for (int q = 1; q < 8; ++q)
+      if (valid[q]) c = c + x[q];
+    // distance 4 inside each group of 8 lanes: lanes 0-3 take lane+4 (row_shl:4 written to DPP banks 0 and 2),
+    // lanes 4-7 take lane-4 (row_shr:4 written to banks 1 and 3)
+    const int ci = __builtin_bit_cast(int, c);
+    int o = __builtin_amdgcn_update_dpp(0, ci, 0x104, 0xf, 0x5, false);
+    o = __builtin_amdgcn_update_dpp(o, ci, 0x114, 0xf, 0xA, false);
+    c = c + __builtin_bit_cast(float, o);
+    c = c + dpp_mov<0xB1>(c);  // distance 1
+    c = c + dpp_mov<0x4E>(c);  // distance 2
+    return c;
   }
-  // butterfly distances below LPP: inside the patch's lanes, every chain
-#pragma unroll
-  for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0xB1>(c[q]);   // 1
-#pragma unroll
-  for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0x4E>(c[q]);   // 2
-  if constexpr (LPP >= 8) {
-#pragma unroll
-    for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0x141>(c[q]);  // 4
-  }
-  if constexpr (LPP >= 16) {
-#pragma unroll
-    for (int q = 0; q < Q; ++q) c[q] = c[q] + dpp_mov<0x140>(c[q]);  // 8
-  }
-  if constexpr (LPP >= 32) {
-#pragma unroll
-    for (int q = 0; q < Q; ++q) c[q] = swap16_sum(c[q]);             // 16
-  }
-  if constexpr (LPP >= 64) c[0] = swap32_sum(c[0]);                  // 32
-  // distances LPP .. 32: the chains are the virtual lanes q*LPP + pl, combine them pairwise
-#pragma unroll
-  for (int o = 1; o < Q; o <<= 1) {
-#pragma unroll
-    for (int q = 0; q < Q; q += 2 * o) c[q] = c[q] + c[q + o];
-  }
-  return c[0];
 }
 
 // FULL: novals == 64*M, every entry slot is a real patch entry (the validity selects fold away);
@@ -490,30 +480,23 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
 
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   const int M = (a.g.novals + 63) / 64;
-  static const int lpp_env = getenv("OFDIS_PATCH_LPP") ? atoi(getenv("OFDIS_PATCH_LPP")) : 8;
-  const int lpp = (M <= 1) ? lpp_env : 64;  // lanes per patch
-  const int ppb = 4 * (64 / lpp);           // patches per 256-thread block
+  const int lpp = (M <= 1) ? 8 : 64;  // lanes per patch
+  const int ppb = 4 * (64 / lpp);     // patches per 256-thread block
   const int blocks_per_frame = (a.g.nop + ppb - 1) / ppb;
   const int grid = ((a.nframes + 7) / 8) * 8 * blocks_per_frame;
   const dim3 gd(grid), bd(256);
   const bool full = a.g.novals == 64 * M;
   const bool gray8 = a.g.noc == 1 && a.g.P == 8 && !getenv("OFDIS_NO_GRAY8");
-  if (M <= 1 && lpp == 8 && gray8 && a.costfct == 0)
+  if (M <= 1 && gray8 && a.costfct == 0)
     hipLaunchKernelGGL((patch_optimize_gray8_kernel<0>), gd, bd, 0, s, a);
-  else if (M <= 1 && lpp == 8 && gray8)
+  else if (M <= 1 && gray8)
     hipLaunchKernelGGL((patch_optimize_gray8_kernel<-1>), gd, bd, 0, s, a);
-  else if (M <= 1 && lpp == 8 && full && a.costfct == 0)
+  else if (M <= 1 && full && a.costfct == 0)
     hipLaunchKernelGGL((patch_optimize_kernel<1, 8, true, 0>), gd, bd, 0, s, a);
-  else if (M <= 1 && lpp == 8 && full)
+  else if (M <= 1 && full)
     hipLaunchKernelGGL((patch_optimize_kernel<1, 8, true, -1>), gd, bd, 0, s, a);
-  else if (M <= 1 && lpp == 8)
-    hipLaunchKernelGGL((patch_optimize_kernel<1, 8, false, -1>), gd, bd, 0, s, a);
-  else if (M <= 1 && lpp == 16)
-    hipLaunchKernelGGL((patch_optimize_kernel<1, 16, false, -1>), gd, bd, 0, s, a);
-  else if (M <= 1 && lpp == 4)
-    hipLaunchKernelGGL((patch_optimize_kernel<1, 4, false, -1>), gd, bd, 0, s, a);
   else if (M <= 1)
-    hipLaunchKernelGGL((patch_optimize_kernel<1, 32, false, -1>), gd, bd, 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 8, false, -1>), gd, bd, 0, s, a);
   else if (M <= 3)
     hipLaunchKernelGGL((patch_optimize_kernel<3, 64, false, -1>), gd, bd, 0, s, a);
   else if (M <= 7)

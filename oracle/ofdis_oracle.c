@@ -23,6 +23,20 @@ int oracle_get_reduce_order(void) { return g_wave64; }
 /* Eigen's .sum() (patch.cpp:74-76,178-179,278,331,401): order unspecified by Eigen; see
  * oracle/eigen_shim/Eigen/Core for the two orders. */
 static float reduce_sum(const float* x, int n) {
+  if (g_wave64 && n <= 64) { /* 8 stride-8 partials, then distance 4, 1, 2 (see eigen_shim/Eigen/Core) */
+    float p[8];
+    for (int l = 0; l < 8; ++l) {
+      float s = 0.0f;
+      int any = 0;
+      for (int k = l; k < n; k += 8) {
+        s = any ? s + x[k] : x[k];
+        any = 1;
+      }
+      p[l] = any ? s : 0.0f;
+    }
+    const float q0 = p[0] + p[4], q1 = p[1] + p[5], q2 = p[2] + p[6], q3 = p[3] + p[7];
+    return (q0 + q1) + (q2 + q3);
+  }
   if (g_wave64) {
     float part[64];
     for (int l = 0; l < 64; ++l) {
