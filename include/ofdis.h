@@ -11,8 +11,10 @@
  * `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *
  * Arithmetic contract: fp32 throughout, every operation separately rounded (no FMA contraction),
- * IEEE divide/sqrt, same operation order as the reference's SSE path; vector reductions use the
- * 64-lane butterfly order documented in DESIGN.md ("reduction order").  The result is bit-identical
+ * IEEE divide/sqrt, same operation order as the reference's SSE path; vector reductions (the only
+ * place the reference leaves the order to Eigen) use the order documented in DESIGN.md ("Reduction
+ * order": <= 64 entries: 8 stride-8 partials, then distance 4, 1, 2; more: 64 strided partials, then
+ * a butterfly at distance 1..32).  The result is bit-identical
  * to the reference sources compiled against oracle/eigen_shim with -DOFDIS_SHIM_WAVE64.
  */
 #ifndef OFDIS_H_
