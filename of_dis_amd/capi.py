@@ -80,6 +80,7 @@ def lib():
         L.ofdis_flow.argtypes = [C.POINTER(OfdisParams)] + [C.POINTER(FP)] * 6 + [FP, FP]
         L.ofdis_params_oppoint.argtypes = [C.POINTER(OfdisParams), C.c_int, C.c_int, C.c_int]
         L.ofdis_test_wave_sum.argtypes = [VP, VP, C.c_int, VP]
+        L.ofdis_test_div_sqrt.argtypes = [VP, VP, VP, C.c_int, VP]
         _lib = L
     return _lib
 
@@ -220,6 +221,15 @@ def wave_sum_test(x):
     check(lib().ofdis_test_wave_sum(d.ptr, o.ptr, x.size, None))
     check(lib().ofdis_sync(None))
     return o.get(x.shape)
+
+
+def div_sqrt_test(a, b):
+    """Rows: div_rn(a,b), a/b, sqrt_rn(|a|), sqrtf(|a|) computed on the device (ofdis_dev.h)."""
+    a, b = _f(a), _f(b)
+    da, db, o = Dev(a), Dev(b), Dev(nbytes=4 * a.nbytes)
+    check(lib().ofdis_test_div_sqrt(da.ptr, db.ptr, o.ptr, a.size, None))
+    check(lib().ofdis_sync(None))
+    return o.get((4, a.size))
 
 
 class Batch:

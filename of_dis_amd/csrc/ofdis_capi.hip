@@ -177,7 +177,9 @@ TvConsts tv_consts(float alpha, float gamma, float delta) {  // refine_variation
 // (planar, row-major; plus diag copies in wx_d/wy_d when the fused kernel is used) on entry; the refined
 // flow is written AoS to flow_out.
 bool use_fused(const ofdis_batch* b, const LevelGeom& g) {
-  return b->wx_d && tv_fused_supported(TvGeom{g.w, g.h, g.noc, b->nframes}, b->p.tv_solverit);
+  const TvConsts c = tv_consts(b->p.tv_alpha, b->p.tv_gamma, b->p.tv_delta);
+  return b->wx_d && tv_fused_supported(TvGeom{g.w, g.h, g.noc, b->nframes}, b->p.tv_solverit) &&
+         tv_fused_params_ok(c.quarter_alpha, c.half_delta_over3, c.half_gamma_over3);
 }
 
 int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow_out,
@@ -652,8 +654,10 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   if (!rc) rc = dalloc(&b, &b.w_im2, npx * p->noc);
   if (!rc) rc = dalloc(&b, &b.derivs, npx * 8 * p->noc);
   if (!rc) rc = dalloc(&b, &b.sys, npx * 7);
+  const TvConsts tc = tv_consts(p->tv_alpha, p->tv_gamma, p->tv_delta);
   const bool want_fused = p->noc == 1 && !getenv("OFDIS_NO_FUSED") &&
-                          tv_fused_supported(TvGeom{g.w, g.h, g.noc, nframes}, p->tv_solverit);
+                          tv_fused_supported(TvGeom{g.w, g.h, g.noc, nframes}, p->tv_solverit) &&
+                          tv_fused_params_ok(tc.quarter_alpha, tc.half_delta_over3, tc.half_gamma_over3);
   if (!rc && want_fused) {
     rc = dalloc(&b, &b.wx_d, npx);
     if (!rc) rc = dalloc(&b, &b.wy_d, npx);
@@ -677,6 +681,12 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
 // test hook (not declared in ofdis.h): wave_sum over groups of 64
 int ofdis_test_wave_sum(const float* in, float* out, int n, void* stream) {
   HIPCHK(launch_wave_sum_test(in, out, n, (hipStream_t)stream));
+  return OFDIS_OK;
+}
+
+// test hook (not declared in ofdis.h): trimmed divide / sqrt next to the compiler's IEEE expansion
+int ofdis_test_div_sqrt(const float* a, const float* b, float* out, int n, void* stream) {
+  HIPCHK(launch_div_sqrt_test(a, b, out, n, (hipStream_t)stream));
   return OFDIS_OK;
 }
 

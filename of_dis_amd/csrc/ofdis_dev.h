@@ -74,6 +74,42 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
+// ----------------------------------------------------------------------------- IEEE divide / sqrt, trimmed
+// hipcc expands a correctly rounded fp32 `a / b` to  v_div_scale x2, v_rcp, 6 fma/mul, v_div_fmas, v_div_fixup
+// and `sqrtf` to a range scale, v_sqrt, a +-1 ulp residual test, an unscale and a class test.  The scale steps
+// only act on operands outside the ranges below, so the kernels whose operands provably stay inside them use
+// the same sequences without them -- same bits, 8 instead of 11 and 9 instead of 15 instructions, and the refined
+// reciprocal is shared by every quotient with the same denominator:
+//   div_by(a, b, rcp_refined(b)) == a / b   for b normal with |b| < 2^126, and a == 0 or 2^-102 <= |a|, and
+//                                           |a / b| normal (v_div_scale_f32 is the identity there); zero, inf
+//                                           and NaN operands give the IEEE result through v_div_fixup.
+//   sqrt_rn(x) == sqrtf(x)                  for x >= 2^-96 (incl. +inf, NaN)
+// tests/test_gpu_kernels.py::test_trimmed_div_sqrt checks both against the compiler's expansion on the device.
+__device__ __forceinline__ float rcp_refined(float b) {
+  const float r0 = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, r0, 1.0f);
+  return __builtin_fmaf(e, r0, r0);
+}
+__device__ __forceinline__ float div_by(float a, float b, float r) {
+  float q = a * r;
+  float e = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(e, r, q);
+  e = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(e, r, q);
+  return __builtin_amdgcn_div_fixupf(q, b, a);
+}
+__device__ __forceinline__ float div_rn(float a, float b) { return div_by(a, b, rcp_refined(b)); }
+__device__ __forceinline__ float sqrt_rn(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+  const float su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+  const float ed = __builtin_fmaf(-sd, s, x);
+  const float eu = __builtin_fmaf(-su, s, x);
+  float r = (ed <= 0.0f) ? sd : s;
+  r = (eu > 0.0f) ? su : r;
+  return r;
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // "diag" plane layout used for the SOR solver's operands (7 system planes, du, dv): pixel (x,y) of a

@@ -620,6 +620,21 @@ __global__ void wave_sum_test_kernel(const float* in, float* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = wave_sum(in[i]);
 }
+// out[0][i] = {div_rn(a,b), a/b}, out[1][i] = {sqrt_rn(|a|), sqrtf(|a|)} interleaved: [4][n] = trimmed q, IEEE q,
+// trimmed sqrt, IEEE sqrt
+__global__ void div_sqrt_test_kernel(const float* a, const float* b, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = a[i], y = b[i];
+  out[i] = div_rn(x, y);
+  out[n + i] = x / y;
+  out[2 * n + i] = sqrt_rn(fabsf(x));
+  out[3 * n + i] = sqrtf(fabsf(x));
+}
+hipError_t launch_div_sqrt_test(const float* a, const float* b, float* out, int n, hipStream_t s) {
+  hipLaunchKernelGGL(div_sqrt_test_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
+  return hipGetLastError();
+}
 hipError_t launch_wave_sum_test(const float* in, float* out, int n, hipStream_t s) {
   hipLaunchKernelGGL(wave_sum_test_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
   return hipGetLastError();

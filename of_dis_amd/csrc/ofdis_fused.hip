@@ -39,7 +39,7 @@ namespace ofdis {
 struct FSlot {
   float a11, a12, a22, b1, b2, sh, sv;  // system of pixel (j, tau - j); a** become the block inverse at step tau
   float dur, dvr;                       // old du,dv of the right neighbour (row tau+1)
-  float hl, vt;                         // left / top edge weights
+  float hl, vt;                         // left / top edge weights (= sh of the left, sv of the upper pixel)
 };
 struct FRow {
   float wx, wy, du, dv;
@@ -49,6 +49,51 @@ struct FDer {
   float m;
 };
 
+// Data term of one gray pixel: ofdis_tvmath.h data_term() with the divisions and square roots written out
+// (ofdis_dev.h: div_by / sqrt_rn; same bits for the operand ranges the launcher guarantees) and the refined
+// reciprocal of each normaliser shared by the two quotients that use it.
+__device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, float hd3, float hg3, float& a11,
+                                               float& a12, float& a22, float& b1, float& b2) {
+  const float ix = D.d[0], iy = D.d[1], iz = D.d[2], ixx = D.d[3], ixy = D.d[4], iyy = D.d[5], ixz = D.d[6],
+              iyz = D.d[7], m = D.m;
+  a11 = 0.0f; a12 = 0.0f; a22 = 0.0f; b1 = 0.0f; b2 = 0.0f;
+  float tmp, tmp2, n1, n2;
+  if (hd3 != 0.0f) {  // uniform
+    tmp = iz + ix * u + iy * v;
+    n1 = ix * ix + iy * iy + DATANORM;
+    const float r1 = rcp_refined(n1);
+    tmp = div_rn(m * hd3, sqrt_rn(div_by(3 * tmp * tmp, n1, r1) + EPS_COLOR));
+    tmp = div_by(tmp, n1, r1);
+    a11 += tmp * ix * ix;
+    a12 += tmp * ix * iy;
+    a22 += tmp * iy * iy;
+    b1 -= tmp * iz * ix;
+    b2 -= tmp * iz * iy;
+  }
+  n1 = ixx * ixx + ixy * ixy + DATANORM;
+  n2 = iyy * iyy + ixy * ixy + DATANORM;
+  const float r1 = rcp_refined(n1), r2 = rcp_refined(n2);
+  tmp = ixz + ixx * u + ixy * v;
+  tmp2 = iyz + ixy * u + iyy * v;
+  tmp = div_rn(m * hg3, sqrt_rn(div_by(3 * tmp * tmp, n1, r1) + div_by(3 * tmp2 * tmp2, n2, r2) + EPS_GRAD));
+  tmp2 = div_by(tmp, n2, r2);
+  tmp = div_by(tmp, n1, r1);
+  a11 += tmp * ixx * ixx + tmp2 * ixy * ixy;
+  a12 += tmp * ixx * ixy + tmp2 * ixy * iyy;
+  a22 += tmp2 * iyy * iyy + tmp * ixy * ixy;
+  b1 -= tmp * ixx * ixz + tmp2 * ixy * iyz;
+  b2 -= tmp2 * iyy * iyz + tmp * ixy * ixz;
+  a11 *= 3; a12 *= 3; a22 *= 3; b1 *= 3; b2 *= 3;
+}
+
+// Border handling.  The reference special-cases every border (solver.c:77-421, opticalflow_aux.c:172-199).  Here
+// an edge weight that does not exist IS zero -- sh = 0 on the last column, sv = 0 on the last row (and in the
+// idle lanes, and DPP shifts zero-fill lane 0), hence hl = 0 on column 0 and vt = 0 on row 0 -- and the terms
+// are added unconditionally: x + (+-0 * finite) == x bit for bit unless x is -0, and none of the accumulators
+// can be -0 at that point (b1, b2 start at +0 and only ever add/subtract, which never yields -0 from +0; the
+// neighbour sums end with "+ b").  "finite" holds because every lane always works on real pixels: before its
+// first and after its last column a lane computes wrapped columns of real data whose results are not stored,
+// and the slot ring starts with a unit diagonal.
 template <int NS>
 __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const int R) {
   constexpr int U = 6;
@@ -56,33 +101,44 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
   const int w = a.t.w, h = a.t.h;
   const int npx = w * h;
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int G = 64 / R;  // frames per wavefront
-  if (wid * G >= a.t.nframes) return;  // whole wave idle (uniform)
-  int f = wid * G + lane / R;
+  const int f0 = wid * G;
+  if (f0 >= a.t.nframes) return;  // whole wave idle (uniform)
+  int fl = lane / R;              // frame of this lane within the wavefront
   const int jr = lane % R;
-  const bool row_ok = (f < a.t.nframes) && (jr < h);
-  if (f >= a.t.nframes) f = a.t.nframes - 1;
+  const bool row_ok = (f0 + fl < a.t.nframes) && (jr < h);
+  if (f0 + fl >= a.t.nframes) fl = a.t.nframes - 1 - f0;
   const int j = jr < h ? jr : h - 1;
   const bool has_top = j > 0, has_bot = j < h - 1;
   const float omega = a.omega, qa = a.quarter_alpha, hd3 = a.half_delta_over3, hg3 = a.half_gamma_over3;
 
-  const float* __restrict__ derp = a.derivs + (size_t)f * 8 * npx + j;
-  const float* __restrict__ mskp = a.mask + (size_t)f * npx + j;
-  const float* __restrict__ wxp = a.wx + (size_t)f * npx + j;
-  const float* __restrict__ wyp = a.wy + (size_t)f * npx + j;
-  float* __restrict__ dup = a.du + (size_t)f * npx + j;
-  float* __restrict__ dvp = a.dv + (size_t)f * npx + j;
+  // one buffer resource per operand, based at the wavefront's first frame: a lane's byte offset within it is
+  // constant, the moving part (plane, diag row) is a scalar offset
+  const int nfr = min(G, a.t.nframes - f0);
+  const int plane_bytes = npx * 4;
+  auto rsrc = [&](const float* base, int planes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)f0 * planes * npx), 0, nfr * planes * plane_bytes,
+                                             0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsD = rsrc(a.derivs, 8), rsM = rsrc(a.mask, 1), rsWx = rsrc(a.wx, 1),
+                               rsWy = rsrc(a.wy, 1), rsU = rsrc(a.du, 1), rsV = rsrc(a.dv, 1);
+  const int vo1 = (fl * npx + j) * 4;      // single-plane operands
+  const int vo8 = (fl * 8 * npx + j) * 4;  // the 8 derivative planes of a frame
+  auto ldf = [&](const __amdgpu_buffer_rsrc_t& rs, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+  };
 
   FRow W[6];
   FDer D[3];
   float uu[3], vv[3], sm[3];
   FSlot slot[6];
 #pragma unroll
-  for (int r = 0; r < 6; ++r) { W[r] = FRow{0, 0, 0, 0}; slot[r] = FSlot{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+  for (int r = 0; r < 6; ++r) { W[r] = FRow{0, 0, 0, 0}; slot[r] = FSlot{1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0}; }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    uu[r] = vv[r] = sm[r] = 0.0f;
+    uu[r] = vv[r] = 0.0f;
+    sm[r] = 1.0f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) D[r].d[q] = 0.0f;
     D[r].m = 0.0f;
@@ -93,15 +149,16 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
 
   auto wrap = [&](int r) { r %= w; return r < 0 ? r + w : r; };
   auto next_row = [&](int r) { return (r + 1 == w) ? 0 : r + 1; };
+  const int row_bytes = h * 4;
   auto load_w = [&](FRow& r, int drow) {
-    const int o = drow * h;
-    r.wx = wxp[o]; r.wy = wyp[o]; r.du = dup[o]; r.dv = dvp[o];
+    const int o = drow * row_bytes;
+    r.wx = ldf(rsWx, vo1, o); r.wy = ldf(rsWy, vo1, o); r.du = ldf(rsU, vo1, o); r.dv = ldf(rsV, vo1, o);
   };
   auto load_d = [&](FDer& r, int drow) {
-    const int o = drow * h;
+    const int o = drow * row_bytes;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) r.d[q] = derp[(size_t)q * npx + o];
-    r.m = mskp[o];
+    for (int q = 0; q < 8; ++q) r.d[q] = ldf(rsD, vo8, q * plane_bytes + o);
+    r.m = ldf(rsM, vo1, o);
   };
 
   // ring index of diag row rho is (rho + 3) mod ring size; the loop variable is k = t + 3, u = k % 6,
@@ -113,17 +170,16 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
   int rowW = wrap(2);   // next W row to load (row t+5 at t = -3)
   int rowD = wrap(0);   // next D row to load (row t+3 at t = -3)
   int srow = wrap(-3 - 2 * (NS - 1));  // row finished by the last sweep at step t = -3
-  int xq = wrap(-3 - j);               // this lane's x on diag row t (per lane)
+  int x2 = wrap(-1 - j);               // this lane's x on diag row t+2 (per lane)
+  bool x1_last = (wrap(-2 - j) == w - 1);  // row t+1 is this lane's last column
 
   const int wtot = a.n_inner * w;  // columns per lane over all iterations
   const int tend = (wtot - 1) + (h - 1) + 2 * (NS - 1);
+  int ig = -3 - j - 2 * (NS - 1);  // global column (over all iterations) the last sweep finishes at step t
   for (int k0 = 0; k0 <= tend + 3; k0 += U) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int t = k0 + u - 3;  // up to U-1 steps past tend are executed: every pixel is then out of range
-      // x of this lane on rows t+1 and t+2
-      const int x1 = (xq + 1 == w) ? 0 : xq + 1;
-      const int x2 = (x1 + 1 == w) ? 0 : x1 + 1;
+      // step t = k0 + u - 3; up to U-1 steps past tend are executed: every pixel is then out of range
       // ---- (1) loads: W row t+5, D row t+3
       load_w(W[(u + 5) % 6], rowW);
       rowW = next_row(rowW);
@@ -136,6 +192,7 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
         vv[u % 3] = r.wy + r.dv;
       }
       // ---- (3) smoothness of row t+2 (opticalflow_aux.c:128-140)
+      const bool x2_last = (x2 == w - 1);
       {
         const float uc = uu[(u + 2) % 3], vc = vv[(u + 2) % 3];
         float ul = uu[(u + 1) % 3], vl = vv[(u + 1) % 3];                  // (x-1, y)
@@ -143,73 +200,59 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
         float ut = wave_from_prev(uu[(u + 1) % 3]), vt = wave_from_prev(vv[(u + 1) % 3]);  // (x, y-1)
         float ub = wave_from_next(uu[u % 3]), vb = wave_from_next(vv[u % 3]);              // (x, y+1)
         if (x2 == 0) { ul = uc; vl = vc; }
-        if (x2 == w - 1) { ur = uc; vr = vc; }
+        if (x2_last) { ur = uc; vr = vc; }
         if (!has_top) { ut = uc; vt = vc; }
         if (!has_bot) { ub = uc; vb = vc; }
         const float ux = D3_C0 * ul + D3_C1 * uc + D3_C2 * ur;
         const float vx = D3_C0 * vl + D3_C1 * vc + D3_C2 * vr;
         const float uy = D3_C0 * ut + D3_C1 * uc + D3_C2 * ub;
         const float vy = D3_C0 * vt + D3_C1 * vc + D3_C2 * vb;
-        sm[(u + 2) % 3] = qa / sqrtf(ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH);
+        sm[(u + 2) % 3] = div_rn(qa, sqrt_rn(ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH));
       }
       // ---- (4) system of pixel row tau = t+1 (opticalflow_aux.c:150-163, 172-199, 342-427)
+      //      x of row tau is x2 of the previous step: "last column" was x2_last then
       {
         const float sc = sm[(u + 1) % 3];
-        const float s_r = sm[(u + 2) % 3], s_l = sm[u % 3];
-        const float s_d = wave_from_next(sm[(u + 2) % 3]), s_u = wave_from_prev(sm[u % 3]);
-        const float sh_c = (x1 < w - 1) ? sc + s_r : 0.0f;
+        const float s_r = sm[(u + 2) % 3];
+        const float s_d = wave_from_next(sm[(u + 2) % 3]);
+        const float sh_c = x1_last ? 0.0f : sc + s_r;
         const float sv_c = has_bot ? sc + s_d : 0.0f;
         const FRow& rc = W[(u + 1) % 6];
         const FRow& rm = W[u % 6];        // row tau-1
         const FRow& rp = W[(u + 2) % 6];  // row tau+1
-        const FDer& dd = D[(u + 1) % 3];
         float a11, a12, a22, b1, b2;
-        auto Df = [&](int kk, int) { return dd.d[kk]; };
-        data_term(Df, 1, dd.m, rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
+        data_term_gray(D[(u + 1) % 3], rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
         const float wx_u = wave_from_prev(rm.wx), wy_u = wave_from_prev(rm.wy);
         const float wx_d = wave_from_next(rp.wx), wy_d = wave_from_next(rp.wy);
-        if (x1 > 0) {
-          const float sh_l = s_l + sc;
-          b1 -= sh_l * (rc.wx - rm.wx);
-          b2 -= sh_l * (rc.wy - rm.wy);
-        }
-        if (x1 < w - 1) {
-          b1 += sh_c * (rp.wx - rc.wx);
-          b2 += sh_c * (rp.wy - rc.wy);
-        }
-        if (has_top) {
-          const float sv_t = s_u + sc;
-          b1 -= sv_t * (rc.wx - wx_u);
-          b2 -= sv_t * (rc.wy - wy_u);
-        }
-        if (has_bot) {
-          b1 += sv_c * (wx_d - rc.wx);
-          b2 += sv_c * (wy_d - rc.wy);
-        }
+        const float sh_l = slot[u % 6].sh;         // (s_l + sc), 0 on column 0
+        const float sv_t = wave_from_prev(slot[u % 6].sv);  // (s_u + sc), 0 on row 0
+        b1 -= sh_l * (rc.wx - rm.wx);
+        b2 -= sh_l * (rc.wy - rm.wy);
+        b1 += sh_c * (rp.wx - rc.wx);
+        b2 += sh_c * (rp.wy - rc.wy);
+        b1 -= sv_t * (rc.wx - wx_u);
+        b2 -= sv_t * (rc.wy - wy_u);
+        b1 += sv_c * (wx_d - rc.wx);
+        b2 += sv_c * (wy_d - rc.wy);
         FSlot& o = slot[(u + 1) % 6];
         o.a11 = a11; o.a12 = a12; o.a22 = a22; o.b1 = b1; o.b2 = b2; o.sh = sh_c; o.sv = sv_c;
         o.dur = rp.du; o.dvr = rp.dv;
+        o.hl = sh_l; o.vt = sv_t;
       }
-      // ---- (5) SOR step t (ofdis_sor.hip): sweep 0 reaches pixel (j, t - j)
+      // ---- (5) SOR step t (ofdis_sor.hip): sweep 0 reaches pixel (j, t - j); block inverse (solver.c:100-110)
       {
         FSlot& c = slot[u % 6];
-        const FSlot& p = slot[(u + 5) % 6];
-        c.hl = (xq > 0) ? p.sh : 0.0f;  // xq = this lane's column on diag row t
-        c.vt = wave_from_prev(p.sv);
-        float d = c.hl + c.sh;
-        if (has_top) d = d + c.vt;
-        if (has_bot) d = d + c.sv;
+        const float d = c.hl + c.sh + c.vt + c.sv;
         const float A11 = c.a22 + d, A22 = c.a11 + d;
         const float det = A11 * A22 - c.a12 * c.a12;
-        c.a11 = A11 / det;
-        c.a22 = A22 / det;
-        c.a12 = c.a12 / (-det);
+        const float rdet = rcp_refined(det);
+        c.a11 = div_by(A11, det, rdet);
+        c.a22 = div_by(A22, det, rdet);
+        c.a12 = -div_by(c.a12, det, rdet);
       }
       float nu[NS], nv[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        int i = xq - 2 * s;  // column of sweep s (wrapped: the lane may already be in the next iteration)
-        if (i < 0) i += w;
         const FSlot& c = slot[(u - 2 * s + 12) % 6];
         float ou, ov, rgu, rgv, bu, bv;
         if (s == 0) {
@@ -224,33 +267,29 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
           bu = wave_from_next(ru[s - 1]);
           bv = wave_from_next(rv[s - 1]);
         }
-        if (!(i < w - 1)) { rgu = 0.0f; rgv = 0.0f; }
         const float tu = wave_from_prev(ru[s]), tv = wave_from_prev(rv[s]);
         const float lu = ru[s], lv = rv[s];
-        float s1 = c.sh * rgu, s2 = c.sh * rgv;
-        if (has_top) { s1 = s1 + c.vt * tu; s2 = s2 + c.vt * tv; }
-        if (has_bot) { s1 = s1 + c.sv * bu; s2 = s2 + c.sv * bv; }
-        s1 = s1 + c.b1;
-        s2 = s2 + c.b2;
-        float B1 = s1, B2 = s2;
-        if (i > 0) { B1 = c.hl * lu + s1; B2 = c.hl * lv + s2; }
+        const float s1 = c.sh * rgu + c.vt * tu + c.sv * bu + c.b1;
+        const float s2 = c.sh * rgv + c.vt * tv + c.sv * bv + c.b2;
+        const float B1 = c.hl * lu + s1, B2 = c.hl * lv + s2;
         nu[s] = ou + omega * (c.a11 * B1 + c.a12 * B2 - ou);
         nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
       }
       {
-        const int ig = t - j - 2 * (NS - 1);  // global column index over all iterations
         if (row_ok && ig >= 0 && ig < wtot) {
-          dup[srow * h] = nu[NS - 1];
-          dvp[srow * h] = nv[NS - 1];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nu[NS - 1]), rsU, vo1, srow * row_bytes, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nv[NS - 1]), rsV, vo1, srow * row_bytes, 0);
         }
         srow = next_row(srow);
+        ++ig;
       }
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         ru2[s] = ru[s]; rv2[s] = rv[s];
         ru[s] = nu[s]; rv[s] = nv[s];
       }
-      xq = x1;
+      x1_last = x2_last;
+      x2 = x2_last ? 0 : x2 + 1;
     }
   }
 }
@@ -259,8 +298,15 @@ bool tv_fused_supported(const TvGeom& t, int iterations) {
   return t.noc == 1 && t.h >= 2 && t.h <= 64 && t.w >= 16 && iterations >= 1 && iterations <= 3;
 }
 
+bool tv_fused_params_ok(float qa, float hd3, float hg3) {
+  auto ok = [](float v) { return v == 0.0f || (v >= 1e-12f && v <= 1e12f); };
+  return ok(qa) && ok(hd3) && ok(hg3);
+}
+
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s) {
-  if (!tv_fused_supported(a.t, a.iterations) || a.n_inner < 1) return hipErrorInvalidValue;
+  if (!tv_fused_supported(a.t, a.iterations) || a.n_inner < 1 ||
+      !tv_fused_params_ok(a.quarter_alpha, a.half_delta_over3, a.half_gamma_over3))
+    return hipErrorInvalidValue;
   const int h = a.t.h;
   const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
   const int G = 64 / R;

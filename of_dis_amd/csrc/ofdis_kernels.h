@@ -114,6 +114,8 @@ struct FusedArgs {
   int n_inner;     // fixed-point iterations run back to back inside one launch
 };
 bool tv_fused_supported(const TvGeom& t, int iterations);
+// the fused kernel's trimmed divisions (ofdis_dev.h) need the three weights to be 0 or of ordinary magnitude
+bool tv_fused_params_ok(float quarter_alpha, float half_delta_over3, float half_gamma_over3);
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s);
 
 // layout conversion of `nplanes` planes of w x h (row-major <-> diag); used by the per-function entry
@@ -136,5 +138,7 @@ hipError_t launch_pyr_planes(const float* src, float* img, float* dx, float* dy,
 
 // test hook: out[i] = wave_sum over each consecutive group of 64 inputs (n multiple of 64)
 hipError_t launch_wave_sum_test(const float* in, float* out, int n, hipStream_t s);
+// test hook: out[4][n] = div_rn(a,b), a/b, sqrt_rn(|a|), sqrtf(|a|)
+hipError_t launch_div_sqrt_test(const float* a, const float* b, float* out, int n, hipStream_t s);
 
 }  // namespace ofdis

@@ -26,6 +26,34 @@ def test_wave_sum_order(gpu, orc):
         assert np.all(got[r] == part[0]), (r, got[r][:4], part[0])
 
 
+def test_trimmed_div_sqrt(gpu):
+    """ofdis_dev.h div_rn / sqrt_rn == the compiler's IEEE expansion on their stated operand ranges, and == numpy's
+    correctly rounded fp32 results (what the reference's x86 divss / sqrtss produce)."""
+    rng = np.random.default_rng(5)
+    n = 1 << 22
+    # log-uniform magnitudes over 2^-40 .. 2^40, random signs, random mantissas
+    def draw():
+        m = rng.integers(0, 1 << 23, n, dtype=np.uint32)
+        e = rng.integers(127 - 40, 127 + 40, n, dtype=np.uint32)
+        sgn = rng.integers(0, 2, n, dtype=np.uint32)
+        return ((sgn << 31) | (e << 23) | m).view(_f32)
+    a, b = draw(), draw()
+    # edge mantissas (all ones / all zeros / one off), zeros, inf and NaN numerators, zero and inf denominators
+    edge = np.array([1.0, 1.9999999, 1.0000001, 1.5, 3.0, 0.33333334, 0.1, 0.01, 1e-6, 16777215.0], _f32)
+    a[:100] = np.repeat(edge, 10)
+    b[:100] = np.tile(edge, 10)
+    a[100:108] = [0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 0.0]
+    b[100:108] = [3.0, 3.0, 2.0, 2.0, 2.0, np.inf, 0.0, 0.0]
+    got = gpu.div_sqrt_test(a, b)
+    with np.errstate(all="ignore"):
+        q = (a / b).astype(_f32)
+        r = np.sqrt(np.abs(a)).astype(_f32)
+    for name, x, y in [("div vs compiler", got[0], got[1]), ("div vs numpy", got[0], q),
+                       ("sqrt vs compiler", got[2], got[3]), ("sqrt vs numpy", got[2], r)]:
+        same = (x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y))
+        assert same.all(), (name, int((~same).sum()), a[~same][:4], b[~same][:4], x[~same][:4], y[~same][:4])
+
+
 @pytest.mark.parametrize("w,h,noc", [(128, 56, 1), (64, 28, 1), (32, 14, 1), (30, 17, 3), (67, 33, 1), (5, 4, 1)])
 def test_image_warp(gpu, orc, w, h, noc):
     rng = np.random.default_rng(1)
