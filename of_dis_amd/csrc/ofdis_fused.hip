@@ -52,13 +52,14 @@ struct FDer {
 // Data term of one gray pixel: ofdis_tvmath.h data_term() with the divisions and square roots written out
 // (ofdis_dev.h: div_by / sqrt_rn; same bits for the operand ranges the launcher guarantees) and the refined
 // reciprocal of each normaliser shared by the two quotients that use it.
+template <bool BRIGHT>
 __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, float hd3, float hg3, float& a11,
                                                float& a12, float& a22, float& b1, float& b2) {
   const float ix = D.d[0], iy = D.d[1], iz = D.d[2], ixx = D.d[3], ixy = D.d[4], iyy = D.d[5], ixz = D.d[6],
               iyz = D.d[7], m = D.m;
   a11 = 0.0f; a12 = 0.0f; a22 = 0.0f; b1 = 0.0f; b2 = 0.0f;
   float tmp, tmp2, n1, n2;
-  if (hd3 != 0.0f) {  // uniform
+  if (BRIGHT) {  // hd3 != 0 (opticalflow_aux.c:352)
     tmp = iz + ix * u + iy * v;
     n1 = ix * ix + iy * iy + DATANORM;
     const float r1 = rcp_refined(n1);
@@ -94,7 +95,7 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
 // neighbour sums end with "+ b").  "finite" holds because every lane always works on real pixels: before its
 // first and after its last column a lane computes wrapped columns of real data whose results are not stored,
 // and the slot ring starts with a unit diagonal.
-template <int NS>
+template <int NS, bool BRIGHT>
 __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const int R) {
   constexpr int U = 6;
   static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
@@ -203,10 +204,12 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
         if (x2_last) { ur = uc; vr = vc; }
         if (!has_top) { ut = uc; vt = vc; }
         if (!has_bot) { ub = uc; vb = vc; }
-        const float ux = D3_C0 * ul + D3_C1 * uc + D3_C2 * ur;
-        const float vx = D3_C0 * vl + D3_C1 * vc + D3_C2 * vr;
-        const float uy = D3_C0 * ut + D3_C1 * uc + D3_C2 * ub;
-        const float vy = D3_C0 * vt + D3_C1 * vc + D3_C2 * vb;
+        // the reference's middle tap is -0 * centre: adding a signed zero changes at most the sign of a zero
+        // result, and each derivative is only ever squared
+        const float ux = D3_C0 * ul + D3_C2 * ur;
+        const float vx = D3_C0 * vl + D3_C2 * vr;
+        const float uy = D3_C0 * ut + D3_C2 * ub;
+        const float vy = D3_C0 * vt + D3_C2 * vb;
         sm[(u + 2) % 3] = div_rn(qa, sqrt_rn(ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH));
       }
       // ---- (4) system of pixel row tau = t+1 (opticalflow_aux.c:150-163, 172-199, 342-427)
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
         const FRow& rm = W[u % 6];        // row tau-1
         const FRow& rp = W[(u + 2) % 6];  // row tau+1
         float a11, a12, a22, b1, b2;
-        data_term_gray(D[(u + 1) % 3], rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
+        data_term_gray<BRIGHT>(D[(u + 1) % 3], rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
         const float wx_u = wave_from_prev(rm.wx), wy_u = wave_from_prev(rm.wy);
         const float wx_d = wave_from_next(rp.wx), wy_d = wave_from_next(rp.wy);
         const float sh_l = slot[u % 6].sh;         // (s_l + sc), 0 on column 0
@@ -312,11 +315,16 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s) {
   const int G = 64 / R;
   const int waves = (a.t.nframes + G - 1) / G;
   const int blocks = (waves + 3) / 4;
+  const bool bright = a.half_delta_over3 != 0.0f;
+#define OFDIS_FUSED_LAUNCH(NS)                                                                        \
+  if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true>), dim3(blocks), dim3(256), 0, s, a, R);  \
+  else hipLaunchKernelGGL((tv_fused_kernel<NS, false>), dim3(blocks), dim3(256), 0, s, a, R)
   switch (a.iterations) {
-    case 1: hipLaunchKernelGGL(tv_fused_kernel<1>, dim3(blocks), dim3(256), 0, s, a, R); break;
-    case 2: hipLaunchKernelGGL(tv_fused_kernel<2>, dim3(blocks), dim3(256), 0, s, a, R); break;
-    default: hipLaunchKernelGGL(tv_fused_kernel<3>, dim3(blocks), dim3(256), 0, s, a, R); break;
+    case 1: OFDIS_FUSED_LAUNCH(1); break;
+    case 2: OFDIS_FUSED_LAUNCH(2); break;
+    default: OFDIS_FUSED_LAUNCH(3); break;
   }
+#undef OFDIS_FUSED_LAUNCH
   return hipGetLastError();
 }
 

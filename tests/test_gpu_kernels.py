@@ -185,3 +185,22 @@ def test_varref_levels(gpu, orc, size):
         ref = orc.varref_level(p, l, pa[0][l], pb[0][l], flow)
         got = gpu.varref_level(p, l, pa[0][l][None], pb[0][l][None], flow[None])
         assert_bits_equal(got[0], ref, f"varref level {l}")
+
+
+@pytest.mark.parametrize("alpha,gamma,delta,innerit,solverit,sor", [
+    (10.0, 10.0, 0.0, 1, 3, 1.6),     # no brightness term (opticalflow_aux.c:352 branch not taken)
+    (3.0, 0.0, 7.5, 2, 2, 1.9),       # no gradient term weight
+    (25.0, 4.0, 1.0, 1, 1, 1.0),      # one sweep, plain Gauss-Seidel
+    (1e-13, 10.0, 5.0, 1, 3, 1.6),    # weight below the fused kernel's range: the unfused path must take over
+])
+def test_varref_parameter_variants(gpu, orc, alpha, gamma, delta, innerit, solverit, sor):
+    p, pa, pb, _, _ = synth_case(320, 240, 77, 1, 2, 1)
+    p.tv_alpha, p.tv_gamma, p.tv_delta = alpha, gamma, delta
+    p.tv_innerit, p.tv_solverit, p.tv_sor = innerit, solverit, sor
+    rng = np.random.default_rng(8)
+    for l in range(p.sc_f, p.sc_l - 1, -1):
+        w, h = p.level_size(l)
+        flow = rand_planes(rng, h, w, 2, scale=1.5)
+        ref = orc.varref_level(p, l, pa[0][l], pb[0][l], flow)
+        got = gpu.varref_level(p, l, pa[0][l][None], pb[0][l][None], flow[None])
+        assert_bits_equal(got[0], ref, f"varref level {l}")
