@@ -221,10 +221,13 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     // patch.cpp:279-282.  The reference evaluates all terms with bitwise &,|; the two ratios have no
     // side effects, so they are only computed where they can decide (min_iter <= cnt < max_iter).
     bool go = (cnt < a.max_iter) && (mares > a.res_thresh);
-    if (go && cnt >= a.min_iter) go = (dpsq / dpsq_init >= a.dp_thresh_sq) && (mares / mares_old <= a.dr_thresh);
+    // div_rn == IEEE division except (by < 2 ulp) for numerators below 2^-102, where neither ratio can be within
+    // 2 ulp of its threshold
+    if (go && cnt >= a.min_iter)
+      go = (div_rn(dpsq, dpsq_init) >= a.dp_thresh_sq) & (div_rn(mares, mares_old) <= a.dr_thresh);
     if (!go) converged = true;
   };
-  auto oob = [&](float x, float y) { return x < g.lb || y < g.lb || x > g.ubw || y > g.ubh; };
+  auto oob = [&](float x, float y) { return (x < g.lb) | (y < g.lb) | (x > g.ubw) | (y > g.ubh); };
 
   // OptimizeStart (patch.cpp:120-156)
   if (oob(ptx, pty) || !(isfinite(ptx) && isfinite(pty))) {
@@ -255,13 +258,15 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     const float ex = stx - ptx, ey = sty - pty;
     // a NaN position passes every comparison of the reference and then indexes out of bounds
     // (SURVEY.md 7-4b); here it is treated as an outlier.
-    if (sqrtf(ex * ex + ey * ey) > a.outlierthresh || oob(ptx, pty) || !(isfinite(ptx) && isfinite(pty))) {
-      p0 = pin0;
-      p1 = pin1;
-      ptx = rx + p0;
-      pty = ry + p1;
-      converged = true;
-    }
+    // branch-free (selects): the three tests are cheap next to the divergence bookkeeping of a nested branch.
+    // sqrt_rn == sqrtf for arguments >= 2^-96, and a smaller argument cannot be within an ulp of the threshold
+    const bool reset =
+        (sqrt_rn(ex * ex + ey * ey) > a.outlierthresh) | oob(ptx, pty) | !(isfinite(ptx) & isfinite(pty));
+    p0 = reset ? pin0 : p0;
+    p1 = reset ? pin1 : p1;
+    ptx = rx + p0;
+    pty = ry + p1;
+    converged = converged | reset;
     compute_err();
   }
 
@@ -426,10 +431,13 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
     mares_old = mares;
     mares = patch_sum<M, LPP>(pw, valid) * inv_nv;
     bool go = (cnt < a.max_iter) && (mares > a.res_thresh);
-    if (go && cnt >= a.min_iter) go = (dpsq / dpsq_init >= a.dp_thresh_sq) && (mares / mares_old <= a.dr_thresh);
+    // div_rn == IEEE division except (by < 2 ulp) for numerators below 2^-102, where neither ratio can be within
+    // 2 ulp of its threshold
+    if (go && cnt >= a.min_iter)
+      go = (div_rn(dpsq, dpsq_init) >= a.dp_thresh_sq) & (div_rn(mares, mares_old) <= a.dr_thresh);
     if (!go) converged = true;
   };
-  auto oob = [&](float x, float y) { return x < g.lb || y < g.lb || x > g.ubw || y > g.ubh; };
+  auto oob = [&](float x, float y) { return (x < g.lb) | (y < g.lb) | (x > g.ubw) | (y > g.ubh); };
 
   if (oob(ptx, pty) || !(isfinite(ptx) && isfinite(pty))) {
     converged = true;
@@ -456,13 +464,15 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
     ptx = rx + p0;
     pty = ry + p1;
     const float ex = stx - ptx, ey = sty - pty;
-    if (sqrtf(ex * ex + ey * ey) > a.outlierthresh || oob(ptx, pty) || !(isfinite(ptx) && isfinite(pty))) {
-      p0 = pin0;
-      p1 = pin1;
-      ptx = rx + p0;
-      pty = ry + p1;
-      converged = true;
-    }
+    // branch-free (selects): the three tests are cheap next to the divergence bookkeeping of a nested branch.
+    // sqrt_rn == sqrtf for arguments >= 2^-96, and a smaller argument cannot be within an ulp of the threshold
+    const bool reset =
+        (sqrt_rn(ex * ex + ey * ey) > a.outlierthresh) | oob(ptx, pty) | !(isfinite(ptx) & isfinite(pty));
+    p0 = reset ? pin0 : p0;
+    p1 = reset ? pin1 : p1;
+    ptx = rx + p0;
+    pty = ry + p1;
+    converged = converged | reset;
     compute_err();
   }
 
