@@ -14,6 +14,7 @@ from .params import OfdisParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libofdis_hip.so")
+LIB_PATH = os.environ.get("OFDIS_LIB", LIB_PATH)  # developer A/B builds (tools/ab_build.py); the product path is the default
 _f32 = np.float32
 FP = C.POINTER(C.c_float)
 VP = C.c_void_p

@@ -158,7 +158,7 @@ DisArgs dis_args(const ofdis_params& p, const LevelGeom& g, int nframes) {
   a.dp_thresh_sq = p.dp_thresh * p.dp_thresh;  // oflow.cpp:88
   a.dr_thresh = p.dr_thresh;
   a.res_thresh = p.res_thresh;
-  a.outlierthresh = (float)p.p_samp_s / 2;  // oflow.cpp:82
+  a.outlier_sq_max = outlier_sq_threshold((float)p.p_samp_s / 2);  // outlierthresh, oflow.cpp:82
   return a;
 }
 

@@ -14,6 +14,7 @@
 // no LDS is used.  The bilinear taps are plain global loads from the padded level image, which is
 // 41 KB at op-point 2 and therefore L1/L2 resident; blocks are mapped so that all patches of a
 // frame run on one XCD (its L2 then holds that frame's four planes once).
+#include <math.h>
 #include <stdlib.h>
 
 #include "ofdis_kernels.h"
@@ -259,9 +260,9 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     // a NaN position passes every comparison of the reference and then indexes out of bounds
     // (SURVEY.md 7-4b); here it is treated as an outlier.
     // branch-free (selects): the three tests are cheap next to the divergence bookkeeping of a nested branch.
-    // sqrt_rn == sqrtf for arguments >= 2^-96, and a smaller argument cannot be within an ulp of the threshold
-    const bool reset =
-        (sqrt_rn(ex * ex + ey * ey) > a.outlierthresh) | oob(ptx, pty) | !(isfinite(ptx) & isfinite(pty));
+    // norm > outlierthresh (patch.cpp:199) without the square root: sqrt is monotonic and correctly rounded, so
+    // sqrtf(x) > t  <=>  x > X, X = the largest float whose square root rounds to <= t (found on the host).
+    const bool reset = (ex * ex + ey * ey > a.outlier_sq_max) | oob(ptx, pty) | !(isfinite(ptx) & isfinite(pty));
     p0 = reset ? pin0 : p0;
     p1 = reset ? pin1 : p1;
     ptx = rx + p0;
@@ -285,28 +286,73 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
 
 // ------------------------------------------------------------------------------------ gray 8x8 fast path
 // Specialisation of patch_optimize_kernel<1, 8, true, COST> for the gray operating points 1 and 2
-// (noc = 1, P = 8, novals = 64): same arithmetic, same reduction order, bit-identical results; what
-// changes is how the target patch is fetched.  A lane owns one COLUMN of its patch (entries q*8 + pl,
-// q = row), and the four bilinear taps of row q are
-//     a = I[row q][col]   b = I[row q][col-1]   c = I[row q-1][col]   d = I[row q-1][col-1]
-// so c,d of a row are a,b of the row above: 9 rows x 2 loads per lane instead of 8 x 4.  The loads are
-// buffer loads: one per-lane byte offset for the whole patch (computed once per iteration), the row
-// stride as a wave-uniform SGPR offset and the column shift in the instruction's immediate field, i.e.
-// no per-load address arithmetic.
+// (noc = 1, P = 8, novals = 64): same arithmetic, same reduction order, bit-identical results.
+//
+// Four lanes per patch, sixteen patches per wavefront.  Lane pl owns the adjacent patch COLUMNS 2pl and 2pl+1
+// (entries r*8 + 2pl and r*8 + 2pl + 1, r = row), held as pairs.  The documented reduction order for <= 64
+// entries (eight column sums p_0..p_7; q_i = p_i + p_(i+4); (q0 + q1) + (q2 + q3)) becomes two in-lane chains of
+// 7 adds, the pair exchanged with the lane two over (q_2pl', q_2pl'+1), one in-lane add and one exchange with
+// the neighbouring lane -- the same additions, operands commuted.  The per-patch scalar work (2x2 solve,
+// position update, termination tests: ~45 % of an iteration's instructions) is paid once per 16 patches.
+//
+// The four bilinear taps of row r are
+//     a = I[row r][col]   b = I[row r][col-1]   c = I[row r-1][col]   d = I[row r-1][col-1]
+// so c,d of a row are a,b of the row above, and a lane's two columns need the three image columns 2pl-1, 2pl,
+// 2pl+1: ONE 12-byte buffer load per image row, 9 per iteration.  The four lanes of a patch then touch one
+// 36-byte span per instruction, i.e. one cache line (two when it straddles): the kernel is bound by L1 tag
+// lookups per distinct line as much as by VALU issue, and this is the minimum (9 rows) per patch evaluation.
+// The row stride is a wave-uniform SGPR offset, the per-lane byte offset is computed once per iteration.
+// A pair is two plain floats: gfx950's SIMDs are 32 lanes wide, a packed v_pk_*_f32 occupies the issue port twice as
+// long as a scalar op, so packing buys nothing and costs the moves that build register pairs.
+struct f2 {
+  float x, y;
+};
+__device__ __forceinline__ f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f2 operator-(f2 a, float b) { return f2{a.x - b, a.y - b}; }
+__device__ __forceinline__ f2 operator*(float a, f2 b) { return f2{a * b.x, a * b.y}; }
+
+__device__ __forceinline__ float gray8_combine(float c0, float c1) {  // column sums p_2pl, p_2pl+1 of this lane
+  c0 = c0 + dpp_mov<0x4E>(c0);  // lane distance 2 = column distance 4: q_(2pl mod 4)
+  c1 = c1 + dpp_mov<0x4E>(c1);  //                                       q_(2pl mod 4 + 1)
+  float q = c0 + c1;            // lanes 0,2: q0 + q1; lanes 1,3: q2 + q3
+  q = q + dpp_mov<0xB1>(q);     // lane distance 1
+  return q;
+}
+__device__ __forceinline__ float gray8_sum(const f2 (&x)[8]) {
+  f2 c = x[0];
+#pragma unroll
+  for (int r = 1; r < 8; ++r) c = c + x[r];
+  return gray8_combine(c.x, c.y);
+}
+// same order for sum |x|
+__device__ __forceinline__ float gray8_abs_sum(const f2 (&x)[8]) {
+  float cx = fabsf(x[0].x), cy = fabsf(x[0].y);
+#pragma unroll
+  for (int r = 1; r < 8; ++r) {
+    cx = cx + fabsf(x[r].x);
+    cy = cy + fabsf(x[r].y);
+  }
+  return gray8_combine(cx, cy);
+}
+
 template <int COST>
 __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs a) {
-  constexpr int M = 1, LPP = 8, Q = 8, E = 8;
+  constexpr int LPP = 4, Q = 16, R = 8;
   const int costfct = COST >= 0 ? COST : a.costfct;
   const LevelGeom& g = a.g;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int blocks_per_frame = (g.nop + 4 * Q - 1) / (4 * Q);
+  const int wpb = blockDim.x >> 6;  // wavefronts per block
+  const int blocks_per_frame = (g.nop + wpb * Q - 1) / (wpb * Q);
   int frame, blk;
   xcd_frame_map(blockIdx.x, blocks_per_frame, frame, blk);
-  if (frame >= a.nframes) return;  // block-uniform
+  if (frame >= a.nframes) return;                // block-uniform
+  if ((blk * wpb + wave) * Q >= g.nop) return;   // wave-uniform: no patch for this wavefront
   const int sub = lane / LPP;
   const int pl = lane % LPP;
-  int ip = (blk * 4 + wave) * Q + sub;
+  int ip = (blk * wpb + wave) * Q + sub;
   const bool live = ip < g.nop;
   if (!live) ip = g.nop - 1;  // idle lane group: shadows the last patch, never stores
 
@@ -321,42 +367,39 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
 
   const int gx = ip / g.noph, gy = ip - gx * g.noph;
   const float rx = (float)(gx * g.steps + g.offw), ry = (float)(gy * g.steps + g.offh);
-  bool valid[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) valid[e] = true;
   const float inv_nv = 1.0f / 64.0f;  // x/64 == x*(1/64): both round the same real number
 
-  // ---- InitializePatch (patch.cpp:287-332): entry q = row q of this lane's column
-  float T[E], Tx[E], Ty[E];
+  // ---- InitializePatch (patch.cpp:287-332): pair r = row r of this lane's two columns
+  f2 T[R], Tx[R], Ty[R];
   {
     const int px = (int)roundf(rx) + g.pad, py = (int)roundf(ry) + g.pad;
-    const unsigned base = (unsigned)((py - 4) * tw + px - 4 + pl);
+    const unsigned base = (unsigned)((py - 4) * tw + px - 4 + 2 * pl);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const unsigned o = base + (unsigned)(e * tw);
-      T[e] = imA[o];
-      Tx[e] = imAx[o];
-      Ty[e] = imAy[o];
+    for (int r = 0; r < R; ++r) {
+      const unsigned o = base + (unsigned)(r * tw);
+      T[r] = f2{imA[o], imA[o + 1]};
+      Tx[r] = f2{imAx[o], imAx[o + 1]};
+      Ty[r] = f2{imAy[o], imAy[o + 1]};
     }
     if (a.patnorm > 0) {
-      const float mean = patch_sum<M, LPP>(T, valid) * inv_nv;
+      const float mean = gray8_sum(T) * inv_nv;
 #pragma unroll
-      for (int e = 0; e < E; ++e) T[e] -= mean;
+      for (int r = 0; r < R; ++r) T[r] = T[r] - mean;
     }
   }
   // ---- ComputeHessian + Cholesky factor (patch.cpp:71-88, Eigen LLT as in oracle/eigen_shim)
   float l00, l10, l11;
   {
-    float pxx[E], pxy[E], pyy[E];
+    f2 pxx[R], pxy[R], pyy[R];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      pxx[e] = Tx[e] * Tx[e];
-      pxy[e] = Tx[e] * Ty[e];
-      pyy[e] = Ty[e] * Ty[e];
+    for (int r = 0; r < R; ++r) {
+      pxx[r] = Tx[r] * Tx[r];
+      pxy[r] = Tx[r] * Ty[r];
+      pyy[r] = Ty[r] * Ty[r];
     }
-    float H00 = patch_sum<M, LPP>(pxx, valid);
-    const float H01 = patch_sum<M, LPP>(pxy, valid);
-    float H11 = patch_sum<M, LPP>(pyy, valid);
+    float H00 = gray8_sum(pxx);
+    const float H01 = gray8_sum(pxy);
+    float H11 = gray8_sum(pyy);
     if (H00 * H11 - H01 * H01 == 0.0f) {
       H00 = (float)((double)H00 + 1e-10);
       H11 = (float)((double)H11 + 1e-10);
@@ -379,124 +422,149 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
     pin1 = fp[2 * i + 1] * 2;
   }
   // ---- OptimizeIter (patch.cpp:159-212)
+  // Register budget: the residual vector lives only inside one evaluation.  What the next Gauss-Newton step
+  // needs of it -- the two gradient sums -- is reduced while it is fresh, and the weights |r| go to memory at the
+  // evaluation after which the patch stops (every patch has exactly one), so only T, Tx, Ty stay resident.
+  const float r00 = rcp_refined(l00), r11 = rcp_refined(l11);  // shared by the four quotients of every solve
   float p0 = pin0, p1 = pin1;
   float ptx = rx + p0, pty = ry + p1;
   const float stx = ptx, sty = pty;
   float dp0 = 0.0f, dp1 = 0.0f;
   float dpsq = 1e-10f, dpsq_init = 1e-10f, mares = 1e20f, mares_old = 1e20f;
+  float b0 = 0.0f, b1 = 0.0f;  // sum Tx.r, sum Ty.r of the latest evaluation (patch.cpp:178-181)
   int cnt = 0;
   bool converged = false;
-  float pdiff[E], pw[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) { pdiff[e] = 0.0f; pw[e] = 0.0f; }
+  float2* pwout = reinterpret_cast<float2*>(a.pweight + ((size_t)frame * g.nop + ip) * 64) + pl;
 
-  auto compute_err = [&]() {  // patch.cpp:264-284, 335-402, 223-262
+  auto cost = [&](float d) {
+    if (costfct == 1) return copysignf(sqrtf(fabsf(d)), d);
+    const float bsq = 5.0f * 5.0f, bsq2 = bsq * 2.0f;
+    return copysignf(sqrtf((sqrtf(1.0f + (d * d) / bsq) - 1.0f) * bsq2), d);
+  };
+  auto compute_err = [&](bool stop) {  // patch.cpp:264-284, 335-402, 223-262
     int pos0 = (int)ceilf(ptx + .00001f), pos1 = (int)ceilf(pty + .00001f);
     const int pos2 = (int)floorf(ptx), pos3 = (int)floorf(pty);
     const float r0 = ptx - (float)pos2, r1 = pty - (float)pos3;
     const float we0 = r0 * r1, we1 = (1 - r0) * r1, we2 = r0 * (1 - r1), we3 = (1 - r0) * (1 - r1);
     pos0 += g.pad;
     pos1 += g.pad;
-    // byte offset of (row pos1-5, column pos0-5+pl): rows rr = 0..8 follow at rr*row_bytes, the
-    // lane's own column (tap a / c) is +4 bytes, its left neighbour (tap b / d) +0
-    const int voff = ((pos1 - 5) * tw + pos0 - 5 + pl) * 4;
-    float A[9], Bn[9];
+    // byte offset of (row pos1-5, column pos0-5+2pl) = the left tap of the lane's first column; rows rr = 0..8
+    // follow at rr*row_bytes
+#ifdef OFDIS_DBG_FIXED_VOFF  // timing experiment only (tools/ab_build.py): every patch reads the same window
+    const int voff = (pos0 + pos1 > -100000 ? 2 * pl : 1) * 4;
+#else
+    const int voff = ((pos1 - 5) * tw + pos0 - 5 + 2 * pl) * 4;
+#endif
+    f2 A[9], Bn[9];
 #pragma unroll
     for (int rr = 0; rr < 9; ++rr) {
-      A[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voff + 4, rr * row_bytes, 0));
-      Bn[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voff, rr * row_bytes, 0));
+      const auto t = __builtin_amdgcn_raw_buffer_load_b96(rsB, voff, rr * row_bytes, 0);
+      // (through a scalar: __builtin_bit_cast applied directly to a vector element reads element 0, ROCm 7.2)
+      const unsigned u0 = t[0], u1 = t[1], u2 = t[2];
+      const float c0 = __builtin_bit_cast(float, u0), c1 = __builtin_bit_cast(float, u1),
+                  c2 = __builtin_bit_cast(float, u2);
+      A[rr] = f2{c1, c2};
+      Bn[rr] = f2{c0, c1};
     }
-    float v[E];
+    f2 v[R];
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = we0 * A[e + 1] + we1 * Bn[e + 1] + we2 * A[e] + we3 * Bn[e];
+    for (int r = 0; r < R; ++r) v[r] = we0 * A[r + 1] + we1 * Bn[r + 1] + we2 * A[r] + we3 * Bn[r];
     if (a.patnorm > 0) {
-      const float mean = patch_sum<M, LPP>(v, valid) * inv_nv;
+      const float mean = gray8_sum(v) * inv_nv;
 #pragma unroll
-      for (int e = 0; e < E; ++e) v[e] -= mean;
+      for (int r = 0; r < R; ++r) v[r] = v[r] - mean;
     }
+    f2 gxr[R], gyr[R];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      float d = v[e] - T[e];
-      if (costfct == 1) {
-        d = copysignf(sqrtf(fabsf(d)), d);
-      } else if (costfct == 2) {
-        const float bsq = 5.0f * 5.0f, bsq2 = bsq * 2.0f;
-        d = copysignf(sqrtf((sqrtf(1.0f + (d * d) / bsq) - 1.0f) * bsq2), d);
-      }
-      pdiff[e] = d;
-      pw[e] = fabsf(d);
+    for (int r = 0; r < R; ++r) {
+      f2 d = v[r] - T[r];
+      if (costfct != 0) d = f2{cost(d.x), cost(d.y)};
+      v[r] = d;  // the residual (patch.cpp:230-261); the weights are |residual|
+      gxr[r] = Tx[r] * d;
+      gyr[r] = Ty[r] * d;
     }
+    b0 = gray8_sum(gxr);
+    b1 = gray8_sum(gyr);
     dpsq = dp0 * dp0 + dp1 * dp1;
     if (cnt == 1) dpsq_init = dpsq;
     mares_old = mares;
-    mares = patch_sum<M, LPP>(pw, valid) * inv_nv;
+    mares = gray8_abs_sum(v) * inv_nv;
     bool go = (cnt < a.max_iter) && (mares > a.res_thresh);
     // div_rn == IEEE division except (by < 2 ulp) for numerators below 2^-102, where neither ratio can be within
     // 2 ulp of its threshold
     if (go && cnt >= a.min_iter)
       go = (div_rn(dpsq, dpsq_init) >= a.dp_thresh_sq) & (div_rn(mares, mares_old) <= a.dr_thresh);
-    if (!go) converged = true;
+    if (!go | stop) {
+      converged = true;
+      if (live) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) pwout[r * 4] = make_float2(fabsf(v[r].x), fabsf(v[r].y));
+      }
+    }
   };
   auto oob = [&](float x, float y) { return (x < g.lb) | (y < g.lb) | (x > g.ubw) | (y > g.ubh); };
 
   if (oob(ptx, pty) || !(isfinite(ptx) && isfinite(pty))) {
-    converged = true;
+    converged = true;  // OptimizeStart (patch.cpp:120-156): no evaluation, pweight keeps its initial zeros
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) pwout[r * 4] = make_float2(0.0f, 0.0f);
+    }
   } else {
-    cnt = 0; dpsq = 1e-10f; dpsq_init = 1e-10f; mares = 1e5f; mares_old = 1e20f;
-    compute_err();
+    dpsq = 1e-10f; dpsq_init = 1e-10f; mares = 1e5f; mares_old = 1e20f;
+    compute_err(false);
   }
   while (!converged) {
     cnt++;
-    float gxr[E], gyr[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      gxr[e] = Tx[e] * pdiff[e];
-      gyr[e] = Ty[e] * pdiff[e];
-    }
-    const float b0 = patch_sum<M, LPP>(gxr, valid);
-    const float b1 = patch_sum<M, LPP>(gyr, valid);
-    const float y0 = b0 / l00;
-    const float y1 = (b1 - l10 * y0) / l11;
-    dp1 = y1 / l11;
-    dp0 = (y0 - l10 * dp1) / l00;
+    // delta_p = LLT(H).solve(b) (patch.cpp:184).  div_by(a, b, rcp_refined(b)) == a / b unless 0 < |a| < 2^-102
+    // (ofdis_dev.h), which a sum of products of image values cannot be (DESIGN.md "Arithmetic contract")
+    const float y0 = div_by(b0, l00, r00);
+    const float y1 = div_by(b1 - l10 * y0, l11, r11);
+    dp1 = div_by(y1, l11, r11);
+    dp0 = div_by(y0 - l10 * dp1, l00, r00);
     p0 -= dp0;
     p1 -= dp1;
     ptx = rx + p0;
     pty = ry + p1;
     const float ex = stx - ptx, ey = sty - pty;
     // branch-free (selects): the three tests are cheap next to the divergence bookkeeping of a nested branch.
-    // sqrt_rn == sqrtf for arguments >= 2^-96, and a smaller argument cannot be within an ulp of the threshold
-    const bool reset =
-        (sqrt_rn(ex * ex + ey * ey) > a.outlierthresh) | oob(ptx, pty) | !(isfinite(ptx) & isfinite(pty));
+    // norm > outlierthresh (patch.cpp:199) without the square root: sqrt is monotonic and correctly rounded, so
+    // sqrtf(x) > t  <=>  x > X, X = the largest float whose square root rounds to <= t (found on the host).
+    const bool reset = (ex * ex + ey * ey > a.outlier_sq_max) | oob(ptx, pty) | !(isfinite(ptx) & isfinite(pty));
     p0 = reset ? pin0 : p0;
     p1 = reset ? pin1 : p1;
     ptx = rx + p0;
     pty = ry + p1;
-    converged = converged | reset;
-    compute_err();
+    compute_err(reset);
   }
 
-  if (live) {
+  if (live && pl == 0) {
     float* pout = a.p_out + ((size_t)frame * g.nop + ip) * 2;
-    if (pl == 0) {
-      pout[0] = p0;
-      pout[1] = p1;
-    }
-    float* pwout = a.pweight + ((size_t)frame * g.nop + ip) * 64;
-#pragma unroll
-    for (int e = 0; e < E; ++e) pwout[e * 8 + pl] = pw[e];
+    pout[0] = p0;
+    pout[1] = p1;
   }
+}
+
+float outlier_sq_threshold(float t) {
+  if (!(t >= 0.0f) || !isfinite(t)) return t;  // NaN / negative / inf: keep the comparison's outcome (never / always / never)
+  float x = t * t;
+  while (x > 0.0f && sqrtf(x) > t) x = nextafterf(x, 0.0f);
+  while (sqrtf(nextafterf(x, INFINITY)) <= t) x = nextafterf(x, INFINITY);
+  return x;
 }
 
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   const int M = (a.g.novals + 63) / 64;
-  const int lpp = (M <= 1) ? 8 : 64;  // lanes per patch
-  const int ppb = 4 * (64 / lpp);     // patches per 256-thread block
-  const int blocks_per_frame = (a.g.nop + ppb - 1) / ppb;
-  const int grid = ((a.nframes + 7) / 8) * 8 * blocks_per_frame;
-  const dim3 gd(grid), bd(256);
   const bool full = a.g.novals == 64 * M;
   const bool gray8 = a.g.noc == 1 && a.g.P == 8 && !getenv("OFDIS_NO_GRAY8");
+  const int lpp = (M <= 1) ? (gray8 ? 4 : 8) : 64;  // lanes per patch
+  const int ppw = 64 / lpp;                           // patches per wavefront
+  const int wpf = (a.g.nop + ppw - 1) / ppw;          // wavefronts per frame
+  const bool fast = gray8 && M <= 1;
+  const int wpb = (fast && wpf < 4) ? wpf : 4;        // wavefronts per block (the generic kernels assume 4)
+  const int blocks_per_frame = (wpf + wpb - 1) / wpb;
+  const int grid = ((a.nframes + 7) / 8) * 8 * blocks_per_frame;
+  const dim3 gd(grid), bd(wpb * 64);
   if (M <= 1 && gray8 && a.costfct == 0)
     hipLaunchKernelGGL((patch_optimize_gray8_kernel<0>), gd, bd, 0, s, a);
   else if (M <= 1 && gray8)

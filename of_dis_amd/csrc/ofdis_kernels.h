@@ -12,7 +12,8 @@ struct DisArgs {
   int nframes;
   // solver parameters (oflow.cpp:76-108)
   int max_iter, min_iter, costfct, patnorm;
-  float dp_thresh_sq, dr_thresh, res_thresh, outlierthresh;
+  float dp_thresh_sq, dr_thresh, res_thresh;
+  float outlier_sq_max;  // largest x with sqrtf(x) <= outlierthresh (= P/2, oflow.cpp:82): outlier_sq_threshold()
   const float* im_a;     // [B][tmp_h][tmp_w][noc]
   const float* im_a_dx;
   const float* im_a_dy;
@@ -21,6 +22,8 @@ struct DisArgs {
   float* p_out;            // [B][nop][2]
   float* pweight;          // [B][nop][novals]
 };
+// largest float x with sqrtf(x) <= t (host sqrtf is correctly rounded)
+float outlier_sq_threshold(float t);
 // PatGridClass::{InitializeGrid, SetTargetImage, InitializeFromCoarserOF, Optimize}
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s);
 
