@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--tv", choices=["on", "off"], default="on")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--scope", choices=["ofclass", "e2e"], default="ofclass",
+                    help="ofclass (the metric): pyramids resident in HBM -> level flow.  e2e (secondary, DESIGN.md 5): "
+                         "8-bit frames resident in HBM -> pyramids -> flow -> full-resolution flow in HBM")
     args = ap.parse_args()
 
     import numpy as np
@@ -196,12 +199,22 @@ def main():
     batch.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
     torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    e2e = args.scope == "e2e"
+    full = torch.empty((B, HEIGHT, WIDTH, 2), dtype=torch.float32, device=dev) if e2e else None
+
+    def step():
+        if e2e:  # secondary scope: raw frames -> pyramids -> path -> full-resolution flow, everything in HBM
+            batch.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
         batch.run(stream)
+        if e2e:
+            batch.upsample(WIDTH, HEIGHT, out_ptr=full.data_ptr(), stream=stream)
+
+    for _ in range(args.warmup):
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        batch.run(stream)
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
@@ -255,7 +268,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"run_OF_INT op-point-2, 1024x436 (padded 1024x448, levels 5-3), patch 8 overlap 0.4, "
                                    f"12 GN iterations, TV {'on (6/5/4 inner its, 3 SOR sweeps, alpha=gamma=10 delta=5)' if tv else 'off'}; "
-                                   f"OFClass scope, pyramids resident in HBM",
+                                   + ("end-to-end scope: 8-bit frames in HBM -> pyramids -> flow -> full-resolution flow in HBM (secondary)"
+                                      if e2e else "OFClass scope, pyramids resident in HBM"),
                        "frames_per_gpu_per_step": B, "global_frames_per_step": B * world,
                        "parallelism": f"frame-sharded x{world}", "tv": args.tv},
             "roofline": roofline, "kernels": kernels,

@@ -114,6 +114,14 @@ int ofdis_batch_upload(ofdis_batch* b, int frame, const float* const* im_a, cons
 int ofdis_batch_build_pyramids_u8(ofdis_batch* b, const uint8_t* img_a, const uint8_t* img_b, int width_org,
                                   int height_org, void* stream);
 
+/* Warm start (the reference's `initflow`, oflow.cpp:217-220; e.g. the previous frame pair's flow of a video):
+ * per frame (w >> (sc_f+1)) x (h >> (sc_f+1)) x 2 floats, AoS.  set_initflow borrows a device array
+ * [nframes][ofdis_batch_initflow_elems] (NULL switches the warm start off again); upload_initflow copies one
+ * frame's host array into a buffer owned by the batch (frames never uploaded start from zero flow). */
+size_t ofdis_batch_initflow_elems(const ofdis_batch* b);
+int ofdis_batch_set_initflow(ofdis_batch* b, const float* initflow_dev);
+int ofdis_batch_upload_initflow(ofdis_batch* b, int frame, const float* initflow_host, void* stream);
+
 /* enqueue the whole hot path (all levels, DIS + densify + TV) for all frames on `stream` */
 int ofdis_batch_run(ofdis_batch* b, void* stream);
 /* device pointer to the result, [nframes][h>>sc_l][w>>sc_l][2] */
@@ -121,6 +129,10 @@ const float* ofdis_batch_flow(const ofdis_batch* b);
 /* device pointer to the dense flow of an intermediate level (for per-level parity tests) */
 const float* ofdis_batch_level_flow(const ofdis_batch* b, int level);
 int ofdis_batch_download(ofdis_batch* b, int frame, float* outflow_host, void* stream);
+/* The step after the path (run_dense.cpp:406-414): values x 2^sc_l, bilinear upsample by 2^sc_l (cv::resize
+ * INTER_LINEAR semantics: half-pixel centres, clamped borders) and crop of the 2^sc_f padding, for all frames:
+ * out_dev = device [nframes][height_org][width_org][2].  Enqueues on `stream`. */
+int ofdis_batch_upsample(ofdis_batch* b, float* out_dev, int width_org, int height_org, void* stream);
 
 /* Kernel timing for the roofline report: when enabled, ofdis_batch_run brackets every launch of
  * the named kernel class with hipEvents on `stream`; ofdis_batch_kernel_time returns the summed

@@ -26,8 +26,9 @@ K_NAMES = ["warp", "derivatives", "tv_system", "sor", "patch_optimize", "densify
 ABI_SYMBOLS = [
     "ofdis_params_oppoint", "ofdis_last_error", "ofdis_version", "ofdis_device_count", "ofdis_set_device",
     "ofdis_flow", "ofdis_batch_create", "ofdis_batch_destroy", "ofdis_batch_input", "ofdis_batch_input_elems",
-    "ofdis_batch_upload", "ofdis_batch_build_pyramids_u8", "ofdis_batch_run", "ofdis_batch_flow",
-    "ofdis_batch_level_flow", "ofdis_batch_download", "ofdis_batch_timing", "ofdis_batch_kernel_time",
+    "ofdis_batch_upload", "ofdis_batch_initflow_elems", "ofdis_batch_set_initflow", "ofdis_batch_upload_initflow",
+    "ofdis_batch_build_pyramids_u8", "ofdis_batch_run", "ofdis_batch_flow",
+    "ofdis_batch_level_flow", "ofdis_batch_download", "ofdis_batch_upsample", "ofdis_batch_timing", "ofdis_batch_kernel_time",
     "ofdis_image_warp", "ofdis_get_derivatives", "ofdis_tv_system", "ofdis_sor_coupled", "ofdis_patchgrid_level",
     "ofdis_varref_level", "ofdis_dev_alloc", "ofdis_dev_free", "ofdis_memcpy_h2d", "ofdis_memcpy_d2h", "ofdis_memcpy_d2d", "ofdis_sync",
 ]
@@ -80,6 +81,11 @@ def lib():
         L.ofdis_varref_level.argtypes = [C.POINTER(OfdisParams), C.c_int, VP, VP, VP, C.c_int, VP]
         L.ofdis_flow.argtypes = [C.POINTER(OfdisParams)] + [C.POINTER(FP)] * 6 + [FP, FP]
         L.ofdis_params_oppoint.argtypes = [C.POINTER(OfdisParams), C.c_int, C.c_int, C.c_int]
+        L.ofdis_batch_upsample.argtypes = [VP, VP, C.c_int, C.c_int, VP]
+        L.ofdis_batch_initflow_elems.restype = C.c_size_t
+        L.ofdis_batch_initflow_elems.argtypes = [VP]
+        L.ofdis_batch_set_initflow.argtypes = [VP, VP]
+        L.ofdis_batch_upload_initflow.argtypes = [VP, C.c_int, FP, VP]
         L.ofdis_test_wave_sum.argtypes = [VP, VP, C.c_int, VP]
         L.ofdis_test_div_sqrt.argtypes = [VP, VP, VP, C.c_int, VP]
         _lib = L
@@ -204,7 +210,7 @@ def _ptr_array(planes, n):
     return arr
 
 
-def flow(p, pyr_a, pyr_a_dx, pyr_a_dy, pyr_b):
+def flow(p, pyr_a, pyr_a_dx, pyr_a_dy, pyr_b, initflow=None):
     """ofdis_flow(): the drop-in for OFC::OFClass::OFClass with host pyramids (lists over levels 0..sc_f)."""
     n = p.sc_f + 1
     keep = [[_f(x) if x is not None else None for x in pl] for pl in (pyr_a, pyr_a_dx, pyr_a_dy, pyr_b)]
@@ -212,7 +218,8 @@ def flow(p, pyr_a, pyr_a_dx, pyr_a_dy, pyr_b):
     out = np.zeros((h, w, 2), _f32)
     nullarr = C.cast(None, C.POINTER(FP))
     check(lib().ofdis_flow(C.byref(p), _ptr_array(keep[0], n), _ptr_array(keep[1], n), _ptr_array(keep[2], n),
-                           _ptr_array(keep[3], n), nullarr, nullarr, out.ctypes.data_as(FP), None))
+                           _ptr_array(keep[3], n), nullarr, nullarr, out.ctypes.data_as(FP),
+                           _f(initflow).ctypes.data_as(FP) if initflow is not None else None))
     return out
 
 
@@ -272,6 +279,14 @@ class Batch:
         assert arr.size == self.input_elems(level) * self.nframes, (arr.shape, self.input_elems(level))
         check(lib().ofdis_memcpy_h2d(self.input_ptr(level, kind), arr.ctypes.data, arr.nbytes))
 
+    def upload_initflow(self, frame, initflow, stream=None):
+        a = _f(initflow)
+        assert a.size == lib().ofdis_batch_initflow_elems(self.h), (a.shape, lib().ofdis_batch_initflow_elems(self.h))
+        check(lib().ofdis_batch_upload_initflow(self.h, frame, a.ctypes.data_as(FP), stream))
+
+    def set_initflow(self, dev_ptr):
+        check(lib().ofdis_batch_set_initflow(self.h, dev_ptr))
+
     def build_pyramids_u8(self, img_a_ptr, img_b_ptr, width_org, height_org, stream=None):
         check(lib().ofdis_batch_build_pyramids_u8(self.h, img_a_ptr, img_b_ptr, width_org, height_org, stream))
 
@@ -285,6 +300,19 @@ class Batch:
         w, h = self.p.level_size(self.p.sc_l)
         out = np.zeros((h, w, 2), _f32)
         check(lib().ofdis_batch_download(self.h, frame, out.ctypes.data_as(FP), stream))
+        return out
+
+    def upsample(self, width_org, height_org, out_ptr=None, stream=None):
+        """ofdis_batch_upsample.  With out_ptr (device pointer) only enqueues; otherwise returns the host array
+        [nframes][height_org][width_org][2]."""
+        if out_ptr is not None:
+            check(lib().ofdis_batch_upsample(self.h, out_ptr, width_org, height_org, stream))
+            return None
+        out = np.zeros((self.nframes, height_org, width_org, 2), _f32)
+        d = Dev(nbytes=out.nbytes)
+        check(lib().ofdis_batch_upsample(self.h, d.ptr, width_org, height_org, stream))
+        check(lib().ofdis_sync(stream))
+        check(lib().ofdis_memcpy_d2h(out.ctypes.data, d.ptr, out.nbytes))
         return out
 
     def download_all(self):

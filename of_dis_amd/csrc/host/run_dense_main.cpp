@@ -7,7 +7,7 @@
 //   run_OF_INT img1 img2 out.flo p1 .. p20            the 20 explicit parameters
 //
 // Pipeline: read 8-bit images -> upload -> on-device padding, pyramid, Sobel (ofdis_batch_build_pyramids_u8)
-// -> hot path (ofdis_batch_run) -> download the (w>>lv_l x h>>lv_l) flow -> x2^lv_l, bilinear upsample, crop
+// -> hot path (ofdis_batch_run) -> x2^lv_l, bilinear upsample, crop on the device (ofdis_batch_upsample) -> download
 // (run_dense.cpp:406-414, cv::resize INTER_LINEAR restated) -> Middlebury .flo.
 #include <math.h>
 #include <stdio.h>
@@ -30,37 +30,6 @@ static double now_ms() {
   struct timeval tv;
   gettimeofday(&tv, nullptr);
   return tv.tv_sec * 1000.0 + tv.tv_usec / 1000.0;
-}
-
-// flowout *= 2^lv_l; cv::resize(x 2^lv_l, INTER_LINEAR); crop (run_dense.cpp:406-414)
-static void upsample_crop(const ofdis_params& p, const float* flow, int width_org, int height_org, float* out) {
-  const int s = 1 << p.sc_l;
-  const int sw = p.width >> p.sc_l, sh = p.height >> p.sc_l;
-  const int left = (p.width - width_org) / 2, top = (p.height - height_org) / 2;
-  const float scf = (float)s;
-  const double inv = 1.0 / (double)s;
-  for (int y = 0; y < height_org; ++y) {
-    float fy = (float)((y + top + 0.5) * inv - 0.5);
-    int sy = (int)floor(fy);
-    fy -= sy;
-    if (sy < 0) { sy = 0; fy = 0; }
-    if (sy >= sh - 1) { sy = sh - 1; fy = 0; }
-    const int sy1 = std::min(sy + 1, sh - 1);
-    for (int x = 0; x < width_org; ++x) {
-      float fx = (float)((x + left + 0.5) * inv - 0.5);
-      int sx = (int)floor(fx);
-      fx -= sx;
-      if (sx < 0) { sx = 0; fx = 0; }
-      if (sx >= sw - 1) { sx = sw - 1; fx = 0; }
-      const int sx1 = std::min(sx + 1, sw - 1);
-      for (int c = 0; c < 2; ++c) {
-        const float v00 = flow[2 * (sy * sw + sx) + c] * scf, v01 = flow[2 * (sy * sw + sx1) + c] * scf;
-        const float v10 = flow[2 * (sy1 * sw + sx) + c] * scf, v11 = flow[2 * (sy1 * sw + sx1) + c] * scf;
-        const float r0 = v00 * (1.0f - fx) + v01 * fx, r1 = v10 * (1.0f - fx) + v11 * fx;
-        out[2 * ((size_t)y * width_org + x) + c] = r0 * (1.0f - fy) + r1 * fy;
-      }
-    }
-  }
 }
 
 int main(int argc, char** argv) {
@@ -140,16 +109,19 @@ int main(int argc, char** argv) {
 
   // *** the hot path (prints the reference's per-level TIME lines itself when verbosity > 1)
   rc = ofdis_batch_run(b, nullptr);
-  const int sw = p.width >> p.sc_l, sh = p.height >> p.sc_l;
-  std::vector<float> flow((size_t)2 * sw * sh);
-  if (!rc) rc = ofdis_batch_download(b, 0, flow.data(), nullptr);
+  // x 2^lv_l, bilinear upsample, crop (run_dense.cpp:406-414) on the device, then one download
+  t0 = now_ms();
+  std::vector<float> full((size_t)2 * width_org * height_org);
+  void* dfull = ofdis_dev_alloc(full.size() * sizeof(float));
+  if (!rc && !dfull) rc = OFDIS_ERR_NOMEM;
+  if (!rc) rc = ofdis_batch_upsample(b, (float*)dfull, width_org, height_org, nullptr);
+  if (!rc) rc = ofdis_sync(nullptr);
+  if (!rc) rc = ofdis_memcpy_d2h(full.data(), dfull, full.size() * sizeof(float));
   if (rc) {
     fprintf(stderr, "%s\n", ofdis_last_error());
     return 1;
   }
-  t0 = now_ms();
-  std::vector<float> full((size_t)2 * width_org * height_org);
-  upsample_crop(p, flow.data(), width_org, height_org, full.data());
+  ofdis_dev_free(dfull);
   if (!ofdis_host::write_flo(f_out, full.data(), width_org, height_org, &err)) {
     printf("%s\n", err.c_str());  // the reference reports and carries on (run_dense.cpp:24-25)
   }

@@ -98,6 +98,8 @@ struct ofdis_batch {
   std::vector<LevelGeom> geom;       // index = level - sc_l
   std::vector<float*> in[4];         // A, A_dx, A_dy, B per level
   std::vector<float*> flow;          // AoS dense flow per level
+  const float* initflow = nullptr;   // borrowed device pointer (ofdis_batch_set_initflow) or null
+  float* initflow_own = nullptr;     // staging buffer of ofdis_batch_upload_initflow
   // scratch, sized for the finest level
   float *pvec = nullptr, *pweight = nullptr;
   float *wx = nullptr, *wy = nullptr, *du = nullptr, *dv = nullptr, *mask = nullptr;
@@ -433,7 +435,7 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
       a.im_a_dx = b->in[1][ii];
       a.im_a_dy = b->in[2][ii];
       a.im_b = b->in[3][ii];
-      a.flow_prev = (sl < p.sc_f) ? b->flow[ii + 1] : nullptr;  // initflow: see ofdis_flow()
+      a.flow_prev = (sl < p.sc_f) ? b->flow[ii + 1] : b->initflow;  // oflow.cpp:209-220
       a.p_out = b->pvec;
       a.pweight = b->pweight;
       HIPCHK(launch_patch_optimize(a, s));
@@ -493,6 +495,45 @@ int ofdis_batch_download(ofdis_batch* b, int frame, float* outflow_host, void* s
   return OFDIS_OK;
 }
 
+// Warm start (oflow.cpp:217-220): the coarsest level initialises its patches from this flow exactly as finer levels
+// do from the level above, i.e. it is indexed as a (w >> (sc_f+1)) x (h >> (sc_f+1)) AoS plane per frame.
+size_t ofdis_batch_initflow_elems(const ofdis_batch* b) {
+  if (!b) return 0;
+  const LevelGeom& g = b->geom[b->nlevels - 1];
+  return (size_t)(g.w / 2) * (g.h / 2) * 2;
+}
+
+int ofdis_batch_set_initflow(ofdis_batch* b, const float* initflow_dev) {
+  if (!b) return fail(OFDIS_ERR_INVALID, "batch is NULL");
+  b->initflow = initflow_dev;
+  return OFDIS_OK;
+}
+
+int ofdis_batch_upload_initflow(ofdis_batch* b, int frame, const float* initflow_host, void* stream) {
+  if (!b || frame < 0 || frame >= b->nframes || !initflow_host) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  const size_t n = ofdis_batch_initflow_elems(b);
+  if (!b->initflow_own) {
+    int rc = dalloc(b, &b->initflow_own, n * b->nframes);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(b->initflow_own, 0, n * b->nframes * sizeof(float), (hipStream_t)stream));
+  }
+  HIPCHK(hipMemcpyAsync(b->initflow_own + (size_t)frame * n, initflow_host, n * sizeof(float), hipMemcpyHostToDevice,
+                        (hipStream_t)stream));
+  b->initflow = b->initflow_own;
+  return OFDIS_OK;
+}
+
+int ofdis_batch_upsample(ofdis_batch* b, float* out_dev, int width_org, int height_org, void* stream) {
+  if (!b || !out_dev) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  const ofdis_params& p = b->p;
+  if (width_org < 1 || height_org < 1 || width_org > p.width || height_org > p.height)
+    return fail(OFDIS_ERR_INVALID, "original size exceeds the padded size");
+  const LevelGeom& g = b->geom[0];
+  HIPCHK(launch_upsample_crop(b->flow[0], out_dev, b->nframes, g.w, g.h, p.sc_l, (p.width - width_org) / 2,
+                              (p.height - height_org) / 2, width_org, height_org, (hipStream_t)stream));
+  return OFDIS_OK;
+}
+
 int ofdis_batch_timing(ofdis_batch* b, int enable) {
   if (!b) return fail(OFDIS_ERR_INVALID, "batch is NULL");
   b->timing = enable != 0;
@@ -520,11 +561,11 @@ int ofdis_flow(const ofdis_params* p, const float* const* im_a, const float* con
                const float* const* im_b_dy, float* outflow, const float* initflow) {
   (void)im_b_dx; (void)im_b_dy;  // never read when usefbcon == 0
   if (!outflow) return fail(OFDIS_ERR_INVALID, "outflow is NULL");
-  if (initflow) return fail(OFDIS_ERR_UNSUPPORTED, "initflow warm start is not supported yet (SURVEY.md 8f-4)");
   ofdis_batch* b = nullptr;
   int rc = ofdis_batch_create(&b, p, 1);
   if (rc) return rc;
   rc = ofdis_batch_upload(b, 0, im_a, im_a_dx, im_a_dy, im_b, nullptr);
+  if (!rc && initflow) rc = ofdis_batch_upload_initflow(b, 0, initflow, nullptr);
   if (!rc) rc = ofdis_batch_run(b, nullptr);
   if (!rc) rc = ofdis_batch_download(b, 0, outflow, nullptr);
   ofdis_batch_destroy(b);

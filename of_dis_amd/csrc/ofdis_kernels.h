@@ -139,6 +139,10 @@ hipError_t launch_pyr_down(const float* src, float* dst, int nframes, int w, int
 hipError_t launch_pyr_planes(const float* src, float* img, float* dx, float* dy, int nframes, int w, int h, int noc,
                              int pad, hipStream_t s);
 
+// x 2^sc_l, bilinear upsample (cv::resize INTER_LINEAR) and crop of the AoS result (run_dense.cpp:406-414)
+hipError_t launch_upsample_crop(const float* flow, float* out, int nframes, int sw, int sh, int sc_l, int left, int top,
+                                int wo, int ho, hipStream_t s);
+
 // test hook: out[i] = wave_sum over each consecutive group of 64 inputs (n multiple of 64)
 hipError_t launch_wave_sum_test(const float* in, float* out, int n, hipStream_t s);
 // test hook: out[4][n] = div_rn(a,b), a/b, sqrt_rn(|a|), sqrtf(|a|)

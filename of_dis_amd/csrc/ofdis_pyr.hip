@@ -134,4 +134,65 @@ hipError_t launch_pyr_planes(const float* src, float* img, float* dx, float* dy,
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------ result to full resolution
+// run_dense.cpp:406-414: flowout *= 2^lv_l; cv::resize(flowout, x 2^lv_l, INTER_LINEAR); crop the padding.
+// cv::resize bilinear for CV_32FC2: half-pixel centres, source index clamped with the fraction forced to 0 at
+// the borders, horizontal interpolation first.  2^lv_l is a power of two, so (X + 0.5) / s - 0.5 is exact in fp32.
+// One thread per output pixel, 8-byte stores; the source (57 KB per frame at op-point 2) is L2 resident.
+__device__ __forceinline__ float2 upsample_px(const float2* __restrict__ fl, int sw, int sy, int sy1, float fy, int X,
+                                              float inv, float scf, bool scale) {
+  float fx = ((float)X + 0.5f) * inv - 0.5f;
+  int sx = (int)floorf(fx);
+  fx -= (float)sx;
+  if (sx < 0) { sx = 0; fx = 0.0f; }
+  if (sx >= sw - 1) { sx = sw - 1; fx = 0.0f; }
+  const int sx1 = min(sx + 1, sw - 1);
+  float2 v00 = fl[sy * sw + sx], v01 = fl[sy * sw + sx1], v10 = fl[sy1 * sw + sx], v11 = fl[sy1 * sw + sx1];
+  if (scale) {
+    v00.x *= scf; v00.y *= scf; v01.x *= scf; v01.y *= scf;
+    v10.x *= scf; v10.y *= scf; v11.x *= scf; v11.y *= scf;
+  }
+  const float ax = 1.0f - fx, ay = 1.0f - fy;
+  const float r0x = v00.x * ax + v01.x * fx, r1x = v10.x * ax + v11.x * fx;
+  const float r0y = v00.y * ax + v01.y * fx, r1y = v10.y * ax + v11.y * fx;
+  return make_float2(r0x * ay + r1x * fy, r0y * ay + r1y * fy);
+}
+
+// grid = (x chunks of 512 pixels, output row, frame); a thread writes two adjacent pixels (16 bytes)
+__global__ __launch_bounds__(256) void upsample_crop_kernel(const float2* __restrict__ flow, float2* __restrict__ out,
+                                                            int sw, int sh, int sc_l, int left, int top, int wo, int ho) {
+  const int f = blockIdx.z, y = blockIdx.y;
+  const int x = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (x >= wo) return;
+  const float scf = (float)(1 << sc_l), inv = 1.0f / scf;
+  float fy = ((float)(y + top) + 0.5f) * inv - 0.5f;
+  int sy = (int)floorf(fy);
+  fy -= (float)sy;
+  if (sy < 0) { sy = 0; fy = 0.0f; }
+  if (sy >= sh - 1) { sy = sh - 1; fy = 0.0f; }
+  const int sy1 = min(sy + 1, sh - 1);
+  const float2* fl = flow + (size_t)f * sw * sh;
+  float2* o = out + ((size_t)f * ho + y) * wo + x;
+  const float2 a = upsample_px(fl, sw, sy, sy1, fy, x + left, inv, scf, sc_l > 0);
+  if (x + 1 < wo) {
+    const float2 b = upsample_px(fl, sw, sy, sy1, fy, x + 1 + left, inv, scf, sc_l > 0);
+    if ((wo & 1) == 0) {
+      *reinterpret_cast<float4*>(o) = make_float4(a.x, a.y, b.x, b.y);  // rows are 16-byte aligned when wo is even
+    } else {
+      o[0] = a;
+      o[1] = b;
+    }
+  } else {
+    o[0] = a;
+  }
+}
+
+hipError_t launch_upsample_crop(const float* flow, float* out, int nframes, int sw, int sh, int sc_l, int left, int top,
+                                int wo, int ho, hipStream_t s) {
+  if (ho > 65535 || nframes > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(upsample_crop_kernel, dim3((wo + 511) / 512, ho, nframes), dim3(256), 0, s, (const float2*)flow,
+                     (float2*)out, sw, sh, sc_l, left, top, wo, ho);
+  return hipGetLastError();
+}
+
 }  // namespace ofdis

@@ -56,6 +56,55 @@ def test_batch_matches_single_and_is_deterministic(gpu, orc):
     b.close()
 
 
+@pytest.mark.parametrize("size,opp", [((1024, 436), 2), ((640, 480), 2), ((333, 251), 1), ((320, 240), 3)])
+def test_upsample_crop_on_device(gpu, orc, size, opp):
+    """ofdis_batch_upsample == the oracle's restatement of run_dense.cpp:406-414 (x 2^sc_l, cv::resize, crop),
+    including odd sizes whose padding is cropped asymmetrically and op-point 3 (finest level 2, x4)."""
+    w, h = size
+    cases = [synth_case(w, h, 4321 + k, 1, opp, 1) for k in range(2)]
+    p = cases[0][0]
+    b = gpu.Batch(p, 2)
+    for k, (_, pa, pb, _, _) in enumerate(cases):
+        b.upload(k, pa[0], pa[1], pa[2], pb[0])
+    b.run()
+    low = b.download_all()
+    full = b.upsample(w, h)
+    b.close()
+    for k in range(2):
+        assert_bits_equal(full[k], orc.upsample_crop(p, low[k], w, h), f"full-resolution flow, frame {k}")
+
+
+def test_initflow_warm_start(gpu, orc):
+    """initflow (oflow.cpp:217-220): the coarsest level starts from a caller-supplied flow, e.g. the previous
+    pair's result of a video.  Checked against the restatement and the reference sources, through ofdis_flow and
+    through the batch interface (frame 1 of the batch stays cold)."""
+    p, pa, pb, _, _ = synth_case(1024, 436, 1300, 1, 2, 1)
+    w, h = p.level_size(p.sc_f)
+    rng = np.random.default_rng(3)
+    init = (rng.standard_normal((h // 2, w // 2, 2)) * 0.4).astype(np.float32)
+    init[0, 0] = (60.0, -60.0)          # sends one start position out of bounds (OptimizeStart path)
+    ref = orc.flow(p, pa[0], pa[1], pa[2], pb[0], initflow=init)
+    cold = orc.flow(p, pa[0], pa[1], pa[2], pb[0])
+    assert not np.array_equal(ref, cold)
+    got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0], initflow=init)
+    assert_bits_equal(got, ref, "ofdis_flow with initflow vs restatement")
+    if oracle.have_ref("int", True):
+        r = oracle.ref("int", True).flow(p, pa[0], pa[1], pa[2], pb[0], initflow=init)
+        assert_bits_equal(got, r, "ofdis_flow with initflow vs reference sources")
+    b = gpu.Batch(p, 2)
+    for k in range(2):
+        b.upload(k, pa[0], pa[1], pa[2], pb[0])
+    b.upload_initflow(0, init)
+    b.run()
+    out = b.download_all()
+    assert_bits_equal(out[0], ref, "batch frame 0 (warm)")
+    assert_bits_equal(out[1], cold, "batch frame 1 (cold)")
+    b.set_initflow(None)
+    b.run()
+    assert_bits_equal(b.download_all()[0], cold, "warm start switched off")
+    b.close()
+
+
 def test_batch_level_flows(gpu, orc):
     p, pa, pb, _, _ = synth_case(1024, 436, 1240, 1, 2, 1)
     _, levels = orc.flow(p, pa[0], pa[1], pa[2], pb[0], want_levels=True)
