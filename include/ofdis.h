@@ -49,7 +49,7 @@ typedef struct ofdis_params {
   float dp_thresh, dr_thresh, res_thresh;
   int   p_samp_s;           /* patch edge length P */
   float patove;             /* patch overlap in [0,1) */
-  int   usefbcon;           /* forward-backward merging: must be 0 */
+  int   usefbcon;           /* forward-backward merging (oflow.cpp:162-170, patchgrid.cpp:277-375) */
   int   costfct;            /* 0 L2, 1 L1, 2 pseudo-Huber (patch.cpp:230-261) */
   int   noc;                /* channels: 1 (run_OF_INT) or 3 (run_OF_RGB) */
   int   patnorm;            /* subtract patch mean */
@@ -77,7 +77,7 @@ int ofdis_set_device(int device);
  * im_*: arrays of sc_f+1 host pointers; entries sc_l..sc_f must be valid (oflow.h:85-87).  Each
  * plane is row-major fp32, (w/2^l + 2*imgpadding) x (h/2^l + 2*imgpadding) x noc, channel
  * interleaved, images replicate-padded, gradients zero-padded (run_dense.cpp:166-175).
- * im_b_dx / im_b_dy may be NULL (never read when usefbcon == 0).
+ * im_b_dx / im_b_dy may be NULL when usefbcon == 0 (never read then).
  * outflow: 2*(w>>sc_l)*(h>>sc_l) floats, AoS (u,v), fully overwritten.
  * initflow: optional (w>>(sc_f+1))*(h>>(sc_f+1))*2 floats or NULL (oflow.cpp:217-220).
  * ------------------------------------------------------------------------------------------- */
@@ -113,6 +113,10 @@ int ofdis_batch_upload(ofdis_batch* b, int frame, const float* const* im_a, cons
  * as the reference does (replicate, floor/ceil split). */
 int ofdis_batch_build_pyramids_u8(ofdis_batch* b, const uint8_t* img_a, const uint8_t* img_b, int width_org,
                                   int height_org, void* stream);
+
+/* usefbcon = 1 only: the gradient pyramids of the second image (the backward grid's templates; never read otherwise) */
+int ofdis_batch_upload_b_gradients(ofdis_batch* b, int frame, const float* const* im_b_dx, const float* const* im_b_dy,
+                                   void* stream);
 
 /* Warm start (the reference's `initflow`, oflow.cpp:217-220; e.g. the previous frame pair's flow of a video):
  * per frame (w >> (sc_f+1)) x (h >> (sc_f+1)) x 2 floats, AoS.  set_initflow borrows a device array

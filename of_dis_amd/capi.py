@@ -26,7 +26,7 @@ K_NAMES = ["warp", "derivatives", "tv_system", "sor", "patch_optimize", "densify
 ABI_SYMBOLS = [
     "ofdis_params_oppoint", "ofdis_last_error", "ofdis_version", "ofdis_device_count", "ofdis_set_device",
     "ofdis_flow", "ofdis_batch_create", "ofdis_batch_destroy", "ofdis_batch_input", "ofdis_batch_input_elems",
-    "ofdis_batch_upload", "ofdis_batch_initflow_elems", "ofdis_batch_set_initflow", "ofdis_batch_upload_initflow",
+    "ofdis_batch_upload", "ofdis_batch_upload_b_gradients", "ofdis_batch_initflow_elems", "ofdis_batch_set_initflow", "ofdis_batch_upload_initflow",
     "ofdis_batch_build_pyramids_u8", "ofdis_batch_run", "ofdis_batch_flow",
     "ofdis_batch_level_flow", "ofdis_batch_download", "ofdis_batch_upsample", "ofdis_batch_timing", "ofdis_batch_kernel_time",
     "ofdis_image_warp", "ofdis_get_derivatives", "ofdis_tv_system", "ofdis_sor_coupled", "ofdis_patchgrid_level",
@@ -82,6 +82,7 @@ def lib():
         L.ofdis_flow.argtypes = [C.POINTER(OfdisParams)] + [C.POINTER(FP)] * 6 + [FP, FP]
         L.ofdis_params_oppoint.argtypes = [C.POINTER(OfdisParams), C.c_int, C.c_int, C.c_int]
         L.ofdis_batch_upsample.argtypes = [VP, VP, C.c_int, C.c_int, VP]
+        L.ofdis_batch_upload_b_gradients.argtypes = [VP, C.c_int, C.POINTER(FP), C.POINTER(FP), VP]
         L.ofdis_batch_initflow_elems.restype = C.c_size_t
         L.ofdis_batch_initflow_elems.argtypes = [VP]
         L.ofdis_batch_set_initflow.argtypes = [VP, VP]
@@ -210,15 +211,18 @@ def _ptr_array(planes, n):
     return arr
 
 
-def flow(p, pyr_a, pyr_a_dx, pyr_a_dy, pyr_b, initflow=None):
+def flow(p, pyr_a, pyr_a_dx, pyr_a_dy, pyr_b, initflow=None, pyr_b_dx=None, pyr_b_dy=None):
     """ofdis_flow(): the drop-in for OFC::OFClass::OFClass with host pyramids (lists over levels 0..sc_f)."""
     n = p.sc_f + 1
     keep = [[_f(x) if x is not None else None for x in pl] for pl in (pyr_a, pyr_a_dx, pyr_a_dy, pyr_b)]
+    keep_b = [[_f(x) if x is not None else None for x in pl] for pl in (pyr_b_dx, pyr_b_dy) if pl is not None]
     w, h = p.level_size(p.sc_l)
     out = np.zeros((h, w, 2), _f32)
     nullarr = C.cast(None, C.POINTER(FP))
+    bdx = _ptr_array(keep_b[0], n) if len(keep_b) == 2 else nullarr
+    bdy = _ptr_array(keep_b[1], n) if len(keep_b) == 2 else nullarr
     check(lib().ofdis_flow(C.byref(p), _ptr_array(keep[0], n), _ptr_array(keep[1], n), _ptr_array(keep[2], n),
-                           _ptr_array(keep[3], n), nullarr, nullarr, out.ctypes.data_as(FP),
+                           _ptr_array(keep[3], n), bdx, bdy, out.ctypes.data_as(FP),
                            _f(initflow).ctypes.data_as(FP) if initflow is not None else None))
     return out
 
@@ -271,6 +275,12 @@ class Batch:
         keep = [[_f(x) if x is not None else None for x in pl] for pl in (pyr_a, pyr_a_dx, pyr_a_dy, pyr_b)]
         check(lib().ofdis_batch_upload(self.h, frame, _ptr_array(keep[0], n), _ptr_array(keep[1], n),
                                        _ptr_array(keep[2], n), _ptr_array(keep[3], n), stream))
+        check(lib().ofdis_sync(stream))
+
+    def upload_b_gradients(self, frame, pyr_b_dx, pyr_b_dy, stream=None):
+        n = self.p.sc_f + 1
+        keep = [[_f(x) if x is not None else None for x in pl] for pl in (pyr_b_dx, pyr_b_dy)]
+        check(lib().ofdis_batch_upload_b_gradients(self.h, frame, _ptr_array(keep[0], n), _ptr_array(keep[1], n), stream))
         check(lib().ofdis_sync(stream))
 
     def set_input(self, level, kind, arr):

@@ -63,7 +63,6 @@ LevelGeom make_geom(const ofdis_params& p, int sl) {
 
 int check_params(const ofdis_params* p) {
   if (!p) return fail(OFDIS_ERR_INVALID, "params is NULL");
-  if (p->usefbcon) return fail(OFDIS_ERR_UNSUPPORTED, "usefbcon=1 (forward-backward merging) is outside this path");
   if (p->noc != 1 && p->noc != 3) return fail(OFDIS_ERR_INVALID, "noc must be 1 or 3");
   if (p->sc_l < 0 || p->sc_f < p->sc_l || p->sc_f > 20) return fail(OFDIS_ERR_INVALID, "need 0 <= sc_l <= sc_f");
   if (p->width <= 0 || p->height <= 0 || (p->width % (1 << p->sc_f)) || (p->height % (1 << p->sc_f)))
@@ -96,7 +95,10 @@ struct ofdis_batch {
   int nframes = 0;
   int nlevels = 0;
   std::vector<LevelGeom> geom;       // index = level - sc_l
-  std::vector<float*> in[4];         // A, A_dx, A_dy, B per level
+  std::vector<float*> in[6];         // A, A_dx, A_dy, B per level (+ B_dx, B_dy when usefbcon)
+  std::vector<float*> flow_bw;       // usefbcon: backward dense flow per level (oflow.cpp:162)
+  float* pvec_bw = nullptr;          // usefbcon: backward grid results
+  float* pweight_bw = nullptr;
   std::vector<float*> flow;          // AoS dense flow per level
   const float* initflow = nullptr;   // borrowed device pointer (ofdis_batch_set_initflow) or null
   float* initflow_own = nullptr;     // staging buffer of ofdis_batch_upload_initflow
@@ -238,6 +240,18 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
   return OFDIS_OK;
 }
 
+// same, starting from an AoS flow (the backward direction of usefbcon, whose densified flow waits in AoS form)
+int run_varref_from_aos(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow,
+                        hipStream_t s) {
+  TvGeom t{g.w, g.h, g.noc, b->nframes};
+  HIPCHK(launch_flow_split(t, flow, b->wx, b->wy, s));
+  if (use_fused(b, g)) {
+    HIPCHK(launch_to_diag(b->wx, b->wx_d, g.w, g.h, b->nframes, s));
+    HIPCHK(launch_to_diag(b->wy, b->wy_d, g.w, g.h, b->nframes, s));
+  }
+  return run_varref(b, g, im_a, im_b, flow, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -298,13 +312,16 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
   b->nframes = nframes;
   b->nlevels = p->sc_f - p->sc_l + 1;
   for (int l = p->sc_l; l <= p->sc_f; ++l) b->geom.push_back(make_geom(*p, l));
-  for (int k = 0; k < 4; ++k) b->in[k].assign(b->nlevels, nullptr);
+  const int nin = p->usefbcon ? 6 : 4;
+  for (int k = 0; k < 6; ++k) b->in[k].assign(b->nlevels, nullptr);
   b->flow.assign(b->nlevels, nullptr);
+  b->flow_bw.assign(b->nlevels, nullptr);
   rc = OFDIS_OK;
   for (int i = 0; i < b->nlevels && !rc; ++i) {
     const LevelGeom& g = b->geom[i];
-    for (int k = 0; k < 4 && !rc; ++k) rc = dalloc(b, &b->in[k][i], g.plane_elems * nframes);
+    for (int k = 0; k < nin && !rc; ++k) rc = dalloc(b, &b->in[k][i], g.plane_elems * nframes);
     if (!rc) rc = dalloc(b, &b->flow[i], (size_t)g.w * g.h * 2 * nframes);
+    if (!rc && p->usefbcon && i > 0) rc = dalloc(b, &b->flow_bw[i], (size_t)g.w * g.h * 2 * nframes);
   }
   const LevelGeom& g0 = b->geom[0];  // finest level: largest of everything
   const size_t npx = (size_t)g0.w * g0.h * nframes;
@@ -312,6 +329,8 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
   for (auto& g : b->geom) nop_max = std::max(nop_max, (size_t)g.nop);
   if (!rc) rc = dalloc(b, &b->pvec, nop_max * 2 * nframes);
   if (!rc) rc = dalloc(b, &b->pweight, nop_max * g0.novals * nframes);
+  if (!rc && p->usefbcon) rc = dalloc(b, &b->pvec_bw, nop_max * 2 * nframes);
+  if (!rc && p->usefbcon) rc = dalloc(b, &b->pweight_bw, nop_max * g0.novals * nframes);
   if (!rc && p->usetvref) {
     if (!rc) rc = dalloc(b, &b->wx, npx);
     if (!rc) rc = dalloc(b, &b->wy, npx);
@@ -347,7 +366,7 @@ void ofdis_batch_destroy(ofdis_batch* b) {
 }
 
 float* ofdis_batch_input(ofdis_batch* b, int level, int kind) {
-  if (!b || level < b->p.sc_l || level > b->p.sc_f || kind < 0 || kind > 3) return nullptr;
+  if (!b || level < b->p.sc_l || level > b->p.sc_f || kind < 0 || kind > (b->p.usefbcon ? 5 : 3)) return nullptr;
   return b->in[kind][level - b->p.sc_l];
 }
 size_t ofdis_batch_input_elems(const ofdis_batch* b, int level) {
@@ -367,6 +386,22 @@ int ofdis_batch_upload(ofdis_batch* b, int frame, const float* const* im_a, cons
       if (!src[k][l]) return fail(OFDIS_ERR_INVALID, "pyramid level pointer is NULL");
       HIPCHK(hipMemcpyAsync(b->in[k][l - b->p.sc_l] + (size_t)frame * n, src[k][l], n * sizeof(float),
                             hipMemcpyHostToDevice, s));
+    }
+  }
+  return OFDIS_OK;
+}
+
+int ofdis_batch_upload_b_gradients(ofdis_batch* b, int frame, const float* const* im_b_dx, const float* const* im_b_dy,
+                                   void* stream) {
+  if (!b || frame < 0 || frame >= b->nframes || !im_b_dx || !im_b_dy) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  if (!b->p.usefbcon) return OFDIS_OK;  // never read (patch.cpp:90-97)
+  const float* const* src[2] = {im_b_dx, im_b_dy};
+  for (int l = b->p.sc_l; l <= b->p.sc_f; ++l) {
+    const size_t n = b->g(l).plane_elems;
+    for (int k = 0; k < 2; ++k) {
+      if (!src[k][l]) return fail(OFDIS_ERR_INVALID, "pyramid level pointer is NULL");
+      HIPCHK(hipMemcpyAsync(b->in[4 + k][l - b->p.sc_l] + (size_t)frame * n, src[k][l], n * sizeof(float),
+                            hipMemcpyHostToDevice, (hipStream_t)stream));
     }
   }
   return OFDIS_OK;
@@ -402,7 +437,8 @@ int ofdis_batch_build_pyramids_u8(ofdis_batch* b, const uint8_t* img_a, const ui
       if (which == 0)
         HIPCHK(launch_pyr_planes(b->pyr_tmp[i], b->in[0][i], b->in[1][i], b->in[2][i], b->nframes, g.w, g.h, p.noc, g.pad, s));
       else
-        HIPCHK(launch_pyr_planes(b->pyr_tmp[i], b->in[3][i], nullptr, nullptr, b->nframes, g.w, g.h, p.noc, g.pad, s));
+        HIPCHK(launch_pyr_planes(b->pyr_tmp[i], b->in[3][i], b->in[4][i], b->in[5][i], b->nframes, g.w, g.h, p.noc, g.pad,
+                                 s));  // B's gradients only exist (non-null) with usefbcon
     }
   }
   return OFDIS_OK;
@@ -428,6 +464,8 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
     if (verbose > 1) { (void)hipStreamSynchronize(s); t0 = now_ms(); }
     // steps 1-3: patch grid construction, initialisation from the coarser flow and the inverse
     // search run as ONE kernel (pconst/pinit are reported as 0, poptim carries the time)
+    const bool fb = p.usefbcon != 0;
+    const bool bw_flow = fb && sl > p.sc_l;  // the backward flow is not needed at the last scale (oflow.cpp:269,291)
     {
       KTimer kt(b, OFDIS_K_PATCH, s);
       DisArgs a = dis_args(p, g, b->nframes);
@@ -439,22 +477,38 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
       a.p_out = b->pvec;
       a.pweight = b->pweight;
       HIPCHK(launch_patch_optimize(a, s));
+      if (fb) {  // the backward grid: images swapped (oflow.cpp:193-197,214-215,234-235)
+        a.im_a = b->in[3][ii];
+        a.im_a_dx = b->in[4][ii];
+        a.im_a_dy = b->in[5][ii];
+        a.im_b = b->in[0][ii];
+        a.flow_prev = (sl < p.sc_f) ? b->flow_bw[ii + 1] : nullptr;
+        a.p_out = b->pvec_bw;
+        a.pweight = b->pweight_bw;
+        HIPCHK(launch_patch_optimize(a, s));
+      }
     }
     if (verbose > 1) { (void)hipStreamSynchronize(s); tt[2] = now_ms() - t0; t0 = now_ms(); }
-    // step 4: densification
-    {
+    // step 4: densification (with usefbcon each direction also merges the other grid's negated flow)
+    for (int dir = 0; dir < (bw_flow ? 2 : 1); ++dir) {
       KTimer kt(b, OFDIS_K_DENSIFY, s);
       DensifyArgs d;
       memset(&d, 0, sizeof(d));
       d.g = g;
       d.nframes = b->nframes;
-      d.p = b->pvec;
-      d.pweight = b->pweight;
-      if (p.usetvref) {
+      d.p = dir ? b->pvec_bw : b->pvec;
+      d.pweight = dir ? b->pweight_bw : b->pweight;
+      if (fb) {
+        d.cg_p = dir ? b->pvec : b->pvec_bw;
+        d.cg_pweight = dir ? b->pweight : b->pweight_bw;
+      }
+      if (p.usetvref && dir == 0) {
         if (use_fused(b, g)) { d.wx_diag = b->wx_d; d.wy_diag = b->wy_d; }  // diag only
         else { d.wx = b->wx; d.wy = b->wy; }
+      } else if (p.usetvref) {  // backward flow: parked as AoS until the forward refinement has used the planes
+        d.flow_aos = b->flow_bw[ii];
       } else {
-        d.flow_aos = b->flow[ii];
+        d.flow_aos = dir ? b->flow_bw[ii] : b->flow[ii];
       }
       HIPCHK(launch_densify(d, s));
     }
@@ -463,6 +517,10 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
     if (p.usetvref) {
       int rc = run_varref(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s);
       if (rc) return rc;
+      if (bw_flow) {  // VarRefClass on the swapped pair (oflow.cpp:291-294)
+        rc = run_varref_from_aos(b, g, b->in[3][ii], b->in[0][ii], b->flow_bw[ii], s);
+        if (rc) return rc;
+      }
     }
     if (verbose > 1) {
       (void)hipStreamSynchronize(s);
@@ -559,12 +617,14 @@ int ofdis_batch_kernel_time(ofdis_batch* b, int k, double* ms_sum, long* launche
 int ofdis_flow(const ofdis_params* p, const float* const* im_a, const float* const* im_a_dx,
                const float* const* im_a_dy, const float* const* im_b, const float* const* im_b_dx,
                const float* const* im_b_dy, float* outflow, const float* initflow) {
-  (void)im_b_dx; (void)im_b_dy;  // never read when usefbcon == 0
   if (!outflow) return fail(OFDIS_ERR_INVALID, "outflow is NULL");
+  if (p && p->usefbcon && (!im_b_dx || !im_b_dy))  // otherwise never read
+    return fail(OFDIS_ERR_INVALID, "usefbcon needs the gradient pyramids of the second image");
   ofdis_batch* b = nullptr;
   int rc = ofdis_batch_create(&b, p, 1);
   if (rc) return rc;
   rc = ofdis_batch_upload(b, 0, im_a, im_a_dx, im_a_dy, im_b, nullptr);
+  if (!rc && p->usefbcon) rc = ofdis_batch_upload_b_gradients(b, 0, im_b_dx, im_b_dy, nullptr);
   if (!rc && initflow) rc = ofdis_batch_upload_initflow(b, 0, initflow, nullptr);
   if (!rc) rc = ofdis_batch_run(b, nullptr);
   if (!rc) rc = ofdis_batch_download(b, 0, outflow, nullptr);

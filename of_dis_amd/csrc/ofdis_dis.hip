@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     // div_rn == IEEE division except (by < 2 ulp) for numerators below 2^-102, where neither ratio can be within
     // 2 ulp of its threshold
     if (go && cnt >= a.min_iter)
-      go = (div_rn(dpsq, dpsq_init) >= a.dp_thresh_sq) & (div_rn(mares, mares_old) <= a.dr_thresh);
+      go = (div_rn(dpsq, dpsq_init) >= a.dp_thresh_sq) && (div_rn(mares, mares_old) <= a.dr_thresh);
     if (!go) converged = true;
   };
   auto oob = [&](float x, float y) { return (x < g.lb) | (y < g.lb) | (x > g.ubw) | (y > g.ubh); };
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
     // div_rn == IEEE division except (by < 2 ulp) for numerators below 2^-102, where neither ratio can be within
     // 2 ulp of its threshold
     if (go && cnt >= a.min_iter)
-      go = (div_rn(dpsq, dpsq_init) >= a.dp_thresh_sq) & (div_rn(mares, mares_old) <= a.dr_thresh);
+      go = (div_rn(dpsq, dpsq_init) >= a.dp_thresh_sq) && (div_rn(mares, mares_old) <= a.dr_thresh);
     if (!go | stop) {
       converged = true;
       if (live) {
@@ -592,6 +592,17 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
 // then flow /= we where we > 0 (patchgrid.cpp:221-271, 377-397).  A pixel is covered by at most
 // ceil(P/steps)^2 patches; visiting them with gx ascending then gy ascending reproduces the
 // reference's ip order, so the sums are bit-identical without atomics.
+// Forward-backward merging (usefbcon = 1, patchgrid.cpp:277-375): after the grid's own patches, every patch of the
+// COMPLEMENTARY grid (ascending index) splats its negated displacement around its final position with bilinear
+// weights: patch pixel (xt,yt) adds w0 to pixel (xt,yt), w1 to (xt-1,yt), w2 to (xt,yt-1), w3 to (xt-1,yt-1).
+// As a gather, pixel t therefore receives from one patch, in the reference's order, w0 from source t, w1 from t+(1,0),
+// w2 from t+(0,1), w3 from t+(1,1).  The block first compacts -- preserving the index order -- the patches whose
+// footprint reaches its rows into LDS (256 candidates per round), then every pixel walks that list.
+struct FbCand {
+  int ip, pos0, pos1;
+  float w0, w1, w2, w3, p0, p1;
+};
+
 template <bool PLANAR>
 __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
   const LevelGeom& g = a.g;
@@ -600,21 +611,25 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
   int frame, blk;
   xcd_frame_map(blockIdx.x, blocks_per_frame, frame, blk);  // a frame's blocks share one XCD's L2
   if (frame >= a.nframes) return;
-  {
-    const int i = blk * 256 + threadIdx.x;
-    if (i >= npx) return;
-    const long long idx = (long long)frame * npx + i;
-    int y, x;
-    if (PLANAR && a.wx == nullptr) {  // diag-only output: enumerate pixels in diag order (coalesced stores)
-      const int d = i / g.h;
-      y = i - d * g.h;
-      x = d - y;
-      if (x < 0) x += g.w * ((-x + g.w - 1) / g.w);
-    } else {
-      y = i / g.w;
-      x = i - y * g.w;
-    }
-    const int P = g.P, lb = -P / 2, ub = P / 2 - 1, st = g.steps, noc = g.noc;
+  const bool fb = a.cg_p != nullptr;
+  const bool diag_enum = PLANAR && a.wx == nullptr && !fb;  // diag-only output: enumerate pixels in diag order
+  const int i = blk * 256 + threadIdx.x;
+  const bool active = i < npx;
+  if (!active && !fb) return;
+  const long long idx = (long long)frame * npx + i;
+  int y, x;
+  if (diag_enum) {  // coalesced stores
+    const int d = i / g.h;
+    y = i - d * g.h;
+    x = d - y;
+    if (x < 0) x += g.w * ((-x + g.w - 1) / g.w);
+  } else {
+    y = i / g.w;
+    x = i - y * g.w;
+  }
+  const int P = g.P, lb = -P / 2, ub = P / 2 - 1, st = g.steps, noc = g.noc;
+  float we = 0.0f, fu = 0.0f, fv = 0.0f;
+  if (active) {
     // rx + lb <= x <= rx + ub, rx = gx*st + offw
     int gx_lo = (x - ub - g.offw + st - 1);
     gx_lo = gx_lo < 0 ? 0 : gx_lo / st;
@@ -628,7 +643,6 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
     if (gy_hi > g.noph - 1) gy_hi = g.noph - 1;
     const float* pf = a.p + (size_t)frame * g.nop * 2;
     const float* pwf = a.pweight + (size_t)frame * g.nop * g.novals;
-    float we = 0.0f, fu = 0.0f, fv = 0.0f;
     for (int gx = gx_lo; gx <= gx_hi; ++gx)
       for (int gy = gy_lo; gy <= gy_hi; ++gy) {
         const int ip = gx * g.noph + gy;
@@ -660,26 +674,100 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
         fu += pf[2 * ip] * absw;
         fv += pf[2 * ip + 1] * absw;
       }
-    if (we > 0) {
-      fu /= we;
-      fv /= we;
-    }
-    if (PLANAR) {
-      if (a.wx) {
-        a.wx[idx] = fu;
-        a.wy[idx] = fv;
-        if (a.wx_diag) {
-          const size_t dg = (size_t)frame * npx + diag_index(x, y, g.w, g.h);
-          a.wx_diag[dg] = fu;
-          a.wy_diag[dg] = fv;
-        }
-      } else {  // idx IS the diag-linear index
-        a.wx_diag[idx] = fu;
-        a.wy_diag[idx] = fv;
+  }
+  if (fb) {  // block-uniform
+    __shared__ FbCand cand[256];
+    __shared__ int wave_cnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i1 = min(npx, blk * 256 + 256) - 1;
+    const int yb0 = (blk * 256) / g.w, yb1 = i1 / g.w;  // rows this block's pixels lie in
+    const float* cpf = a.cg_p + (size_t)frame * g.nop * 2;
+    const float* cpwf = a.cg_pweight + (size_t)frame * g.nop * g.novals;
+    for (int base = 0; base < g.nop; base += 256) {
+      const int ipc = base + threadIdx.x;
+      FbCand c;
+      bool hit = false;
+      if (ipc < g.nop) {
+        const int gx = ipc / g.noph, gy = ipc - gx * g.noph;
+        c.ip = ipc;
+        c.p0 = cpf[2 * ipc];
+        c.p1 = cpf[2 * ipc + 1];
+        // GetPointPos(): pt_iter = pt_ref + p_iter (patch.cpp:214-221)
+        const float rp0 = (float)(gx * st + g.offw) + c.p0, rp1 = (float)(gy * st + g.offh) + c.p1;
+        c.pos0 = (int)ceil((double)rp0 + .00001);  // the reference adds a DOUBLE here (patchgrid.cpp:304-305)
+        c.pos1 = (int)ceil((double)rp1 + .00001);
+        const float r0 = rp0 - (float)(int)floorf(rp0), r1 = rp1 - (float)(int)floorf(rp1);
+        c.w0 = r0 * r1;
+        c.w1 = (1 - r0) * r1;
+        c.w2 = r0 * (1 - r1);
+        c.w3 = (1 - r0) * (1 - r1);
+        // source rows ys = pos1 + lb .. pos1 + ub feed target rows ys - 1 and ys
+        hit = (c.pos1 + ub >= yb0) && (c.pos1 + lb - 1 <= yb1);
       }
-    } else {
-      reinterpret_cast<float2*>(a.flow_aos)[idx] = make_float2(fu, fv);
+      const unsigned long long bal = __ballot(hit);
+      const int before = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_cnt[wave] = __popcll(bal);
+      __syncthreads();
+      int off = 0, n = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < wave) off += wave_cnt[q];
+        n += wave_cnt[q];
+      }
+      if (hit) cand[off + before] = c;
+      __syncthreads();
+      if (active) {
+        for (int k = 0; k < n; ++k) {
+          const FbCand& cc = cand[k];
+          // valid source rectangle of this patch in patch coordinates (condition patchgrid.cpp:321)
+          const int L = max(0, 1 - (cc.pos0 + lb)), Rr = min(P - 1, g.w - 2 - (cc.pos0 + lb));
+          const int T = max(0, 1 - (cc.pos1 + lb)), Bt = min(P - 1, g.h - 2 - (cc.pos1 + lb));
+          const int in_row = Rr - L + 1;
+          const float* pwp = cpwf + (size_t)cc.ip * g.novals;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int kx = x + (q & 1) - cc.pos0 - lb, ky = y + (q >> 1) - cc.pos1 - lb;
+            if (kx < L || kx > Rr || ky < T || ky > Bt) continue;
+            const float wq = q == 0 ? cc.w0 : (q == 1 ? cc.w1 : (q == 2 ? cc.w2 : cc.w3));
+            float absw;
+            if (noc == 1) {
+              absw = 1.0f / fmaxf(2.0f, pwp[ky * P + kx]);
+            } else {  // running pointer: +1 per visited pixel, +2 more per pixel that passed the condition
+              const float* pw = pwp + ky * P + kx + 2 * ((ky - T) * in_row + (kx - L));
+              absw = fmaxf(2.0f, pw[0]);
+              absw += fmaxf(2.0f, pw[1]);
+              absw += fmaxf(2.0f, pw[2]);
+              absw = 1.0f / absw;
+            }
+            we += wq * absw;
+            fu -= wq * (cc.p0 * absw);  // reversed flow
+            fv -= wq * (cc.p1 * absw);
+          }
+        }
+      }
+      __syncthreads();
     }
+    if (!active) return;
+  }
+  if (we > 0) {
+    fu /= we;
+    fv /= we;
+  }
+  if (PLANAR) {
+    const size_t dg = (size_t)frame * npx + diag_index(x, y, g.w, g.h);
+    if (a.wx) {
+      a.wx[idx] = fu;
+      a.wy[idx] = fv;
+    }
+    if (diag_enum) {  // idx IS the diag-linear index
+      a.wx_diag[idx] = fu;
+      a.wy_diag[idx] = fv;
+    } else if (a.wx_diag) {
+      a.wx_diag[dg] = fu;
+      a.wy_diag[dg] = fv;
+    }
+  } else {
+    reinterpret_cast<float2*>(a.flow_aos)[idx] = make_float2(fu, fv);
   }
 }
 

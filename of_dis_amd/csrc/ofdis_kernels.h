@@ -37,6 +37,9 @@ struct DensifyArgs {
   float* wy;
   float* wx_diag;        // optional second copy in the solver's diag layout (fused TV path)
   float* wy_diag;
+  // forward-backward merging (usefbcon, patchgrid.cpp:277-375): the complementary grid's results, or null
+  const float* cg_p;        // [B][nop][2]
+  const float* cg_pweight;  // [B][nop][novals]
 };
 // PatGridClass::AggregateFlowDense as an order-preserving gather
 hipError_t launch_densify(const DensifyArgs& a, hipStream_t s);

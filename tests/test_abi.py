@@ -93,7 +93,7 @@ def test_status_codes_without_a_gpu():
     L = capi.lib()
     h = C.c_void_p()
     p = oppoint(2, 1024, 436)
-    for bad, code in ((p.copy(usefbcon=1), -2), (p.copy(width=1000), -1), (p.copy(imgpadding=4), -1),
+    for bad, code in ((p.copy(width=1000), -1), (p.copy(imgpadding=4), -1),
                       (p.copy(noc=2), -1), (p.copy(sc_l=6), -1), (p.copy(costfct=10), -2)):
         rc = L.ofdis_batch_create(C.byref(h), C.byref(bad), 4)
         assert rc == code, (bad.as_dict(), rc, L.ofdis_last_error())

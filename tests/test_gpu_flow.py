@@ -105,6 +105,44 @@ def test_initflow_warm_start(gpu, orc):
     b.close()
 
 
+FB_CASES = [
+    pytest.param((1024, 436), 1, 2, 1, id="gray-op2-tv"),
+    pytest.param((640, 480), 1, 2, 0, id="gray-op2-notv"),
+    pytest.param((333, 251), 1, 1, 1, id="gray-op1-odd-size"),
+    pytest.param((320, 240), 3, 3, 1, id="rgb-op3-tv"),
+]
+
+
+@pytest.mark.parametrize("size,noc,opp,tv", FB_CASES)
+def test_forward_backward_consistency(gpu, orc, size, noc, opp, tv):
+    """usefbcon = 1 (oflow.cpp:162-170,193-197,214-215,234-235,269-270,291-294; patchgrid.cpp:277-375): a second grid
+    on the swapped pair, each dense flow merged with the other grid's negated, bilinearly splatted displacements.
+    The checker is the reference itself (oracle/_ref, built from the unmodified sources with the defined summation
+    order); the C restatement does not cover this mode."""
+    kind = "int" if noc == 1 else "rgb"
+    if not oracle.have_ref(kind, True):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    p, pa, pb, _, _ = synth_case(size[0], size[1], 2024, noc, opp, tv)
+    p = p.copy(usefbcon=1)
+    R = oracle.ref(kind, True)
+    ref = R.flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
+    plain = R.flow(p.copy(usefbcon=0), pa[0], pa[1], pa[2], pb[0])
+    assert not np.array_equal(ref, plain)
+    got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
+    assert_bits_equal(got, ref, "usefbcon=1 vs reference sources")
+    # batch interface, two frames with swapped roles
+    b = gpu.Batch(p, 2)
+    b.upload(0, pa[0], pa[1], pa[2], pb[0])
+    b.upload_b_gradients(0, pb[1], pb[2])
+    b.upload(1, pb[0], pb[1], pb[2], pa[0])
+    b.upload_b_gradients(1, pa[1], pa[2])
+    b.run()
+    out = b.download_all()
+    b.close()
+    assert_bits_equal(out[0], ref, "batch frame 0")
+    assert_bits_equal(out[1], R.flow(p, pb[0], pb[1], pb[2], pa[0], pyr_b_dx=pa[1], pyr_b_dy=pa[2]), "batch frame 1 (B -> A)")
+
+
 def test_batch_level_flows(gpu, orc):
     p, pa, pb, _, _ = synth_case(1024, 436, 1240, 1, 2, 1)
     _, levels = orc.flow(p, pa[0], pa[1], pa[2], pb[0], want_levels=True)
@@ -122,9 +160,6 @@ def test_batch_level_flows(gpu, orc):
 def test_error_behaviour(gpu):
     from of_dis_amd.params import oppoint
     p = oppoint(2, 1024, 436)
-    bad = p.copy(usefbcon=1)
-    with pytest.raises(gpu.OfdisError):
-        gpu.Batch(bad, 1)
     bad = p.copy(width=1000)
     with pytest.raises(gpu.OfdisError):
         gpu.Batch(bad, 1)
