@@ -92,3 +92,24 @@ def test_run_of_rgb_and_png(gpu, tmp_path):
     r = subprocess.run([EXE[3], pa, pb, fo2] + args, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert_bits_equal(read_flo(fo2), ref, "PNG input == PPM input")
+
+
+@pytest.mark.gpu
+def test_run_of_int_forward_backward(gpu, tmp_path):
+    """CLI parameter 10 (usefbcon, README.md:64): the binary builds the second image's gradient pyramid as well and the
+    result equals the reference core run on the oracle's pyramids, upsampled by the oracle."""
+    if not oracle.have_ref("int", True):
+        pytest.skip("oracle/_ref not built")
+    w, h = 640, 480
+    ia, ib, _ = gen_synth.make_pair(w, h, 33)
+    fa, fb, fo = str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm"), str(tmp_path / "o.flo")
+    gen_synth.write_pgm(fa, ia)
+    gen_synth.write_pgm(fb, ib)
+    args = "5 3 12 12 0.05 0.95 0 8 0.40 1 1 0 1 10 10 5 1 3 1.6 0".split()
+    r = subprocess.run([EXE[1], fa, fb, fo] + args, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    p = oppoint(2, w, h).copy(usefbcon=1, sc_f=5, sc_l=3)
+    O = oracle.c_oracle()
+    pa, pb = O.build_pyramid(p, ia), O.build_pyramid(p, ib)
+    core = oracle.ref("int", True).flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
+    assert_bits_equal(read_flo(fo), O.upsample_crop(p, core, w, h), "usefbcon .flo vs reference core + oracle pipeline")
