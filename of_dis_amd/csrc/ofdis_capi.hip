@@ -51,6 +51,7 @@ LevelGeom make_geom(const ofdis_params& p, int sl) {
   g.tmp_h = g.h + 2 * g.pad;
   int steps = (int)floor(p.p_samp_s * (1 - p.patove));
   g.steps = steps < 1 ? 1 : steps;
+  g.steps_magic = g.steps > 1 ? (unsigned)((0x100000000ull + (unsigned)g.steps - 1) / (unsigned)g.steps) : 0u;
   g.novals = p.noc * p.p_samp_s * p.p_samp_s;
   g.nopw = (int)ceil((float)g.w / (float)g.steps);
   g.noph = (int)ceil((float)g.h / (float)g.steps);
@@ -67,6 +68,8 @@ int check_params(const ofdis_params* p) {
   if (p->sc_l < 0 || p->sc_f < p->sc_l || p->sc_f > 20) return fail(OFDIS_ERR_INVALID, "need 0 <= sc_l <= sc_f");
   if (p->width <= 0 || p->height <= 0 || (p->width % (1 << p->sc_f)) || (p->height % (1 << p->sc_f)))
     return fail(OFDIS_ERR_INVALID, "width/height must be positive multiples of 2^sc_f (oflow.h:87)");
+  if ((p->width >> p->sc_l) > 32768 || (p->height >> p->sc_l) > 32768)
+    return fail(OFDIS_ERR_UNSUPPORTED, "finest level larger than 32768 pixels in one dimension");
   if (p->p_samp_s < 2 || (p->p_samp_s & 1)) return fail(OFDIS_ERR_INVALID, "p_samp_s must be even and >= 2");
   if (p->imgpadding < p->p_samp_s) return fail(OFDIS_ERR_INVALID, "imgpadding must be >= p_samp_s (oflow.cpp:147-149)");
   if (p->noc * p->p_samp_s * p->p_samp_s > 64 * 12) return fail(OFDIS_ERR_UNSUPPORTED, "patch too large (novals > 768)");
@@ -186,8 +189,9 @@ bool use_fused(const ofdis_batch* b, const LevelGeom& g) {
          tv_fused_params_ok(c.quarter_alpha, c.half_delta_over3, c.half_gamma_over3);
 }
 
+// `dfuse` (fused-TV levels only): the level's densification has not run yet and is done inside the warp kernel.
 int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow_out,
-               hipStream_t s) {
+               hipStream_t s, const DensifyArgs* dfuse = nullptr) {
   const ofdis_params& p = b->p;
   TvGeom t{g.w, g.h, g.noc, b->nframes};
   const size_t npx = (size_t)g.w * g.h;
@@ -196,9 +200,10 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
   const bool fused = use_fused(b, g);
   {
     KTimer kt(b, OFDIS_K_WARP, s);
-    if (fused) {  // wx_d, wy_d in, mask_d out (diag); the warped image stays row-major
+    if (fused) {  // wx_d, wy_d in (or produced here), mask_d out (diag); the warped image stays row-major
       WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx_d, b->wy_d, b->w_im2, b->mask_d};
-      HIPCHK(launch_warp_diag(wa, s));
+      if (dfuse) HIPCHK(launch_densify_warp_diag(*dfuse, wa, s));
+      else HIPCHK(launch_warp_diag(wa, s));
     } else {
       WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx, b->wy, b->w_im2, b->mask};
       HIPCHK(launch_warp(wa, s));
@@ -489,9 +494,12 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
       }
     }
     if (verbose > 1) { (void)hipStreamSynchronize(s); tt[2] = now_ms() - t0; t0 = now_ms(); }
-    // step 4: densification (with usefbcon each direction also merges the other grid's negated flow)
+    // step 4: densification (with usefbcon each direction also merges the other grid's negated flow).  On the
+    // fused-TV levels the forward densification is part of the warp kernel of step 5.
+    const bool densify_in_warp = p.usetvref && !fb && use_fused(b, g) && !getenv("OFDIS_NO_DENSIFY_WARP");
+    DensifyArgs dfw;
+    memset(&dfw, 0, sizeof(dfw));
     for (int dir = 0; dir < (bw_flow ? 2 : 1); ++dir) {
-      KTimer kt(b, OFDIS_K_DENSIFY, s);
       DensifyArgs d;
       memset(&d, 0, sizeof(d));
       d.g = g;
@@ -510,12 +518,17 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
       } else {
         d.flow_aos = dir ? b->flow_bw[ii] : b->flow[ii];
       }
+      if (dir == 0 && densify_in_warp) {
+        dfw = d;
+        continue;
+      }
+      KTimer kt(b, OFDIS_K_DENSIFY, s);
       HIPCHK(launch_densify(d, s));
     }
     if (verbose > 1) { (void)hipStreamSynchronize(s); tt[3] = now_ms() - t0; t0 = now_ms(); }
     // step 5: variational refinement
     if (p.usetvref) {
-      int rc = run_varref(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s);
+      int rc = run_varref(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s, densify_in_warp ? &dfw : nullptr);
       if (rc) return rc;
       if (bw_flow) {  // VarRefClass on the swapped pair (oflow.cpp:291-294)
         rc = run_varref_from_aos(b, g, b->in[3][ii], b->in[0][ii], b->flow_bw[ii], s);

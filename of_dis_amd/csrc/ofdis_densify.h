@@ -1,0 +1,65 @@
+// ofdis_densify.h -- the per-pixel gather of PatGridClass::AggregateFlowDense (patchgrid.cpp:213-275), shared by
+// densify_kernel (ofdis_dis.hip) and the fused densify + warp kernel (ofdis_tv.hip).
+#pragma once
+#include "ofdis_dev.h"
+
+namespace ofdis {
+
+// Reference: for ip ascending, for every pixel of the patch inside the image:
+//   absw = 1/max(2,|r|)  (RGB: 1/sum_c max(2,|r_c|));  we += absw;  flow += p*absw;
+// A pixel is covered by at most ceil(P/steps)^2 patches; visiting them with gx ascending then gy ascending
+// reproduces the reference's ip order, so the sums are bit-identical without atomics.
+// pf = this frame's [nop][2] displacements, pwf = its [nop][novals] weights; accumulates into we, fu, fv.
+__device__ __forceinline__ void densify_accumulate(const LevelGeom& g, const float* __restrict__ pf,
+                                                   const float* __restrict__ pwf, int x, int y, float& we, float& fu,
+                                                   float& fv) {
+  const int P = g.P, lb = -P / 2, ub = P / 2 - 1, st = g.steps, noc = g.noc;
+  // rx + lb <= x <= rx + ub, rx = gx*st + offw
+  // floor(n / steps) for 0 <= n < 65536 as a multiply-high with ceil(2^32 / steps): exact because the rounding
+  // excess n * (magic * steps - 2^32) stays below 2^32 / steps for these n (steps <= P <= 27)
+  const unsigned magic = g.steps_magic;
+  auto div_st = [&](int n) { return magic ? (int)__umulhi((unsigned)n, magic) : n; };
+  int gx_lo = (x - ub - g.offw + st - 1);
+  gx_lo = gx_lo < 0 ? 0 : div_st(gx_lo);
+  int gx_hi = x - lb - g.offw;
+  gx_hi = gx_hi < 0 ? -1 : div_st(gx_hi);
+  if (gx_hi > g.nopw - 1) gx_hi = g.nopw - 1;
+  int gy_lo = (y - ub - g.offh + st - 1);
+  gy_lo = gy_lo < 0 ? 0 : div_st(gy_lo);
+  int gy_hi = y - lb - g.offh;
+  gy_hi = gy_hi < 0 ? -1 : div_st(gy_hi);
+  if (gy_hi > g.noph - 1) gy_hi = g.noph - 1;
+  for (int gx = gx_lo; gx <= gx_hi; ++gx)
+    for (int gy = gy_lo; gy <= gy_hi; ++gy) {
+      const int ip = gx * g.noph + gy;
+      const int rxi = gx * st + g.offw, ryi = gy * st + g.offh;
+      const int kx = x - rxi - lb, ky = y - ryi - lb;
+      // The reference walks pweight with a RUNNING pointer: +1 per visited patch pixel and, for RGB,
+      // +2 more only for pixels inside the image (patchgrid.cpp:242,256-257), so for RGB patches that
+      // overlap the border the entries are shifted.  Closed form of that pointer for pixel (kx,ky):
+      int pidx;
+      if (noc == 1) {
+        pidx = ky * P + kx;
+      } else {
+        const int left_out = max(0, -(rxi + lb)), right_out = max(0, rxi + ub - (g.w - 1));
+        const int top_out = max(0, -(ryi + lb));
+        const int in_row = P - left_out - right_out;
+        pidx = top_out * P + (ky - top_out) * (3 * in_row + (P - in_row)) + left_out + (kx - left_out) * 3;
+      }
+      const float* pw = pwf + (size_t)ip * g.novals + pidx;
+      float absw;
+      if (noc == 1) {
+        absw = div_rn(1.0f, fmaxf(2.0f, pw[0]));  // == 1.0f / x: numerator 1, denominator >= 2 (ofdis_dev.h)
+      } else {
+        absw = fmaxf(2.0f, pw[0]);
+        absw += fmaxf(2.0f, pw[1]);
+        absw += fmaxf(2.0f, pw[2]);
+        absw = div_rn(1.0f, absw);
+      }
+      we += absw;
+      fu += pf[2 * ip] * absw;
+      fv += pf[2 * ip + 1] * absw;
+    }
+}
+
+}  // namespace ofdis

@@ -22,6 +22,7 @@ struct LevelGeom {
   float lb, ubw, ubh;  // valid patch-centre range (tmp_lb, tmp_ubw, tmp_ubh)
   // patch grid
   int P, steps, nopw, noph, nop, offw, offh, novals;
+  unsigned steps_magic;  // ceil(2^32 / steps) for steps > 1 (0 for steps == 1): n / steps == umulhi(n, magic), 0 <= n < 65536
   size_t plane_elems;  // tmp_w*tmp_h*noc
 };
 

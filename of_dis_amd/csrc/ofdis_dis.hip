@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "ofdis_kernels.h"
+#include "ofdis_densify.h"
 
 namespace ofdis {
 
@@ -629,52 +630,8 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
   }
   const int P = g.P, lb = -P / 2, ub = P / 2 - 1, st = g.steps, noc = g.noc;
   float we = 0.0f, fu = 0.0f, fv = 0.0f;
-  if (active) {
-    // rx + lb <= x <= rx + ub, rx = gx*st + offw
-    int gx_lo = (x - ub - g.offw + st - 1);
-    gx_lo = gx_lo < 0 ? 0 : gx_lo / st;
-    int gx_hi = x - lb - g.offw;
-    gx_hi = gx_hi < 0 ? -1 : gx_hi / st;
-    if (gx_hi > g.nopw - 1) gx_hi = g.nopw - 1;
-    int gy_lo = (y - ub - g.offh + st - 1);
-    gy_lo = gy_lo < 0 ? 0 : gy_lo / st;
-    int gy_hi = y - lb - g.offh;
-    gy_hi = gy_hi < 0 ? -1 : gy_hi / st;
-    if (gy_hi > g.noph - 1) gy_hi = g.noph - 1;
-    const float* pf = a.p + (size_t)frame * g.nop * 2;
-    const float* pwf = a.pweight + (size_t)frame * g.nop * g.novals;
-    for (int gx = gx_lo; gx <= gx_hi; ++gx)
-      for (int gy = gy_lo; gy <= gy_hi; ++gy) {
-        const int ip = gx * g.noph + gy;
-        const int rxi = gx * st + g.offw, ryi = gy * st + g.offh;
-        const int kx = x - rxi - lb, ky = y - ryi - lb;
-        // The reference walks pweight with a RUNNING pointer: +1 per visited patch pixel and, for RGB,
-        // +2 more only for pixels inside the image (patchgrid.cpp:242,256-257), so for RGB patches that
-        // overlap the border the entries are shifted.  Closed form of that pointer for pixel (kx,ky):
-        int pidx;
-        if (noc == 1) {
-          pidx = ky * P + kx;
-        } else {
-          const int left_out = max(0, -(rxi + lb)), right_out = max(0, rxi + ub - (g.w - 1));
-          const int top_out = max(0, -(ryi + lb));
-          const int in_row = P - left_out - right_out;
-          pidx = top_out * P + (ky - top_out) * (3 * in_row + (P - in_row)) + left_out + (kx - left_out) * 3;
-        }
-        const float* pw = pwf + (size_t)ip * g.novals + pidx;
-        float absw;
-        if (noc == 1) {
-          absw = 1.0f / fmaxf(2.0f, pw[0]);
-        } else {
-          absw = fmaxf(2.0f, pw[0]);
-          absw += fmaxf(2.0f, pw[1]);
-          absw += fmaxf(2.0f, pw[2]);
-          absw = 1.0f / absw;
-        }
-        we += absw;
-        fu += pf[2 * ip] * absw;
-        fv += pf[2 * ip + 1] * absw;
-      }
-  }
+  if (active)
+    densify_accumulate(g, a.p + (size_t)frame * g.nop * 2, a.pweight + (size_t)frame * g.nop * g.novals, x, y, we, fu, fv);
   if (fb) {  // block-uniform
     __shared__ FbCand cand[256];
     __shared__ int wave_cnt[4];
@@ -772,6 +729,8 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
 }
 
 hipError_t launch_densify(const DensifyArgs& a, hipStream_t s) {
+  // (A patch-major variant -- one wavefront per 32x32 tile accumulating in LDS, one contiguous 256-byte weight read per
+  // patch -- was measured at twice the time of this gather: ~90 dependent LDS read-modify-write rounds per tile.)
   const int blocks_per_frame = (a.g.w * a.g.h + 255) / 256;
   const long long blocks = (long long)((a.nframes + 7) / 8) * 8 * blocks_per_frame;
   if (a.flow_aos)
