@@ -214,8 +214,10 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
     DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs, fused ? 1 : 0, nullptr, nullptr};
     HIPCHK(launch_derivatives(da, s));
   }
-  HIPCHK(hipMemsetAsync(b->du, 0, npx * b->nframes * sizeof(float), s));  // image_erase :186-187
-  HIPCHK(hipMemsetAsync(b->dv, 0, npx * b->nframes * sizeof(float), s));
+  if (!fused || n_inner <= 0) {  // image_erase :186-187 (the fused kernel treats its first pass as du = dv = 0 itself)
+    HIPCHK(hipMemsetAsync(b->du, 0, npx * b->nframes * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(b->dv, 0, npx * b->nframes * sizeof(float), s));
+  }
   if (fused && n_inner > 0) {  // every fixed-point iteration of this level in one launch
     KTimer kt(b, OFDIS_K_FUSED, s);
     FusedArgs fa{t, b->derivs, b->mask_d, b->wx_d, b->wy_d, b->du, b->dv, c.quarter_alpha, c.half_delta_over3,

@@ -168,6 +168,9 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
   load_w(W[2], wrap(-1));
   load_w(W[3], wrap(0));
   load_w(W[4], wrap(1));
+  // du, dv are zero before the first fixed-point iteration (refine_variational.cpp:186-187): the kernel never reads
+  // them during its first pass over the columns, so the caller does not have to clear them
+  W[2].du = W[2].dv = W[3].du = W[3].dv = W[4].du = W[4].dv = 0.0f;
   int rowW = wrap(2);   // next W row to load (row t+5 at t = -3)
   int rowD = wrap(0);   // next D row to load (row t+3 at t = -3)
   int srow = wrap(-3 - 2 * (NS - 1));  // row finished by the last sweep at step t = -3
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
   const int wtot = a.n_inner * w;  // columns per lane over all iterations
   const int tend = (wtot - 1) + (h - 1) + 2 * (NS - 1);
   int ig = -3 - j - 2 * (NS - 1);  // global column (over all iterations) the last sweep finishes at step t
+  bool first_w = true;             // row t+5 at t = -3 is column 2 - j: first iteration (w >= 16)
   for (int k0 = 0; k0 <= tend + 3; k0 += U) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -184,6 +188,10 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
       // ---- (1) loads: W row t+5, D row t+3
       load_w(W[(u + 5) % 6], rowW);
       rowW = next_row(rowW);
+      if (first_w) {  // this lane's column on row t+5 still belongs to the first iteration: du = dv = 0 (image_erase)
+        W[(u + 5) % 6].du = 0.0f;
+        W[(u + 5) % 6].dv = 0.0f;
+      }
       load_d(D[u % 3], rowD);
       rowD = next_row(rowD);
       // ---- (2) uu, vv of row t+3 (refine_variational.cpp:210-216: uu = wx + du of before this call)
@@ -279,6 +287,7 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
         nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
       }
       {
+        first_w = ig + (6 + 2 * (NS - 1)) < w;  // for the next step's row
         if (row_ok && ig >= 0 && ig < wtot) {
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nu[NS - 1]), rsU, vo1, srow * row_bytes, 0);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nv[NS - 1]), rsV, vo1, srow * row_bytes, 0);
