@@ -117,7 +117,14 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // w x h plane lives at ((x+y) mod w)*h + y, i.e. wrapped anti-diagonal d = (x+y) mod w is ONE
 // contiguous row of h floats (a bijection onto w*h, no padding).  The wavefront SOR reads/writes
 // one such row per step (ofdis_sor.hip).
-__host__ __device__ __forceinline__ int diag_index(int x, int y, int w, int h) { return ((x + y) % w) * h + y; }
+// (0 <= x < w, 0 <= y < h: x + y wraps at most once unless h > w, so the general modulo -- ~35 instructions for a
+// run-time divisor -- is kept off the common path.)
+__host__ __device__ __forceinline__ int diag_index(int x, int y, int w, int h) {
+  int d = x + y;
+  if (d >= w) d -= w;
+  if (d >= w) d %= w;
+  return d * h + y;
+}
 
 // Blocks of one frame stay on one XCD: the dispatcher places block n on XCD n % 8 (observed, used for L2
 // affinity only -- correctness does not depend on it), so block n works on frame (n/8/bpf)*8 + n%8.
