@@ -58,6 +58,10 @@ typedef struct ofdis_params {
   int   tv_innerit, tv_solverit;
   float tv_sor;
   int   verbosity;          /* 0 silent, 1 total time, 2 per-level TIME lines (oflow.cpp:179,303,359) */
+  int   selectmode;         /* the reference's compile-time SELECTMODE: 0 or 1 = optical flow (run_OF_*, two flow
+                             * channels), 2 = stereo depth (run_DE_*: ONE channel = horizontal displacement <= 0,
+                             * patch.cpp:188-193, refine_variational.cpp:245-336).  Every flow array below then has
+                             * one float per pixel instead of two.  usefbcon is not available in mode 2. */
 } ofdis_params;
 
 /* Fill `p` with the reference's operating point 1..4 for an image of `width_org` columns
@@ -135,7 +139,7 @@ const float* ofdis_batch_level_flow(const ofdis_batch* b, int level);
 int ofdis_batch_download(ofdis_batch* b, int frame, float* outflow_host, void* stream);
 /* The step after the path (run_dense.cpp:406-414): values x 2^sc_l, bilinear upsample by 2^sc_l (cv::resize
  * INTER_LINEAR semantics: half-pixel centres, clamped borders) and crop of the 2^sc_f padding, for all frames:
- * out_dev = device [nframes][height_org][width_org][2].  Enqueues on `stream`. */
+ * out_dev = device [nframes][height_org][width_org][2] ([..][1] in stereo-depth mode).  Enqueues on `stream`. */
 int ofdis_batch_upsample(ofdis_batch* b, float* out_dev, int width_org, int height_org, void* stream);
 
 /* Kernel timing for the roofline report: when enabled, ofdis_batch_run brackets every launch of

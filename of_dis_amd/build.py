@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 ROOT = os.path.dirname(HERE)
 
-HIP_SOURCES = ["ofdis_dis.hip", "ofdis_tv.hip", "ofdis_sor.hip", "ofdis_fused.hip", "ofdis_pyr.hip", "ofdis_capi.hip"]
+HIP_SOURCES = ["ofdis_dis.hip", "ofdis_tv.hip", "ofdis_sor.hip", "ofdis_fused.hip", "ofdis_de.hip", "ofdis_pyr.hip", "ofdis_capi.hip"]
 # -ffp-contract=off: every fp32 operation separately rounded, like the reference's SSE path.
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
             "-Wall", "-Wno-unused-function"]
@@ -75,16 +75,17 @@ def build(force=False, verbose=False):
     so = lib_path()
     if force or _newer(so, objs):
         _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs, verbose)
-    # host executables (reference CLI contract: run_OF_INT / run_OF_RGB)
+    # host executables (reference CLI contract: run_OF_INT / run_OF_RGB and the stereo-depth run_DE_INT / run_DE_RGB)
     host_dir = os.path.join(CSRC, "host")
     main_cpp = os.path.join(host_dir, "run_dense_main.cpp")
     if os.path.exists(main_cpp):
         host_srcs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".cpp")]
         host_hdrs = [os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".h")]
-        for name, noc in (("run_OF_INT", 1), ("run_OF_RGB", 3)):
+        for name, noc, mode in (("run_OF_INT", 1, 1), ("run_OF_RGB", 3, 1), ("run_DE_INT", 1, 2), ("run_DE_RGB", 3, 2)):
             exe = os.path.join(LIBDIR, name)
             if force or _newer(exe, host_srcs + host_hdrs + headers + [so]):
-                _run(["g++", "-O2", "-std=c++17", "-Wall", f"-DOFDIS_NOC={noc}", "-I", os.path.join(ROOT, "include")]
+                _run(["g++", "-O2", "-std=c++17", "-Wall", f"-DOFDIS_NOC={noc}", f"-DOFDIS_MODE={mode}", "-I",
+                      os.path.join(ROOT, "include")]
                      + host_srcs + ["-o", exe, "-L", LIBDIR, "-lofdis_hip", "-lz", "-Wl,-rpath,$ORIGIN"], verbose)
     return so
 

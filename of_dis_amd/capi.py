@@ -189,10 +189,10 @@ def patchgrid_level(p, level, im_a, im_a_dx, im_a_dy, im_b, flow_prev=None):
     nop = nw * nh
     bufs = [Dev(x) for x in (im_a, im_a_dx, im_a_dy, im_b)]
     dprev = Dev(_f(flow_prev)) if flow_prev is not None else None
-    dp, dflow = Dev(nbytes=B * nop * 2 * 4), Dev(nbytes=B * h * w * 2 * 4)
+    dp, dflow = Dev(nbytes=B * nop * 2 * 4), Dev(nbytes=B * h * w * p.nop * 4)
     check(lib().ofdis_patchgrid_level(C.byref(p), level, *[b.ptr for b in bufs], dprev.ptr if dprev else None,
                                       dp.ptr, dflow.ptr, B, None))
-    return dp.get((B, nop, 2)), dflow.get((B, h, w, 2))
+    return dp.get((B, nop, 2)), dflow.get((B, h, w, p.nop))
 
 
 def varref_level(p, level, im_a, im_b, flow):
@@ -217,7 +217,7 @@ def flow(p, pyr_a, pyr_a_dx, pyr_a_dy, pyr_b, initflow=None, pyr_b_dx=None, pyr_
     keep = [[_f(x) if x is not None else None for x in pl] for pl in (pyr_a, pyr_a_dx, pyr_a_dy, pyr_b)]
     keep_b = [[_f(x) if x is not None else None for x in pl] for pl in (pyr_b_dx, pyr_b_dy) if pl is not None]
     w, h = p.level_size(p.sc_l)
-    out = np.zeros((h, w, 2), _f32)
+    out = np.zeros((h, w, p.nop), _f32)
     nullarr = C.cast(None, C.POINTER(FP))
     bdx = _ptr_array(keep_b[0], n) if len(keep_b) == 2 else nullarr
     bdy = _ptr_array(keep_b[1], n) if len(keep_b) == 2 else nullarr
@@ -308,7 +308,7 @@ class Batch:
 
     def download(self, frame, stream=None):
         w, h = self.p.level_size(self.p.sc_l)
-        out = np.zeros((h, w, 2), _f32)
+        out = np.zeros((h, w, self.p.nop), _f32)
         check(lib().ofdis_batch_download(self.h, frame, out.ctypes.data_as(FP), stream))
         return out
 
@@ -318,7 +318,7 @@ class Batch:
         if out_ptr is not None:
             check(lib().ofdis_batch_upsample(self.h, out_ptr, width_org, height_org, stream))
             return None
-        out = np.zeros((self.nframes, height_org, width_org, 2), _f32)
+        out = np.zeros((self.nframes, height_org, width_org, self.p.nop), _f32)
         d = Dev(nbytes=out.nbytes)
         check(lib().ofdis_batch_upsample(self.h, d.ptr, width_org, height_org, stream))
         check(lib().ofdis_sync(stream))
@@ -327,14 +327,14 @@ class Batch:
 
     def download_all(self):
         w, h = self.p.level_size(self.p.sc_l)
-        out = np.zeros((self.nframes, h, w, 2), _f32)
+        out = np.zeros((self.nframes, h, w, self.p.nop), _f32)
         check(lib().ofdis_sync(None))
         check(lib().ofdis_memcpy_d2h(out.ctypes.data, self.flow_ptr(), out.nbytes))
         return out
 
     def level_flow(self, level):
         w, h = self.p.level_size(level)
-        out = np.zeros((self.nframes, h, w, 2), _f32)
+        out = np.zeros((self.nframes, h, w, self.p.nop), _f32)
         check(lib().ofdis_sync(None))
         check(lib().ofdis_memcpy_d2h(out.ctypes.data, lib().ofdis_batch_level_flow(self.h, level), out.nbytes))
         return out

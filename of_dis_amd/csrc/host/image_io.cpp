@@ -179,4 +179,20 @@ bool write_flo(const std::string& path, const float* flow_uv, int width, int hei
   return ok;
 }
 
+// SavePFMFile (run_dense.cpp:60-81): "Pf", size, scale -1.000000 (little endian), rows bottom-up, values negated
+bool write_pfm(const std::string& path, const float* disp, int width, int height, std::string* err) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) { *err = "WriteFile: could not open file " + path; return false; }
+  fprintf(f, "Pf\n%d %d\n%f\n", width, height, (float)-1.0f);
+  bool ok = true;
+  for (int y = height - 1; y >= 0 && ok; --y)
+    for (int x = 0; x < width; ++x) {
+      const float t = -disp[(size_t)y * width + x];
+      if (fwrite(&t, sizeof(float), 1, f) != 1) { ok = false; break; }
+    }
+  fclose(f);
+  if (!ok) *err = "WriteFile: problem writing data to " + path;
+  return ok;
+}
+
 }  // namespace ofdis_host

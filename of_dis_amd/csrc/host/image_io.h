@@ -21,5 +21,7 @@ bool read_image(const std::string& path, int want_channels, Image8* out, std::st
 
 // SaveFlowFile (run_dense.cpp:16-57): "PIEH", int32 width, int32 height, then rows of (float u, float v).
 bool write_flo(const std::string& path, const float* flow_uv, int width, int height, std::string* err);
+// stereo-depth result (run_dense.cpp:60-81): one channel, PFM
+bool write_pfm(const std::string& path, const float* disp, int width, int height, std::string* err);
 
 }  // namespace ofdis_host

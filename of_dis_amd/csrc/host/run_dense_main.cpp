@@ -5,6 +5,7 @@
 //   run_OF_INT img1 img2 out.flo                      operating point 2
 //   run_OF_INT img1 img2 out.flo X                    operating point X in 1..4
 //   run_OF_INT img1 img2 out.flo p1 .. p20            the 20 explicit parameters
+// With -DOFDIS_MODE=2: run_DE_INT / run_DE_RGB, the stereo-depth binaries (one displacement channel, .pfm output).
 //
 // Pipeline: read 8-bit images -> upload -> on-device padding, pyramid, Sobel (ofdis_batch_build_pyramids_u8)
 // -> hot path (ofdis_batch_run) -> x2^lv_l, bilinear upsample, crop on the device (ofdis_batch_upsample) -> download
@@ -25,6 +26,10 @@
 #ifndef OFDIS_NOC
 #define OFDIS_NOC 1
 #endif
+#ifndef OFDIS_MODE  // the reference's SELECTMODE: 1 optical flow (run_OF_*, .flo), 2 stereo depth (run_DE_*, .pfm)
+#define OFDIS_MODE 1
+#endif
+#define OFDIS_NCH (OFDIS_MODE == 2 ? 1 : 2)
 
 static double now_ms() {
   struct timeval tv;
@@ -80,6 +85,7 @@ int main(int argc, char** argv) {
     p.verbosity = atoi(argv[k++]);
     p.imgpadding = p.p_samp_s;
   }
+  p.selectmode = OFDIS_MODE;
   // *** pad to a multiple of 2^lv_f (run_dense.cpp:298-311)
   const int scfct = 1 << p.sc_f;
   p.width = width_org + (scfct - width_org % scfct) % scfct;
@@ -111,7 +117,7 @@ int main(int argc, char** argv) {
   rc = ofdis_batch_run(b, nullptr);
   // x 2^lv_l, bilinear upsample, crop (run_dense.cpp:406-414) on the device, then one download
   t0 = now_ms();
-  std::vector<float> full((size_t)2 * width_org * height_org);
+  std::vector<float> full((size_t)OFDIS_NCH * width_org * height_org);
   void* dfull = ofdis_dev_alloc(full.size() * sizeof(float));
   if (!rc && !dfull) rc = OFDIS_ERR_NOMEM;
   if (!rc) rc = ofdis_batch_upsample(b, (float*)dfull, width_org, height_org, nullptr);
@@ -122,7 +128,11 @@ int main(int argc, char** argv) {
     return 1;
   }
   ofdis_dev_free(dfull);
+#if OFDIS_MODE == 2
+  if (!ofdis_host::write_pfm(f_out, full.data(), width_org, height_org, &err)) {
+#else
   if (!ofdis_host::write_flo(f_out, full.data(), width_org, height_org, &err)) {
+#endif
     printf("%s\n", err.c_str());  // the reference reports and carries on (run_dense.cpp:24-25)
   }
   if (verbosity > 1) printf("TIME (Saving flow file  ) (ms): %3g\n", now_ms() - t0);

@@ -78,6 +78,9 @@ int check_params(const ofdis_params* p) {
   if (p->usetvref && ((p->height >> p->sc_f) < 4))
     return fail(OFDIS_ERR_INVALID, "coarsest level must have >= 4 rows for the TV derivative filter (image.c:401-434)");
   if (p->max_iter < 0 || p->tv_innerit < 0 || p->tv_solverit < 0) return fail(OFDIS_ERR_INVALID, "negative iteration count");
+  if (p->selectmode < 0 || p->selectmode > 2) return fail(OFDIS_ERR_INVALID, "selectmode must be 0/1 (optical flow) or 2 (stereo depth)");
+  if (p->selectmode == 2 && p->usefbcon)
+    return fail(OFDIS_ERR_UNSUPPORTED, "forward-backward merging is not available in stereo-depth mode");
   return OFDIS_OK;
 }
 
@@ -103,6 +106,8 @@ struct ofdis_batch {
   float* pvec_bw = nullptr;          // usefbcon: backward grid results
   float* pweight_bw = nullptr;
   std::vector<float*> flow;          // AoS dense flow per level
+  int nop = 2;                       // flow channels (1 in stereo-depth mode)
+  float* uu = nullptr;               // stereo TV: clamped flow + increment (row-major)
   const float* initflow = nullptr;   // borrowed device pointer (ofdis_batch_set_initflow) or null
   float* initflow_own = nullptr;     // staging buffer of ofdis_batch_upload_initflow
   // scratch, sized for the finest level
@@ -166,6 +171,8 @@ DisArgs dis_args(const ofdis_params& p, const LevelGeom& g, int nframes) {
   a.dr_thresh = p.dr_thresh;
   a.res_thresh = p.res_thresh;
   a.outlier_sq_max = outlier_sq_threshold((float)p.p_samp_s / 2);  // outlierthresh, oflow.cpp:82
+  a.stereo = p.selectmode == 2;
+  a.camlr = 0;  // the forward grid is the left camera (oflow.cpp:153-156)
   return a;
 }
 
@@ -247,6 +254,48 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
   return OFDIS_OK;
 }
 
+// VarRefClass::RefLevelDE (refine_variational.cpp:245-336), stereo-depth mode: b->wx holds the densified horizontal
+// displacement (row-major), b->wy zeros; the refined plane goes to flow_out ([B][h][w], one channel).
+int run_varref_de(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow_out,
+                  hipStream_t s) {
+  const ofdis_params& p = b->p;
+  TvGeom t{g.w, g.h, g.noc, b->nframes};
+  const size_t n = (size_t)g.w * g.h * b->nframes;
+  const int n_inner = p.tv_innerit * (g.level + 1);
+  const TvConsts c = tv_consts(p.tv_alpha, p.tv_gamma, p.tv_delta);
+  {
+    KTimer kt(b, OFDIS_K_WARP, s);
+    WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx, b->wy, b->w_im2, b->mask};
+    HIPCHK(launch_warp(wa, s));
+  }
+  {
+    KTimer kt(b, OFDIS_K_DERIV, s);
+    DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs, 0, nullptr, nullptr};
+    HIPCHK(launch_derivatives(da, s));
+  }
+  HIPCHK(hipMemsetAsync(b->du, 0, n * sizeof(float), s));                                    // image_erase(du)
+  HIPCHK(hipMemcpyAsync(b->uu, b->wx, n * sizeof(float), hipMemcpyDeviceToDevice, s));      // uu = wx (:283)
+  for (int it = 0; it < n_inner; ++it) {
+    {
+      KTimer kt(b, OFDIS_K_SYSTEM, s);
+      DeSystemArgs sa{t, b->mask, b->wx, b->uu, b->du, b->derivs, c.quarter_alpha, c.half_delta_over3,
+                      c.half_gamma_over3, b->sys};
+      HIPCHK(launch_de_system(sa, s));
+    }
+    {
+      KTimer kt(b, OFDIS_K_SOR, s);
+      DeSorArgs so{t, b->sys, b->du, p.tv_solverit, p.tv_sor};
+      HIPCHK(launch_de_sor(so, s));
+    }
+    {
+      KTimer kt(b, OFDIS_K_UPDATE, s);
+      HIPCHK(launch_de_update(t, b->wx, b->du, b->uu, nullptr, 0, s));  // camlr == 0 (cpt = left camera)
+    }
+  }
+  HIPCHK(hipMemcpyAsync(flow_out, b->uu, n * sizeof(float), hipMemcpyDeviceToDevice, s));   // wx = uu (:318)
+  return OFDIS_OK;
+}
+
 // same, starting from an AoS flow (the backward direction of usefbcon, whose densified flow waits in AoS form)
 int run_varref_from_aos(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow,
                         hipStream_t s) {
@@ -318,6 +367,7 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
   b->p = *p;
   b->nframes = nframes;
   b->nlevels = p->sc_f - p->sc_l + 1;
+  b->nop = p->selectmode == 2 ? 1 : 2;
   for (int l = p->sc_l; l <= p->sc_f; ++l) b->geom.push_back(make_geom(*p, l));
   const int nin = p->usefbcon ? 6 : 4;
   for (int k = 0; k < 6; ++k) b->in[k].assign(b->nlevels, nullptr);
@@ -327,7 +377,7 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
   for (int i = 0; i < b->nlevels && !rc; ++i) {
     const LevelGeom& g = b->geom[i];
     for (int k = 0; k < nin && !rc; ++k) rc = dalloc(b, &b->in[k][i], g.plane_elems * nframes);
-    if (!rc) rc = dalloc(b, &b->flow[i], (size_t)g.w * g.h * 2 * nframes);
+    if (!rc) rc = dalloc(b, &b->flow[i], (size_t)g.w * g.h * b->nop * nframes);
     if (!rc && p->usefbcon && i > 0) rc = dalloc(b, &b->flow_bw[i], (size_t)g.w * g.h * 2 * nframes);
   }
   const LevelGeom& g0 = b->geom[0];  // finest level: largest of everything
@@ -347,7 +397,8 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
     if (!rc) rc = dalloc(b, &b->w_im2, npx * p->noc);
     if (!rc) rc = dalloc(b, &b->derivs, npx * 8 * p->noc);
     if (!rc) rc = dalloc(b, &b->sys, npx * 7);
-    if (!rc && p->noc == 1 && !getenv("OFDIS_NO_FUSED")) {
+    if (!rc && p->selectmode == 2) rc = dalloc(b, &b->uu, npx);
+    if (!rc && p->noc == 1 && p->selectmode != 2 && !getenv("OFDIS_NO_FUSED")) {
       rc = dalloc(b, &b->wx_d, npx);
       if (!rc) rc = dalloc(b, &b->wy_d, npx);
       if (!rc) rc = dalloc(b, &b->mask_d, npx);
@@ -508,6 +559,7 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
       d.nframes = b->nframes;
       d.p = dir ? b->pvec_bw : b->pvec;
       d.pweight = dir ? b->pweight_bw : b->pweight;
+      d.stereo = p.selectmode == 2;
       if (fb) {
         d.cg_p = dir ? b->pvec : b->pvec_bw;
         d.cg_pweight = dir ? b->pweight : b->pweight_bw;
@@ -529,7 +581,10 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
     }
     if (verbose > 1) { (void)hipStreamSynchronize(s); tt[3] = now_ms() - t0; t0 = now_ms(); }
     // step 5: variational refinement
-    if (p.usetvref) {
+    if (p.usetvref && p.selectmode == 2) {
+      int rc = run_varref_de(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s);
+      if (rc) return rc;
+    } else if (p.usetvref) {
       int rc = run_varref(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s, densify_in_warp ? &dfw : nullptr);
       if (rc) return rc;
       if (bw_flow) {  // VarRefClass on the swapped pair (oflow.cpp:291-294)
@@ -561,7 +616,7 @@ const float* ofdis_batch_level_flow(const ofdis_batch* b, int level) {
 int ofdis_batch_download(ofdis_batch* b, int frame, float* outflow_host, void* stream) {
   if (!b || frame < 0 || frame >= b->nframes || !outflow_host) return fail(OFDIS_ERR_INVALID, "bad arguments");
   const LevelGeom& g = b->geom[0];
-  const size_t n = (size_t)g.w * g.h * 2;
+  const size_t n = (size_t)g.w * g.h * b->nop;
   HIPCHK(hipMemcpyAsync(outflow_host, b->flow[0] + (size_t)frame * n, n * sizeof(float), hipMemcpyDeviceToHost,
                         (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
@@ -573,7 +628,7 @@ int ofdis_batch_download(ofdis_batch* b, int frame, float* outflow_host, void* s
 size_t ofdis_batch_initflow_elems(const ofdis_batch* b) {
   if (!b) return 0;
   const LevelGeom& g = b->geom[b->nlevels - 1];
-  return (size_t)(g.w / 2) * (g.h / 2) * 2;
+  return (size_t)(g.w / 2) * (g.h / 2) * b->nop;
 }
 
 int ofdis_batch_set_initflow(ofdis_batch* b, const float* initflow_dev) {
@@ -603,7 +658,7 @@ int ofdis_batch_upsample(ofdis_batch* b, float* out_dev, int width_org, int heig
     return fail(OFDIS_ERR_INVALID, "original size exceeds the padded size");
   const LevelGeom& g = b->geom[0];
   HIPCHK(launch_upsample_crop(b->flow[0], out_dev, b->nframes, g.w, g.h, p.sc_l, (p.width - width_org) / 2,
-                              (p.height - height_org) / 2, width_org, height_org, (hipStream_t)stream));
+                              (p.height - height_org) / 2, width_org, height_org, b->nop, (hipStream_t)stream));
   return OFDIS_OK;
 }
 
@@ -737,6 +792,7 @@ int ofdis_patchgrid_level(const ofdis_params* p, int level, const float* im_a, c
     DensifyArgs d;
     memset(&d, 0, sizeof(d));
     d.g = g; d.nframes = nframes; d.p = pv; d.pweight = pw; d.flow_aos = flow_out;
+    d.stereo = p->selectmode == 2;
     e = launch_densify(d, s);
   }
   if (e == hipSuccess && p_out)
@@ -771,7 +827,7 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   if (!rc) rc = dalloc(&b, &b.derivs, npx * 8 * p->noc);
   if (!rc) rc = dalloc(&b, &b.sys, npx * 7);
   const TvConsts tc = tv_consts(p->tv_alpha, p->tv_gamma, p->tv_delta);
-  const bool want_fused = p->noc == 1 && !getenv("OFDIS_NO_FUSED") &&
+  const bool want_fused = p->noc == 1 && p->selectmode != 2 && !getenv("OFDIS_NO_FUSED") &&
                           tv_fused_supported(TvGeom{g.w, g.h, g.noc, nframes}, p->tv_solverit) &&
                           tv_fused_params_ok(tc.quarter_alpha, tc.half_delta_over3, tc.half_gamma_over3);
   if (!rc && want_fused) {
@@ -779,14 +835,23 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
     if (!rc) rc = dalloc(&b, &b.wy_d, npx);
     if (!rc) rc = dalloc(&b, &b.mask_d, npx);
   }
-  if (!rc) {
-    TvGeom t{g.w, g.h, g.noc, nframes};
-    hipError_t e = launch_flow_split(t, flow, b.wx, b.wy, s);
-    if (e == hipSuccess && want_fused) e = launch_to_diag(b.wx, b.wx_d, g.w, g.h, nframes, s);
-    if (e == hipSuccess && want_fused) e = launch_to_diag(b.wy, b.wy_d, g.w, g.h, nframes, s);
-    if (e != hipSuccess) rc = hipfail(e, "flow_split");
+  if (!rc && p->selectmode == 2) {  // one channel: wx = flow, wy = 0
+    b.nop = 1;
+    rc = dalloc(&b, &b.uu, npx);
+    hipError_t e = hipMemcpyAsync(b.wx, flow, npx * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(b.wy, 0, npx * sizeof(float), s);
+    if (e != hipSuccess) rc = hipfail(e, "stereo flow copy");
+    if (!rc) rc = run_varref_de(&b, g, im_a, im_b, flow, s);
+  } else {
+    if (!rc) {
+      TvGeom t{g.w, g.h, g.noc, nframes};
+      hipError_t e = launch_flow_split(t, flow, b.wx, b.wy, s);
+      if (e == hipSuccess && want_fused) e = launch_to_diag(b.wx, b.wx_d, g.w, g.h, nframes, s);
+      if (e == hipSuccess && want_fused) e = launch_to_diag(b.wy, b.wy_d, g.w, g.h, nframes, s);
+      if (e != hipSuccess) rc = hipfail(e, "flow_split");
+    }
+    if (!rc) rc = run_varref(&b, g, im_a, im_b, flow, s);
   }
-  if (!rc) rc = run_varref(&b, g, im_a, im_b, flow, s);
   hipError_t e = hipStreamSynchronize(s);
   if (!rc && e != hipSuccess) rc = hipfail(e, "sync");
   for (void* d : b.allocs) (void)hipFree(d);

@@ -145,16 +145,22 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     float H00 = patch_sum<M, LPP>(pxx, valid);
     const float H01 = patch_sum<M, LPP>(pxy, valid);
     float H11 = patch_sum<M, LPP>(pyy, valid);
-    if (H00 * H11 - H01 * H01 == 0.0f) {  // float += double literal in the reference
-      H00 = (float)((double)H00 + 1e-10);
-      H11 = (float)((double)H11 + 1e-10);
-    }
-    l00 = H00; l10 = H01; l11 = H11;
-    if (!(l00 <= 0.0f)) {
-      l00 = sqrtf(l00);
-      l10 = l10 / l00;
-      const float x = l11 - l10 * l10;
-      if (!(x <= 0.0f)) l11 = sqrtf(x);
+    if (a.stereo) {  // 1x1 Hessian of the horizontal displacement (patch.cpp:83-87)
+      if (H00 == 0.0f) H00 = (float)((double)H00 + 1e-10);
+      l00 = H00; l10 = 0.0f; l11 = 1.0f;
+      if (!(l00 <= 0.0f)) l00 = sqrtf(l00);
+    } else {
+      if (H00 * H11 - H01 * H01 == 0.0f) {  // float += double literal in the reference
+        H00 = (float)((double)H00 + 1e-10);
+        H11 = (float)((double)H11 + 1e-10);
+      }
+      l00 = H00; l10 = H01; l11 = H11;
+      if (!(l00 <= 0.0f)) {
+        l00 = sqrtf(l00);
+        l10 = l10 / l00;
+        const float x = l11 - l10 * l10;
+        if (!(x <= 0.0f)) l11 = sqrtf(x);
+      }
     }
   }
 
@@ -163,9 +169,13 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   if (a.flow_prev) {
     const int x = (int)floorf(rx / 2), y = (int)floorf(ry / 2);
     const int i = y * (g.w / 2) + x;
-    const float* fp = a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2) * 2;
-    pin0 = fp[2 * i] * 2;
-    pin1 = fp[2 * i + 1] * 2;
+    if (a.stereo) {  // one channel
+      pin0 = (a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2))[i] * 2;
+    } else {
+      const float* fp = a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2) * 2;
+      pin0 = fp[2 * i] * 2;
+      pin1 = fp[2 * i + 1] * 2;
+    }
   }
 
   // ---- OptimizeIter (patch.cpp:159-212).  All state below is uniform per patch; the lane groups of a
@@ -249,12 +259,19 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     const float b0 = patch_sum<M, LPP>(gxr, valid);
     const float b1 = patch_sum<M, LPP>(gyr, valid);
     // delta_p = LLT(H).solve(b)
-    const float y0 = b0 / l00;
-    const float y1 = (b1 - l10 * y0) / l11;
-    dp1 = y1 / l11;
-    dp0 = (y0 - l10 * dp1) / l00;
-    p0 -= dp0;
-    p1 -= dp1;
+    if (a.stereo) {  // patch.cpp:180-193: 1x1 system, then the disparity sign constraint of the camera side
+      dp0 = (b0 / l00) / l00;
+      dp1 = 0.0f;
+      p0 -= dp0;
+      p0 = a.camlr == 0 ? ((0.0f < p0) ? 0.0f : p0) : ((p0 < 0.0f) ? 0.0f : p0);  // std::min / std::max (p, 0)
+    } else {
+      const float y0 = b0 / l00;
+      const float y1 = (b1 - l10 * y0) / l11;
+      dp1 = y1 / l11;
+      dp0 = (y0 - l10 * dp1) / l00;
+      p0 -= dp0;
+      p1 -= dp1;
+    }
     ptx = rx + p0;
     pty = ry + p1;
     const float ex = stx - ptx, ey = sty - pty;
@@ -557,7 +574,7 @@ float outlier_sq_threshold(float t) {
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   const int M = (a.g.novals + 63) / 64;
   const bool full = a.g.novals == 64 * M;
-  const bool gray8 = a.g.noc == 1 && a.g.P == 8 && !getenv("OFDIS_NO_GRAY8");
+  const bool gray8 = a.g.noc == 1 && a.g.P == 8 && !a.stereo && !getenv("OFDIS_NO_GRAY8");
   const int lpp = (M <= 1) ? (gray8 ? 4 : 8) : 64;  // lanes per patch
   const int ppw = 64 / lpp;                           // patches per wavefront
   const int wpf = (a.g.nop + ppw - 1) / ppw;          // wavefronts per frame
@@ -723,6 +740,8 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
       a.wx_diag[dg] = fu;
       a.wy_diag[dg] = fv;
     }
+  } else if (a.stereo) {
+    a.flow_aos[idx] = fu;  // one channel (patchgrid.cpp:267,390)
   } else {
     reinterpret_cast<float2*>(a.flow_aos)[idx] = make_float2(fu, fv);
   }

@@ -12,6 +12,7 @@ struct DisArgs {
   int nframes;
   // solver parameters (oflow.cpp:76-108)
   int max_iter, min_iter, costfct, patnorm;
+  int stereo, camlr;  // SELECTMODE=2: one horizontal displacement per patch; camlr 0 -> p <= 0, 1 -> p >= 0 (patch.cpp:188-193)
   float dp_thresh_sq, dr_thresh, res_thresh;
   float outlier_sq_max;  // largest x with sqrtf(x) <= outlierthresh (= P/2, oflow.cpp:82): outlier_sq_threshold()
   const float* im_a;     // [B][tmp_h][tmp_w][noc]
@@ -38,6 +39,7 @@ struct DensifyArgs {
   float* wx_diag;        // optional second copy in the solver's diag layout (fused TV path)
   float* wy_diag;
   // forward-backward merging (usefbcon, patchgrid.cpp:277-375): the complementary grid's results, or null
+  int stereo;               // one flow channel: flow_aos is [B][h][w], wy / wy_diag are not written
   const float* cg_p;        // [B][nop][2]
   const float* cg_pweight;  // [B][nop][novals]
 };
@@ -146,7 +148,30 @@ hipError_t launch_pyr_planes(const float* src, float* img, float* dx, float* dy,
 
 // x 2^sc_l, bilinear upsample (cv::resize INTER_LINEAR) and crop of the AoS result (run_dense.cpp:406-414)
 hipError_t launch_upsample_crop(const float* flow, float* out, int nframes, int sw, int sh, int sc_l, int left, int top,
-                                int wo, int ho, hipStream_t s);
+                                int wo, int ho, int channels, hipStream_t s);
+
+// ---- stereo-depth mode (SELECTMODE=2; ofdis_de.hip)
+struct DeSystemArgs {
+  TvGeom t;
+  const float* mask;   // row-major [B][h][w]
+  const float* wx;     // row-major: the flow before the increment
+  const float* uu;     // row-major: clamped flow + increment of the previous fixed-point iteration
+  const float* du;     // diag
+  const float* derivs; // row-major [B][8*noc][h][w]
+  float quarter_alpha, half_delta_over3, half_gamma_over3;
+  float* sys;          // [B][4][w*h] diag: a11, b1, smooth_horiz, smooth_vert
+};
+hipError_t launch_de_system(const DeSystemArgs& a, hipStream_t s);
+struct DeSorArgs {
+  TvGeom t;
+  const float* sys;
+  float* du;  // diag, in/out
+  int iterations;
+  float omega;
+};
+hipError_t launch_de_sor(const DeSorArgs& a, hipStream_t s);
+hipError_t launch_de_update(const TvGeom& t, const float* wx, const float* du, float* uu, float* out, int camlr,
+                            hipStream_t s);
 
 // test hook: out[i] = wave_sum over each consecutive group of 64 inputs (n multiple of 64)
 hipError_t launch_wave_sum_test(const float* in, float* out, int n, hipStream_t s);

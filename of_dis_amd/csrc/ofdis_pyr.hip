@@ -187,9 +187,41 @@ __global__ __launch_bounds__(256) void upsample_crop_kernel(const float2* __rest
   }
 }
 
+// one-channel result of the stereo-depth mode (CV_32FC1, same resize): one pixel per thread
+__global__ __launch_bounds__(256) void upsample_crop1_kernel(const float* __restrict__ flow, float* __restrict__ out,
+                                                             int sw, int sh, int sc_l, int left, int top, int wo, int ho) {
+  const int f = blockIdx.z, y = blockIdx.y;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= wo) return;
+  const float scf = (float)(1 << sc_l), inv = 1.0f / scf;
+  float fy = ((float)(y + top) + 0.5f) * inv - 0.5f;
+  int sy = (int)floorf(fy);
+  fy -= (float)sy;
+  if (sy < 0) { sy = 0; fy = 0.0f; }
+  if (sy >= sh - 1) { sy = sh - 1; fy = 0.0f; }
+  const int sy1 = min(sy + 1, sh - 1);
+  float fx = ((float)(x + left) + 0.5f) * inv - 0.5f;
+  int sx = (int)floorf(fx);
+  fx -= (float)sx;
+  if (sx < 0) { sx = 0; fx = 0.0f; }
+  if (sx >= sw - 1) { sx = sw - 1; fx = 0.0f; }
+  const int sx1 = min(sx + 1, sw - 1);
+  const float* fl = flow + (size_t)f * sw * sh;
+  float v00 = fl[sy * sw + sx], v01 = fl[sy * sw + sx1], v10 = fl[sy1 * sw + sx], v11 = fl[sy1 * sw + sx1];
+  if (sc_l > 0) { v00 *= scf; v01 *= scf; v10 *= scf; v11 *= scf; }
+  const float ax = 1.0f - fx, ay = 1.0f - fy;
+  const float r0 = v00 * ax + v01 * fx, r1 = v10 * ax + v11 * fx;
+  out[((size_t)f * ho + y) * wo + x] = r0 * ay + r1 * fy;
+}
+
 hipError_t launch_upsample_crop(const float* flow, float* out, int nframes, int sw, int sh, int sc_l, int left, int top,
-                                int wo, int ho, hipStream_t s) {
+                                int wo, int ho, int channels, hipStream_t s) {
   if (ho > 65535 || nframes > 65535) return hipErrorInvalidValue;
+  if (channels == 1) {
+    hipLaunchKernelGGL(upsample_crop1_kernel, dim3((wo + 255) / 256, ho, nframes), dim3(256), 0, s, flow, out, sw, sh,
+                       sc_l, left, top, wo, ho);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(upsample_crop_kernel, dim3((wo + 511) / 512, ho, nframes), dim3(256), 0, s, (const float2*)flow,
                      (float2*)out, sw, sh, sc_l, left, top, wo, ho);
   return hipGetLastError();

@@ -20,7 +20,7 @@ class OfdisParams(C.Structure):
         ("usetvref", C.c_int),
         ("tv_alpha", C.c_float), ("tv_gamma", C.c_float), ("tv_delta", C.c_float),
         ("tv_innerit", C.c_int), ("tv_solverit", C.c_int), ("tv_sor", C.c_float),
-        ("verbosity", C.c_int),
+        ("verbosity", C.c_int), ("selectmode", C.c_int),
     ]
 
     def copy(self, **kw):
@@ -32,6 +32,11 @@ class OfdisParams(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+    @property
+    def nop(self):
+        """flow channels: 2 (optical flow) or 1 (stereo depth, selectmode 2) -- the reference's op.nop"""
+        return 1 if self.selectmode == 2 else 2
 
     # ---- derived geometry (reference oflow.cpp:91,138-157; patchgrid.cpp:42-48)
     def level_size(self, level):

@@ -183,7 +183,8 @@ class COracle(_Base):
 
 
 class RefLib(_Base):
-    """The reference itself (oracle/_ref/libofdis_ref_{int,rgb}[_w64].so)."""
+    """The reference itself (oracle/_ref/libofdis_ref_{int,rgb}[_w64].so; kind "de_int" / "de_rgb" = the stereo-depth
+    build, SELECTMODE=2, whose flows have ONE channel)."""
 
     def __init__(self, kind="int", wave64=False):
         fn = f"libofdis_ref_{kind}{'_w64' if wave64 else ''}.so"
@@ -197,6 +198,7 @@ class RefLib(_Base):
         self.noc = self.lib.ofdis_ref_noc()
         self.wave64 = bool(self.lib.ofdis_ref_wave64_order())
         self.name = f"reference[{kind}{',wave64' if wave64 else ''}]"
+        self.nop = 1 if kind.startswith("de_") else 2   # oflow.cpp:76-80
 
     def image_warp(self, src, wx, wy):
         src = _c(src)
@@ -255,7 +257,7 @@ class RefLib(_Base):
         nw, nh = p.grid(level)
         nop = nw * nh
         pout = np.zeros((nop, 2), _f32)
-        flow = np.zeros((h, w, 2), _f32)
+        flow = np.zeros((h, w, self.nop), _f32)
         n = C.c_int(0)
         fp = _p(_c(flow_prev)) if flow_prev is not None else None
         rc = self.lib.ofdis_ref_patchgrid_level(
@@ -270,7 +272,7 @@ class RefLib(_Base):
     def flow(self, p, pyr_a, pyr_a_dx, pyr_a_dy, pyr_b, initflow=None, pyr_b_dx=None, pyr_b_dy=None):
         n = p.sc_f + 1
         w, h = p.level_size(p.sc_l)
-        out = np.zeros((h, w, 2), _f32)
+        out = np.zeros((h, w, self.nop), _f32)
         keep = [[_c(x) if x is not None else None for x in pl]
                 for pl in (pyr_a, pyr_a_dx, pyr_a_dy, pyr_b, pyr_b_dx or pyr_a_dx, pyr_b_dy or pyr_a_dy)]
         ini = _p(_c(initflow)) if initflow is not None else None

@@ -76,7 +76,11 @@ void fill_params(OFC::optparam& op, OFC::camparam& cp, int w_lv, int h_lv, int l
                  int max_iter, int min_iter, float dp_thresh, float dr_thresh, float res_thresh,
                  int p_samp_s, float patove, int costfct, int noc, int patnorm, float tv_alpha,
                  float tv_gamma, float tv_delta, int tv_innerit, int tv_solverit, float tv_sor) {
-  op.nop = 2;
+#if (SELECTMODE == 1)
+  op.nop = 2;  // oflow.cpp:76-80
+#else
+  op.nop = 1;
+#endif
   op.p_samp_s = p_samp_s;
   op.outlierthresh = (float)op.p_samp_s / 2;
   op.patove = patove;
@@ -176,9 +180,15 @@ int ofdis_ref_patchgrid_level(const float* im_a, const float* im_a_dx, const flo
   if (nopatches_out) *nopatches_out = n;
   if (p_out)
     for (int i = 0; i < n; ++i) {
+#if (SELECTMODE == 1)
       const Eigen::Vector2f* d = grid.pat[i]->GetParam();  // p_iter (patch.h:78)
       p_out[2 * i] = (*d)[0];
       p_out[2 * i + 1] = (*d)[1];
+#else  // stereo: one horizontal displacement per patch (patch.h:80)
+      const Eigen::Matrix<float, 1, 1>* d = grid.pat[i]->GetParam();
+      p_out[2 * i] = (*d)[0];
+      p_out[2 * i + 1] = 0.0f;
+#endif
     }
   if (flow_out) grid.AggregateFlowDense(flow_out);
   return 0;

@@ -113,3 +113,36 @@ def test_run_of_int_forward_backward(gpu, tmp_path):
     pa, pb = O.build_pyramid(p, ia), O.build_pyramid(p, ib)
     core = oracle.ref("int", True).flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
     assert_bits_equal(read_flo(fo), O.upsample_crop(p, core, w, h), "usefbcon .flo vs reference core + oracle pipeline")
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline() == b"Pf\n"
+        w, h = map(int, f.readline().split())
+        assert f.readline() == b"-1.000000\n"            # fprintf("%f", -1.0f): little endian (run_dense.cpp:70)
+        d = np.frombuffer(f.read(), np.float32)
+    assert d.size == w * h
+    return -d.reshape(h, w)[::-1]                         # rows bottom-up, values negated (run_dense.cpp:72-79)
+
+
+@pytest.mark.gpu
+def test_run_de_int_stereo_binary(gpu, tmp_path):
+    """run_DE_INT (the reference's SELECTMODE=2 binary): .pfm of the horizontal displacement at full resolution."""
+    if not oracle.have_ref("de_int", True):
+        pytest.skip("oracle/_ref stereo build missing")
+    w, h = 1024, 436
+    ia, ib, _ = gen_synth.make_pair(w, h, 34)
+    fa, fb, fo = str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm"), str(tmp_path / "o.pfm")
+    gen_synth.write_pgm(fa, ib)                           # second image first: negative horizontal motion
+    gen_synth.write_pgm(fb, ia)
+    r = subprocess.run([os.path.join(ROOT, "of_dis_amd", "lib", "run_DE_INT"), fa, fb, fo, "2"], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    p = oppoint(2, w, h).copy(selectmode=2)
+    O = oracle.c_oracle()
+    pa, pb = O.build_pyramid(p, ib), O.build_pyramid(p, ia)
+    core = oracle.ref("de_int", True).flow(p, pa[0], pa[1], pa[2], pb[0])
+    assert core.min() < -0.5                              # a real displacement field, not all clamped to zero
+    two = np.concatenate([core, core], axis=-1)           # the oracle's resize is per channel
+    expect = O.upsample_crop(p.copy(selectmode=0), two, w, h)[..., 0]
+    assert_bits_equal(read_pfm(fo), expect, "run_DE_INT .pfm vs reference core + oracle upsample")
