@@ -468,11 +468,7 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
     pos1 += g.pad;
     // byte offset of (row pos1-5, column pos0-5+2pl) = the left tap of the lane's first column; rows rr = 0..8
     // follow at rr*row_bytes
-#ifdef OFDIS_DBG_FIXED_VOFF  // timing experiment only (tools/ab_build.py): every patch reads the same window
-    const int voff = (pos0 + pos1 > -100000 ? 2 * pl : 1) * 4;
-#else
     const int voff = ((pos1 - 5) * tw + pos0 - 5 + 2 * pl) * 4;
-#endif
     f2 A[9], Bn[9];
 #pragma unroll
     for (int rr = 0; rr < 9; ++rr) {
