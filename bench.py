@@ -87,17 +87,11 @@ def algorithmic_bytes(p, nframes, fused_tv=True):
                                             + nop * 8 + nop * nv * 4)
         launches["patch_optimize"] += 1
         fused = p.usetvref and fused_tv and noc == 1 and h <= 64 and w >= 16 and p.tv_solverit <= 3
-        densify_in_warp = fused and not p.usefbcon and not os.environ.get("OFDIS_NO_DENSIFY_WARP")
-        dens = nframes * (nop * 8 + nop * nv * 4) + 8 * npx           # p, pweight in; wx, wy out
-        if densify_in_warp:
-            out["warp"] += dens                                       # densification runs inside the warp kernel
-        else:
-            out["densify"] += dens
-            launches["densify"] += 1
+        out["densify"] += nframes * (nop * 8 + nop * nv * 4) + 8 * npx       # p, pweight in; wx, wy out
+        launches["densify"] += 1
         if p.usetvref:
             n_inner = p.tv_innerit * (l + 1)
-            # wx,wy in (not when produced in the same kernel) + src once + dst + mask
-            out["warp"] += ((0 if densify_in_warp else 8) + 4 * noc + 4 * noc + 4) * npx
+            out["warp"] += (8 + 4 * noc + 4 * noc + 4) * npx          # wx,wy + src once + dst + mask
             out["derivatives"] += 40 * noc * npx                      # I0,I1w in, 8 planes out
             if fused:   # system + SOR in one kernel: derivs, mask, wx, wy, du, dv in; du, dv out
                 out["tv_fused"] += n_inner * (32 * noc + 20 + 8) * npx

@@ -196,9 +196,8 @@ bool use_fused(const ofdis_batch* b, const LevelGeom& g) {
          tv_fused_params_ok(c.quarter_alpha, c.half_delta_over3, c.half_gamma_over3);
 }
 
-// `dfuse` (fused-TV levels only): the level's densification has not run yet and is done inside the warp kernel.
 int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow_out,
-               hipStream_t s, const DensifyArgs* dfuse = nullptr) {
+               hipStream_t s) {
   const ofdis_params& p = b->p;
   TvGeom t{g.w, g.h, g.noc, b->nframes};
   const size_t npx = (size_t)g.w * g.h;
@@ -207,10 +206,9 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
   const bool fused = use_fused(b, g);
   {
     KTimer kt(b, OFDIS_K_WARP, s);
-    if (fused) {  // wx_d, wy_d in (or produced here), mask_d out (diag); the warped image stays row-major
+    if (fused) {  // wx_d, wy_d in, mask_d out (diag); the warped image stays row-major
       WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx_d, b->wy_d, b->w_im2, b->mask_d};
-      if (dfuse) HIPCHK(launch_densify_warp_diag(*dfuse, wa, s));
-      else HIPCHK(launch_warp_diag(wa, s));
+      HIPCHK(launch_warp_diag(wa, s));
     } else {
       WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx, b->wy, b->w_im2, b->mask};
       HIPCHK(launch_warp(wa, s));
@@ -547,11 +545,10 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
       }
     }
     if (verbose > 1) { (void)hipStreamSynchronize(s); tt[2] = now_ms() - t0; t0 = now_ms(); }
-    // step 4: densification (with usefbcon each direction also merges the other grid's negated flow).  On the
-    // fused-TV levels the forward densification is part of the warp kernel of step 5.
-    const bool densify_in_warp = p.usetvref && !fb && use_fused(b, g) && !getenv("OFDIS_NO_DENSIFY_WARP");
-    DensifyArgs dfw;
-    memset(&dfw, 0, sizeof(dfw));
+    // step 4: densification (with usefbcon each direction also merges the other grid's negated flow).
+    // (Doing it inside the warp kernel -- one launch and one flow round trip less -- was measured: same time, 2.4x
+    // the HBM traffic because a 32x32 pixel tile re-fetches the weight lines of the patches it shares with its
+    // neighbours; not kept.)
     for (int dir = 0; dir < (bw_flow ? 2 : 1); ++dir) {
       DensifyArgs d;
       memset(&d, 0, sizeof(d));
@@ -572,10 +569,6 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
       } else {
         d.flow_aos = dir ? b->flow_bw[ii] : b->flow[ii];
       }
-      if (dir == 0 && densify_in_warp) {
-        dfw = d;
-        continue;
-      }
       KTimer kt(b, OFDIS_K_DENSIFY, s);
       HIPCHK(launch_densify(d, s));
     }
@@ -585,7 +578,7 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
       int rc = run_varref_de(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s);
       if (rc) return rc;
     } else if (p.usetvref) {
-      int rc = run_varref(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s, densify_in_warp ? &dfw : nullptr);
+      int rc = run_varref(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s);
       if (rc) return rc;
       if (bw_flow) {  // VarRefClass on the swapped pair (oflow.cpp:291-294)
         rc = run_varref_from_aos(b, g, b->in[3][ii], b->in[0][ii], b->flow_bw[ii], s);

@@ -65,8 +65,6 @@ hipError_t launch_warp(const WarpArgs& a, hipStream_t s);
 // same computation with wx, wy read from and mask written to the solver's diag layout (fused TV path);
 // src must be the padded pyramid plane, dst stays row-major (the derivative stencils read it)
 hipError_t launch_warp_diag(const WarpArgs& a, hipStream_t s);
-// densify (d.wx_diag, d.wy_diag out) + warp with that flow (a.dst row-major, a.mask diag; a.wx, a.wy unused)
-hipError_t launch_densify_warp_diag(const DensifyArgs& d, const WarpArgs& a, hipStream_t s);
 
 // get_derivatives.  im1 as for WarpArgs.src; im2w packed planar [B][noc][h][w].
 // out [B][8][noc][h][w]

@@ -14,7 +14,6 @@
 #include <stdlib.h>
 
 #include "ofdis_kernels.h"
-#include "ofdis_densify.h"
 #include "ofdis_tvmath.h"
 
 namespace ofdis {
@@ -179,89 +178,6 @@ __global__ __launch_bounds__(256) void warp_diag_kernel(const WarpArgs a) {
     const int y = y0 + ry, x = x0 + rx;
     if (y < h && x < w) a.mask[fo + diag_index(x, y, w, h)] = m_t[ry * TW + rx];
   }
-}
-
-// Densification fused into the warp (gray/RGB, fused-TV levels): the thread that will warp pixels x..x+3 of row y
-// first gathers their flow from the patch results (ofdis_densify.h; weights are read along patch rows, i.e. in
-// 32-byte runs instead of one float per lane per cache line as in a diag-ordered densify), warps with it, and the
-// block writes wx, wy and the mask to the solver's diag layout through LDS.  Per pixel: 4 weights + 2 displacements
-// in, wx, wy, mask, warped image out -- the flow never makes a round trip through HBM between the two stages.
-__global__ __launch_bounds__(256) void densify_warp_diag_kernel(const DensifyArgs d, const WarpArgs a) {
-  constexpr int TW = 32, TH = 32;
-  __shared__ __attribute__((aligned(16))) float wx_t[TH * TW];
-  __shared__ __attribute__((aligned(16))) float wy_t[TH * TW];
-  __shared__ __attribute__((aligned(16))) float m_t[TH * TW];
-  const int w = a.t.w, h = a.t.h, noc = a.t.noc;
-  const int npx = w * h;
-  const int tiles_x = (w + TW - 1) / TW;
-  int frame, tile;
-  xcd_frame_map(blockIdx.x, tiles_x * ((h + TH - 1) / TH), frame, tile);
-  if (frame >= a.t.nframes) return;
-  const int tx = tile % tiles_x, ty = tile / tiles_x;
-  const int x0 = tx * TW, y0 = ty * TH;
-  const size_t fo = (size_t)frame * npx;
-  const LevelGeom& g = d.g;
-  const float* pf = d.p + (size_t)frame * g.nop * 2;
-  const float* pwf = d.pweight + (size_t)frame * g.nop * g.novals;
-  {
-    const int ry = threadIdx.x >> 3, q4 = (threadIdx.x & 7) * 4;
-    const int y = y0 + ry, x = x0 + q4;
-    if (y < h && x < w) {
-      float m[4], r[4][3], fxs[4], fys[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        m[k] = 0.0f;
-        r[k][0] = r[k][1] = r[k][2] = 0.0f;
-        fxs[k] = fys[k] = 0.0f;
-        if (x + k < w) {
-          float we = 0.0f, fu = 0.0f, fv = 0.0f;
-          densify_accumulate(g, pf, pwf, x + k, y, we, fu, fv);
-          if (we > 0) {  // patchgrid.cpp:377-397
-            fu /= we;
-            fv /= we;
-          }
-          fxs[k] = fu;
-          fys[k] = fv;
-          warp_pixel<true>(a, frame, x + k, y, fu, fv, m[k], r[k]);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        wx_t[ry * TW + q4 + k] = fxs[k];
-        wy_t[ry * TW + q4 + k] = fys[k];
-        m_t[ry * TW + q4 + k] = m[k];
-      }
-      for (int c = 0; c < noc; ++c) {
-        float* dd = a.dst + ((size_t)frame * noc + c) * npx + (size_t)y * w + x;
-        if (x + 3 < w && (w & 3) == 0) {
-          *reinterpret_cast<float4*>(dd) = make_float4(r[0][c], r[1][c], r[2][c], r[3][c]);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (x + k < w) dd[k] = r[k][c];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int n = threadIdx.x; n < TH * TW; n += 256) {
-    const int ry = n % TH, r = n / TH;
-    const int rx = (r - ry) & (TW - 1);
-    const int y = y0 + ry, x = x0 + rx;
-    if (y < h && x < w) {
-      const size_t o = fo + diag_index(x, y, w, h);
-      d.wx_diag[o] = wx_t[ry * TW + rx];
-      d.wy_diag[o] = wy_t[ry * TW + rx];
-      a.mask[o] = m_t[ry * TW + rx];
-    }
-  }
-}
-
-hipError_t launch_densify_warp_diag(const DensifyArgs& d, const WarpArgs& a, hipStream_t s) {
-  if (!a.src_padded || !d.wx_diag || !d.wy_diag || d.cg_p) return hipErrorInvalidValue;
-  const int tiles = ((a.t.w + 31) / 32) * ((a.t.h + 31) / 32);
-  hipLaunchKernelGGL(densify_warp_diag_kernel, dim3(((a.t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, d, a);
-  return hipGetLastError();
 }
 
 hipError_t launch_warp_diag(const WarpArgs& a, hipStream_t s) {
