@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--tv", choices=["on", "off"], default="on")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="ofdis_batch_set_pipeline: sub-batches on internal streams, consecutive steps overlap (1 = off)")
     ap.add_argument("--scope", choices=["ofclass", "e2e"], default="ofclass",
                     help="ofclass (the metric): pyramids resident in HBM -> level flow.  e2e (secondary, DESIGN.md 5): "
                          "8-bit frames resident in HBM -> pyramids -> flow -> full-resolution flow in HBM")
@@ -195,6 +197,7 @@ def main():
     tstream = torch.cuda.Stream(device=dev)
     stream = tstream.cuda_stream
     batch = capi.Batch(p, B)
+    batch.set_pipeline(args.pipeline)
     torch.cuda.synchronize()  # frames were generated on torch's default stream
     batch.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
     torch.cuda.synchronize()
@@ -271,7 +274,9 @@ def main():
                                    + ("end-to-end scope: 8-bit frames in HBM -> pyramids -> flow -> full-resolution flow in HBM (secondary)"
                                       if e2e else "OFClass scope, pyramids resident in HBM"),
                        "frames_per_gpu_per_step": B, "global_frames_per_step": B * world,
-                       "parallelism": f"frame-sharded x{world}", "tv": args.tv},
+                       "parallelism": f"frame-sharded x{world}", "tv": args.tv,
+                       "pipeline": f"{args.pipeline} sub-batches per GPU on internal HIP streams, consecutive steps "
+                                   f"overlap inside the timed region" if args.pipeline > 1 else "off"},
             "roofline": roofline, "kernels": kernels,
         }
         if not args.no_parity:

@@ -132,6 +132,13 @@ int ofdis_batch_upload_initflow(ofdis_batch* b, int frame, const float* initflow
 
 /* enqueue the whole hot path (all levels, DIS + densify + TV) for all frames on `stream` */
 int ofdis_batch_run(ofdis_batch* b, void* stream);
+/* Throughput option: cut the batch into `sub_batches` (2..4; 0 or 1 = off, the default) parts that run on internal
+ * streams forked from the caller's stream and NOT joined at the end of ofdis_batch_run, so that consecutive passes
+ * overlap (coarse-level kernels of one part fill the issue slots left by another part's kernels).  Results are then
+ * complete on a stream only after ofdis_batch_join(b, stream); ofdis_batch_download / _upsample join themselves.
+ * Do not modify the inputs of a pass before joining it.  Results are identical in either mode. */
+int ofdis_batch_set_pipeline(ofdis_batch* b, int sub_batches);
+int ofdis_batch_join(ofdis_batch* b, void* stream);
 /* device pointer to the result, [nframes][h>>sc_l][w>>sc_l][2] */
 const float* ofdis_batch_flow(const ofdis_batch* b);
 /* device pointer to the dense flow of an intermediate level (for per-level parity tests) */

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "ofdis_params_oppoint", "ofdis_last_error", "ofdis_version", "ofdis_device_count", "ofdis_set_device",
     "ofdis_flow", "ofdis_batch_create", "ofdis_batch_destroy", "ofdis_batch_input", "ofdis_batch_input_elems",
     "ofdis_batch_upload", "ofdis_batch_upload_b_gradients", "ofdis_batch_initflow_elems", "ofdis_batch_set_initflow", "ofdis_batch_upload_initflow",
-    "ofdis_batch_build_pyramids_u8", "ofdis_batch_run", "ofdis_batch_flow",
+    "ofdis_batch_build_pyramids_u8", "ofdis_batch_run", "ofdis_batch_set_pipeline", "ofdis_batch_join", "ofdis_batch_flow",
     "ofdis_batch_level_flow", "ofdis_batch_download", "ofdis_batch_upsample", "ofdis_batch_timing", "ofdis_batch_kernel_time",
     "ofdis_image_warp", "ofdis_get_derivatives", "ofdis_tv_system", "ofdis_sor_coupled", "ofdis_patchgrid_level",
     "ofdis_varref_level", "ofdis_dev_alloc", "ofdis_dev_free", "ofdis_memcpy_h2d", "ofdis_memcpy_d2h", "ofdis_memcpy_d2d", "ofdis_sync",
@@ -82,6 +82,8 @@ def lib():
         L.ofdis_flow.argtypes = [C.POINTER(OfdisParams)] + [C.POINTER(FP)] * 6 + [FP, FP]
         L.ofdis_params_oppoint.argtypes = [C.POINTER(OfdisParams), C.c_int, C.c_int, C.c_int]
         L.ofdis_batch_upsample.argtypes = [VP, VP, C.c_int, C.c_int, VP]
+        L.ofdis_batch_set_pipeline.argtypes = [VP, C.c_int]
+        L.ofdis_batch_join.argtypes = [VP, VP]
         L.ofdis_batch_upload_b_gradients.argtypes = [VP, C.c_int, C.POINTER(FP), C.POINTER(FP), VP]
         L.ofdis_batch_initflow_elems.restype = C.c_size_t
         L.ofdis_batch_initflow_elems.argtypes = [VP]
@@ -303,6 +305,12 @@ class Batch:
     def run(self, stream=None):
         check(lib().ofdis_batch_run(self.h, stream))
 
+    def set_pipeline(self, sub_batches):
+        check(lib().ofdis_batch_set_pipeline(self.h, sub_batches))
+
+    def join(self, stream=None):
+        check(lib().ofdis_batch_join(self.h, stream))
+
     def flow_ptr(self):
         return lib().ofdis_batch_flow(self.h)
 
@@ -328,6 +336,7 @@ class Batch:
     def download_all(self):
         w, h = self.p.level_size(self.p.sc_l)
         out = np.zeros((self.nframes, h, w, self.p.nop), _f32)
+        self.join(None)
         check(lib().ofdis_sync(None))
         check(lib().ofdis_memcpy_d2h(out.ctypes.data, self.flow_ptr(), out.nbytes))
         return out
@@ -335,6 +344,7 @@ class Batch:
     def level_flow(self, level):
         w, h = self.p.level_size(level)
         out = np.zeros((self.nframes, h, w, self.p.nop), _f32)
+        self.join(None)
         check(lib().ofdis_sync(None))
         check(lib().ofdis_memcpy_d2h(out.ctypes.data, lib().ofdis_batch_level_flow(self.h, level), out.nbytes))
         return out

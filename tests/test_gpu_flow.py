@@ -143,6 +143,36 @@ def test_forward_backward_consistency(gpu, orc, size, noc, opp, tv):
     assert_bits_equal(out[1], R.flow(p, pb[0], pb[1], pb[2], pa[0], pyr_b_dx=pa[1], pyr_b_dy=pa[2]), "batch frame 1 (B -> A)")
 
 
+@pytest.mark.parametrize("nsub", [2, 3, 4])
+def test_pipelined_sub_batches(gpu, orc, nsub):
+    """ofdis_batch_set_pipeline: sub-batches on internal streams with a deferred join.  Every frame's result must be
+    what it is alone (ragged splits included), back-to-back passes must agree, and switching the mode off again
+    must leave nothing in flight."""
+    cases = [synth_case(1024, 436, 1500 + k, 1, 2, 1) for k in range(3)]
+    p = cases[0][0]
+    order = [0, 1, 2, 2, 1, 0, 1]               # 7 frames: ragged for 2, 3 and 4 sub-batches
+    refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
+    b = gpu.Batch(p, len(order))
+    for slot, k in enumerate(order):
+        _, pa, pb, _, _ = cases[k]
+        b.upload(slot, pa[0], pa[1], pa[2], pb[0])
+    b.set_pipeline(nsub)
+    for rep in range(2):
+        b.run()
+        b.run()                                  # two passes in flight before anything joins
+        out = b.download_all()
+        for slot, k in enumerate(order):
+            assert_bits_equal(out[slot], refs[k], f"pipelined run {rep} slot {slot} (frame {k})")
+    assert_bits_equal(b.download(3), refs[order[3]], "ofdis_batch_download joins by itself")
+    full = b.upsample(1024, 436)
+    assert_bits_equal(full[5], orc.upsample_crop(p, refs[order[5]], 1024, 436), "ofdis_batch_upsample joins by itself")
+    b.run()
+    b.set_pipeline(0)
+    b.run()
+    assert_bits_equal(b.download_all()[6], refs[order[6]], "back to the single-stream mode")
+    b.close()
+
+
 def test_batch_level_flows(gpu, orc):
     p, pa, pb, _, _ = synth_case(1024, 436, 1240, 1, 2, 1)
     _, levels = orc.flow(p, pa[0], pa[1], pa[2], pb[0], want_levels=True)
