@@ -98,6 +98,15 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
 template <int NS, bool BRIGHT>
 __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const int R) {
   constexpr int U = 6;
+  // prefetch distances: the W row (wx,wy,du,dv) of diag row t+PDW and the D row (8 derivatives + mask) of row t+PDD are
+  // requested at step t; first uses are rows t+3 (uu, vv) and t+1 (data term).  (5, 3) = two steps of slack, 141 VGPRs,
+  // 3 wavefronts per SIMD; (4, 2) = one step of slack, 128 VGPRs, 4 wavefronts per SIMD measured the same kernel time
+  // and 1 % less end to end (tools/ab_build.py), so the occupancy is not what limits this kernel.
+#ifndef OFDIS_FUSED_PDW
+#define OFDIS_FUSED_PDW 5
+#define OFDIS_FUSED_PDD 3
+#endif
+  constexpr int PDW = OFDIS_FUSED_PDW, PDD = OFDIS_FUSED_PDD;
   static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
   const int w = a.t.w, h = a.t.h;
   const int npx = w * h;
@@ -167,12 +176,12 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
   // prologue: W rows -1, 0, 1 (indices 2, 3, 4)
   load_w(W[2], wrap(-1));
   load_w(W[3], wrap(0));
-  load_w(W[4], wrap(1));
+  if (PDW == 5) load_w(W[4], wrap(1));
   // du, dv are zero before the first fixed-point iteration (refine_variational.cpp:186-187): the kernel never reads
   // them during its first pass over the columns, so the caller does not have to clear them
   W[2].du = W[2].dv = W[3].du = W[3].dv = W[4].du = W[4].dv = 0.0f;
-  int rowW = wrap(2);   // next W row to load (row t+5 at t = -3)
-  int rowD = wrap(0);   // next D row to load (row t+3 at t = -3)
+  int rowW = wrap(PDW - 3);  // next W row to load (row t+PDW at t = -3)
+  int rowD = wrap(PDD - 3);  // next D row to load (row t+PDD at t = -3)
   int srow = wrap(-3 - 2 * (NS - 1));  // row finished by the last sweep at step t = -3
   int x2 = wrap(-1 - j);               // this lane's x on diag row t+2 (per lane)
   bool x1_last = (wrap(-2 - j) == w - 1);  // row t+1 is this lane's last column
@@ -186,13 +195,13 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
     for (int u = 0; u < U; ++u) {
       // step t = k0 + u - 3; up to U-1 steps past tend are executed: every pixel is then out of range
       // ---- (1) loads: W row t+5, D row t+3
-      load_w(W[(u + 5) % 6], rowW);
+      load_w(W[(u + PDW) % 6], rowW);
       rowW = next_row(rowW);
       if (first_w) {  // this lane's column on row t+5 still belongs to the first iteration: du = dv = 0 (image_erase)
-        W[(u + 5) % 6].du = 0.0f;
-        W[(u + 5) % 6].dv = 0.0f;
+        W[(u + PDW) % 6].du = 0.0f;
+        W[(u + PDW) % 6].dv = 0.0f;
       }
-      load_d(D[u % 3], rowD);
+      load_d(D[(u + PDD) % 3], rowD);
       rowD = next_row(rowD);
       // ---- (2) uu, vv of row t+3 (refine_variational.cpp:210-216: uu = wx + du of before this call)
       {
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
         nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
       }
       {
-        first_w = ig + (6 + 2 * (NS - 1)) < w;  // for the next step's row
+        first_w = ig + (PDW + 1 + 2 * (NS - 1)) < w;  // for the next step's row
         if (row_ok && ig >= 0 && ig < wtot) {
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nu[NS - 1]), rsU, vo1, srow * row_bytes, 0);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nv[NS - 1]), rsV, vo1, srow * row_bytes, 0);
