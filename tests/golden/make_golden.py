@@ -52,6 +52,26 @@ def flow_case(name, w, h, seed, channels, op_point, **over):
     print(name, {k: v.shape for k, v in out.items() if k.startswith("flow")})
 
 
+def mode_case(name, w, h, seed, channels, op_point, swap=False, **over):
+    """Final flow only, for the modes the C restatement does not cover (forward-backward merging, stereo depth):
+    the HIP path is then pinned on boxes without oracle/_ref as well.  File name prefix "mode_"."""
+    ia, ib, _ = gen_synth.make_pair(w, h, seed, channels)
+    if swap:
+        ia, ib = ib, ia
+    p = oppoint(op_point, w, h, noc=channels).copy(**over)
+    O = oracle.c_oracle()
+    pa, pb = O.build_pyramid(p, ia), O.build_pyramid(p, ib)
+    kind = ("de_" if p.selectmode == 2 else "") + ("int" if channels == 1 else "rgb")
+    out = {"img_a": ia, "img_b": ib, "size": np.array([w, h]),
+           "params": np.array([getattr(p, n) for n, _ in p._fields_], np.float64),
+           "param_names": np.array([n for n, _ in p._fields_])}
+    out["flow_w64"] = oracle.ref(kind, True).flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
+    if oracle.have_ref(kind, False):
+        out["flow_seq"] = oracle.ref(kind, False).flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
+    np.savez_compressed(os.path.join(HERE, "mode_" + name + ".npz"), **out)
+    print("mode_" + name, out["flow_w64"].shape, float(np.abs(out["flow_w64"]).mean()))
+
+
 def kernel_vectors():
     """FDF1.0.1 functions on small random planes (gray 32x14 and rgb 30x17)."""
     out = {}
@@ -93,3 +113,7 @@ if __name__ == "__main__":
     flow_case("op2_gray_256x128", 256, 128, 2024, 1, 2)
     flow_case("op2_gray_320x200_notv_l1", 320, 200, 2025, 1, 2, usetvref=0, costfct=1)
     flow_case("op3_rgb_192x96_l1", 192, 96, 2026, 3, 3, costfct=1, max_iter=6, min_iter=6)
+    mode_case("fbcon_gray_256x128", 256, 128, 2027, 1, 2, usefbcon=1)
+    mode_case("fbcon_rgb_192x96", 192, 96, 2028, 3, 3, usefbcon=1, max_iter=6, min_iter=6)
+    mode_case("stereo_gray_256x128", 256, 128, 2029, 1, 2, swap=True, selectmode=2)
+    mode_case("stereo_rgb_192x96", 192, 96, 2030, 3, 3, swap=True, selectmode=2, max_iter=6, min_iter=6)

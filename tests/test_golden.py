@@ -121,6 +121,34 @@ def test_hip_reproduces_golden_flow(gpu, name):
     assert mean * (1 << p.sc_l) < 1e-3, (mean, mx, frac)   # north-star tolerance vs the sequential-sum build
 
 
+MODE_CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(HERE, "golden", "mode_*.npz")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MODE_CASES)
+def test_hip_reproduces_golden_modes(gpu, name):
+    """Forward-backward merging and stereo depth against vectors produced by the reference compiled in those modes
+    (tests/golden/make_golden.py): needs neither /root/reference nor oracle/_ref."""
+    z, p = load_case(name)
+    ia, ib = z["img_a"], z["img_b"]
+    ho, wo = ia.shape[:2]
+    b = gpu.Batch(p, 2)
+    da, db = gpu.Dev(np.stack([ia] * 2)), gpu.Dev(np.stack([ib] * 2))
+    b.build_pyramids_u8(da.ptr, db.ptr, wo, ho)   # also exercises the second image's gradient pyramid (usefbcon)
+    b.run()
+    out = b.download_all()
+    b.close()
+    for s in range(2):
+        assert_bits_equal(out[s], z["flow_w64"], f"{name} slot {s}")
+    if "flow_seq" in z.files:
+        d = np.sqrt(((out[0].astype(np.float64) - z["flow_seq"]) ** 2).sum(-1)).mean()
+        assert d * (1 << p.sc_l) < 1e-3, d            # any summation order lands within the north-star tolerance
+
+
+def test_golden_mode_vectors_are_present():
+    assert len(MODE_CASES) == 4, MODE_CASES
+
+
 @pytest.mark.gpu
 def test_hip_reproduces_golden_kernels(gpu):
     z = np.load(os.path.join(HERE, "golden", "fdf_kernels.npz"))
