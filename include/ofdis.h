@@ -61,7 +61,7 @@ typedef struct ofdis_params {
   int   selectmode;         /* the reference's compile-time SELECTMODE: 0 or 1 = optical flow (run_OF_*, two flow
                              * channels), 2 = stereo depth (run_DE_*: ONE channel = horizontal displacement <= 0,
                              * patch.cpp:188-193, refine_variational.cpp:245-336).  Every flow array below then has
-                             * one float per pixel instead of two.  usefbcon is not available in mode 2. */
+                             * one float per pixel instead of two. */
 } ofdis_params;
 
 /* Fill `p` with the reference's operating point 1..4 for an image of `width_org` columns

@@ -79,8 +79,7 @@ int check_params(const ofdis_params* p) {
     return fail(OFDIS_ERR_INVALID, "coarsest level must have >= 4 rows for the TV derivative filter (image.c:401-434)");
   if (p->max_iter < 0 || p->tv_innerit < 0 || p->tv_solverit < 0) return fail(OFDIS_ERR_INVALID, "negative iteration count");
   if (p->selectmode < 0 || p->selectmode > 2) return fail(OFDIS_ERR_INVALID, "selectmode must be 0/1 (optical flow) or 2 (stereo depth)");
-  if (p->selectmode == 2 && p->usefbcon)
-    return fail(OFDIS_ERR_UNSUPPORTED, "forward-backward merging is not available in stereo-depth mode");
+
   return OFDIS_OK;
 }
 
@@ -261,7 +260,7 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
 // VarRefClass::RefLevelDE (refine_variational.cpp:245-336), stereo-depth mode: b->wx holds the densified horizontal
 // displacement (row-major), b->wy zeros; the refined plane goes to flow_out ([B][h][w], one channel).
 int run_varref_de(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow_out,
-                  hipStream_t s) {
+                  hipStream_t s, int camlr = 0) {
   const ofdis_params& p = b->p;
   TvGeom t{g.w, g.h, g.noc, b->nframes};
   const size_t n = (size_t)g.w * g.h * b->nframes;
@@ -293,7 +292,7 @@ int run_varref_de(ofdis_batch* b, const LevelGeom& g, const float* im_a, const f
     }
     {
       KTimer kt(b, OFDIS_K_UPDATE, s);
-      HIPCHK(launch_de_update(t, b->wx, b->du, b->uu, nullptr, 0, s));  // camlr == 0 (cpt = left camera)
+      HIPCHK(launch_de_update(t, b->wx, b->du, b->uu, nullptr, camlr, s));  // min / max with 0 by camera side
     }
   }
   HIPCHK(hipMemcpyAsync(flow_out, b->uu, n * sizeof(float), hipMemcpyDeviceToDevice, s));   // wx = uu (:318)
@@ -654,6 +653,7 @@ int run_levels(ofdis_batch* b, hipStream_t s) {
         a.flow_prev = (sl < p.sc_f) ? b->flow_bw[ii + 1] : nullptr;
         a.p_out = b->pvec_bw;
         a.pweight = b->pweight_bw;
+        a.camlr = 1;  // the backward grid is the right camera: displacement >= 0 (oflow.cpp:155-156, patch.cpp:191-192)
         HIPCHK(launch_patch_optimize(a, s));
       }
     }
@@ -690,6 +690,13 @@ int run_levels(ofdis_batch* b, hipStream_t s) {
     if (p.usetvref && p.selectmode == 2) {
       int rc = run_varref_de(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s);
       if (rc) return rc;
+      if (bw_flow) {  // backward direction: right camera, its densified plane waits in flow_bw (one channel)
+        const size_t n = (size_t)g.w * g.h * b->nframes;
+        HIPCHK(hipMemcpyAsync(b->wx, b->flow_bw[ii], n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemsetAsync(b->wy, 0, n * sizeof(float), s));
+        rc = run_varref_de(b, g, b->in[3][ii], b->in[0][ii], b->flow_bw[ii], s, 1);
+        if (rc) return rc;
+      }
     } else if (p.usetvref) {
       int rc = run_varref(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s);
       if (rc) return rc;

@@ -78,3 +78,17 @@ def test_stereo_flow_bit_exact(gpu, size, noc, opp, tv):
     assert out.shape[-1] == 1 and full.shape == (3, size[1], size[0], 1)
     for k in range(3):
         assert_bits_equal(out[k], ref, f"batch frame {k}")
+
+
+@pytest.mark.parametrize("size,noc,opp,tv", [((640, 480), 1, 2, 1), ((333, 251), 1, 1, 0), ((320, 240), 3, 3, 1)])
+def test_stereo_forward_backward(gpu, size, noc, opp, tv):
+    """usefbcon in stereo mode: the backward grid is the right camera (displacement >= 0, patch.cpp:191-192,
+    refine_variational.cpp:308-315), merged one-channel splats (patchgrid.cpp:366-371)."""
+    p, pa, pb = _case(size[0], size[1], 93, noc, opp, tv)
+    p = p.copy(usefbcon=1)
+    R = _ref(noc)
+    ref = R.flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
+    plain = R.flow(p.copy(usefbcon=0), pa[0], pa[1], pa[2], pb[0])
+    assert not np.array_equal(ref, plain)
+    got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
+    assert_bits_equal(got, ref, "stereo + usefbcon vs reference sources")
