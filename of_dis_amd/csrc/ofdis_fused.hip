@@ -93,8 +93,10 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
 // are added unconditionally: x + (+-0 * finite) == x bit for bit unless x is -0, and none of the accumulators
 // can be -0 at that point (b1, b2 start at +0 and only ever add/subtract, which never yields -0 from +0; the
 // neighbour sums end with "+ b").  "finite" holds because every lane always works on real pixels: before its
-// first and after its last column a lane computes wrapped columns of real data whose results are not stored,
-// and the slot ring starts with a unit diagonal.
+// first and after its last column a lane computes wrapped columns of real data whose results are not stored;
+// every such system has at least one positive edge weight (quarter_alpha > 0 is a launch condition, a pixel is
+// never first and last column at once), so det >= (sum of weights)^2 > 0; the slot ring starts with a unit
+// diagonal and unit weights.
 template <int NS, bool BRIGHT>
 __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const int R) {
   constexpr int U = 6;
@@ -144,7 +146,10 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
   float uu[3], vv[3], sm[3];
   FSlot slot[6];
 #pragma unroll
-  for (int r = 0; r < 6; ++r) { W[r] = FRow{0, 0, 0, 0}; slot[r] = FSlot{1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0}; }
+  // Fill-phase slots: unit diagonal AND unit edge weights.  The first slot a lane produces takes its left / top weights
+  // from these; with zeros, a lane whose first fill pixel is a last-column pixel of the last image row (w == h) had all
+  // four weights and (derivative ring still empty) the whole system zero: det = 0, NaN, and 0 * NaN poisoned the row.
+  for (int r = 0; r < 6; ++r) { W[r] = FRow{0, 0, 0, 0}; slot[r] = FSlot{1, 0, 1, 0, 0, 1, 1, 0, 0, 0, 0}; }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     uu[r] = vv[r] = 0.0f;
@@ -321,7 +326,7 @@ bool tv_fused_supported(const TvGeom& t, int iterations) {
 
 bool tv_fused_params_ok(float qa, float hd3, float hg3) {
   auto ok = [](float v) { return v == 0.0f || (v >= 1e-12f && v <= 1e12f); };
-  return ok(qa) && ok(hd3) && ok(hg3);
+  return qa > 0.0f && ok(qa) && ok(hd3) && ok(hg3);  // qa == 0: no smoothness at all, singular systems possible
 }
 
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s) {

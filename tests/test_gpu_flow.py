@@ -256,3 +256,69 @@ def test_baseline_config4_rgb_1080p(gpu, orc):
     ref = orc.flow(p, pa[0], pa[1], pa[2], pb[0])
     got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
     assert_bits_equal(got, ref, "config 4")
+
+
+def _random_config(rng):
+    noc = int(rng.choice([1, 1, 3]))
+    P = int(rng.choice([4, 6, 8, 8, 10, 12]))
+    sc_l = int(rng.integers(0, 3))
+    sc_f = sc_l + int(rng.integers(0, 3))
+    mult = 1 << sc_f
+    # level sizes must leave >= 4 rows at the coarsest level (TV derivative filter) and a few patches
+    w = int(rng.integers(5, 14)) * mult + int(rng.integers(0, mult))
+    h = int(rng.integers(4, 10)) * mult + int(rng.integers(0, mult))
+    if rng.random() < 0.35:           # larger frames: finest levels above 64 rows (multi-wave / tiled solver paths)
+        w, h = w * 3 + int(rng.integers(0, 7)), h * 4 + int(rng.integers(0, 7))
+    w, h = max(w, 5 * mult), max(h, 4 * mult)
+    over = dict(sc_f=sc_f, sc_l=sc_l, p_samp_s=P, imgpadding=P, patove=float(rng.choice([0.0, 0.3, 0.4, 0.55, 0.75, 0.9])),
+                max_iter=int(rng.integers(1, 9)), costfct=int(rng.integers(0, 3)), patnorm=int(rng.integers(0, 2)),
+                usetvref=int(rng.integers(0, 2)), tv_innerit=int(rng.integers(1, 3)), tv_solverit=int(rng.integers(1, 5)),
+                tv_sor=float(rng.choice([1.0, 1.6, 1.9])), tv_alpha=float(rng.choice([3.0, 10.0, 25.0])),
+                tv_delta=float(rng.choice([0.0, 5.0])), res_thresh=float(rng.choice([0.0, 0.0, 1.5])),
+                dp_thresh=float(rng.choice([0.05, 0.2])), dr_thresh=float(rng.choice([0.95, 0.7])))
+    over["min_iter"] = int(rng.integers(0, over["max_iter"] + 1))
+    return w, h, noc, over
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configurations(gpu, orc, seed):
+    """Seeded random draws over the whole parameter space of the constructor (patch size, overlap, pyramid range,
+    channels, cost function, early-termination thresholds, TV settings, odd image sizes): every kernel variant
+    (lanes per patch, masked / full patches, fused / tiled / multi-wave / serial solvers) against the restatement."""
+    import gen_synth
+    from of_dis_amd.params import oppoint, padded_size
+    rng = np.random.default_rng(7000 + seed)
+    w, h, noc, over = _random_config(rng)
+    ia, ib, _ = gen_synth.make_pair(w, h, 7100 + seed, noc)
+    p = oppoint(2, w, h, noc=noc).copy(**over)
+    p.width, p.height = padded_size(w, h, p.sc_f)
+    pa, pb = orc.build_pyramid(p, ia), orc.build_pyramid(p, ib)
+    ref = orc.flow(p, pa[0], pa[1], pa[2], pb[0])
+    got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
+    assert_bits_equal(got, ref, f"seed {seed}: {w}x{h} noc={noc} {over}")
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_configurations_modes(gpu, seed):
+    """The same random draws with forward-backward merging (even seeds) or in stereo-depth mode (odd seeds; every
+    fourth with both), against the reference compiled in that mode."""
+    import gen_synth
+    from of_dis_amd.params import oppoint, padded_size
+    rng = np.random.default_rng(9000 + seed)
+    w, h, noc, over = _random_config(rng)
+    stereo = seed % 2 == 1
+    over["usefbcon"] = 1 if (not stereo or seed % 4 == 3) else 0
+    over["selectmode"] = 2 if stereo else 0
+    kind = ("de_" if stereo else "") + ("int" if noc == 1 else "rgb")
+    if not oracle.have_ref(kind, True):
+        pytest.skip("oracle/_ref not built")
+    ia, ib, _ = gen_synth.make_pair(w, h, 9100 + seed, noc)
+    if stereo:
+        ia, ib = ib, ia
+    p = oppoint(2, w, h, noc=noc).copy(**over)
+    p.width, p.height = padded_size(w, h, p.sc_f)
+    O = oracle.c_oracle()
+    pa, pb = O.build_pyramid(p, ia), O.build_pyramid(p, ib)
+    ref = oracle.ref(kind, True).flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
+    got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
+    assert_bits_equal(got, ref, f"seed {seed}: {w}x{h} noc={noc} {over}")

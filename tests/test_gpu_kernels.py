@@ -204,3 +204,21 @@ def test_varref_parameter_variants(gpu, orc, alpha, gamma, delta, innerit, solve
         ref = orc.varref_level(p, l, pa[0][l], pb[0][l], flow)
         got = gpu.varref_level(p, l, pa[0][l][None], pb[0][l][None], flow[None])
         assert_bits_equal(got[0], ref, f"varref level {l}")
+
+
+@pytest.mark.parametrize("w,h", [(38, 38), (64, 64), (56, 56), (24, 24), (16, 16), (40, 38), (36, 40), (17, 33), (64, 60)])
+def test_varref_square_and_near_square_levels(gpu, orc, w, h):
+    """The fused TV kernel's fill phase once produced an all-zero system (0/0) for the lane whose first fill pixel is a
+    last-column pixel of the last image row -- exactly when w == h -- and 0 * NaN then poisoned that row."""
+    import gen_synth
+    from of_dis_amd.params import oppoint
+    ia, ib, _ = gen_synth.make_pair(w, h, 5, 1)
+    rng = np.random.default_rng(w * 100 + h)
+    for innerit, solverit in ((1, 1), (2, 3)):
+        p = oppoint(2, w, h).copy(sc_f=0, sc_l=0, p_samp_s=4, imgpadding=4, tv_innerit=innerit, tv_solverit=solverit)
+        p.width, p.height = w, h
+        pa, pb = orc.build_pyramid(p, ia), orc.build_pyramid(p, ib)
+        flow = rand_planes(rng, h, w, 2, scale=1.0)
+        ref = orc.varref_level(p, 0, pa[0][0], pb[0][0], flow)
+        got = gpu.varref_level(p, 0, pa[0][0][None], pb[0][0][None], flow[None])
+        assert_bits_equal(got[0], ref, f"varref {w}x{h} innerit={innerit} solverit={solverit}")
