@@ -322,3 +322,40 @@ def test_random_configurations_modes(gpu, seed):
     ref = oracle.ref(kind, True).flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
     got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
     assert_bits_equal(got, ref, f"seed {seed}: {w}x{h} noc={noc} {over}")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_batches_from_u8(gpu, orc, seed):
+    """Random batch sizes (frames per wavefront groups, XCD block mapping and the last partial groups are all
+    batch-size dependent), odd frame sizes, on-device pyramid from 8-bit frames, optional pipelining, full-resolution
+    result: every frame against the restatement run on the oracle's host pyramid."""
+    import gen_synth
+    from of_dis_amd.params import oppoint, padded_size
+    rng = np.random.default_rng(15000 + seed)
+    noc = 3 if seed % 4 == 3 else 1
+    w, h = int(rng.integers(90, 400)), int(rng.integers(70, 300))
+    nfr = int(rng.integers(1, 14))
+    opp = int(rng.choice([1, 2, 3])) if noc == 1 else 3
+    p = oppoint(opp, w, h, noc=noc)
+    p.width, p.height = padded_size(w, h, p.sc_f)
+    frames = [gen_synth.make_pair(w, h, 15100 + 20 * seed + k, noc)[:2] for k in range(min(nfr, 3))]
+    order = [int(rng.integers(0, len(frames))) for _ in range(nfr)]
+    ia = np.stack([frames[k][0] for k in order])
+    ib = np.stack([frames[k][1] for k in order])
+    b = gpu.Batch(p, nfr)
+    if seed % 2:
+        b.set_pipeline(2 + seed % 3)
+    da, db = gpu.Dev(ia), gpu.Dev(ib)
+    b.build_pyramids_u8(da.ptr, db.ptr, w, h)
+    b.run()
+    b.run()
+    out = b.download_all()
+    full = b.upsample(w, h)
+    b.close()
+    refs = []
+    for fa, fb in frames:
+        pa, pb = orc.build_pyramid(p, fa), orc.build_pyramid(p, fb)
+        refs.append(orc.flow(p, pa[0], pa[1], pa[2], pb[0]))
+    for slot, k in enumerate(order):
+        assert_bits_equal(out[slot], refs[k], f"seed {seed} slot {slot}/{nfr} (frame {k}) {w}x{h} op{opp} noc={noc}")
+        assert_bits_equal(full[slot], orc.upsample_crop(p, refs[k], w, h), f"seed {seed} slot {slot} full resolution")

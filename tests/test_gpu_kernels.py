@@ -222,3 +222,57 @@ def test_varref_square_and_near_square_levels(gpu, orc, w, h):
         ref = orc.varref_level(p, 0, pa[0][0], pb[0][0], flow)
         got = gpu.varref_level(p, 0, pa[0][0][None], pb[0][0][None], flow[None])
         assert_bits_equal(got[0], ref, f"varref {w}x{h} innerit={innerit} solverit={solverit}")
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_varref_levels(gpu, orc, seed):
+    """Random level geometry (mostly in the fused kernel's range: gray, 2 <= h <= 64, w >= 16; some outside it and some
+    RGB), random TV parameters and a random incoming flow with out-of-image displacements."""
+    import gen_synth
+    from of_dis_amd.params import oppoint
+    rng = np.random.default_rng(12000 + seed)
+    noc = 3 if seed % 6 == 5 else 1
+    w = int(rng.integers(16, 140)) if seed % 5 else int(rng.integers(5, 16))
+    h = int(rng.integers(4, 65)) if seed % 7 else int(rng.integers(65, 150))
+    if seed % 9 == 0:
+        h = w = int(rng.integers(16, 65))
+    ia, ib, _ = gen_synth.make_pair(w, h, 12100 + seed, noc)
+    p = oppoint(2, w, h, noc=noc).copy(sc_f=0, sc_l=0, p_samp_s=4, imgpadding=4,
+                                       tv_innerit=int(rng.integers(1, 4)), tv_solverit=int(rng.integers(1, 5)),
+                                       tv_sor=float(rng.choice([1.0, 1.6, 1.95])), tv_alpha=float(rng.choice([1.0, 10.0, 40.0])),
+                                       tv_gamma=float(rng.choice([0.0, 10.0, 20.0])), tv_delta=float(rng.choice([0.0, 5.0, 15.0])))
+    p.width, p.height = w, h
+    pa, pb = orc.build_pyramid(p, ia), orc.build_pyramid(p, ib)
+    flow = rand_planes(rng, h, w, 2, scale=float(rng.choice([0.2, 1.5, 6.0])))
+    flow[rng.integers(0, h), rng.integers(0, w)] = (3.0 * w, -3.0 * h)      # far outside: mask 0, clamped taps
+    ref = orc.varref_level(p, 0, pa[0][0], pb[0][0], flow)
+    got = gpu.varref_level(p, 0, pa[0][0][None], pb[0][0][None], flow[None])
+    assert_bits_equal(got[0], ref, f"seed {seed}: {w}x{h} noc={noc} innerit={p.tv_innerit} solverit={p.tv_solverit}")
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_patchgrid_levels(gpu, orc, seed):
+    """Random patch size / overlap / iteration limits / cost function at one level with a random coarse flow that
+    sends some patches out of bounds at the start and others over the outlier threshold."""
+    import gen_synth
+    from of_dis_amd.params import oppoint
+    rng = np.random.default_rng(13000 + seed)
+    noc = 3 if seed % 4 == 3 else 1
+    P = int(rng.choice([4, 8, 8, 8, 12, 6]))
+    w, h = int(rng.integers(3 * P, 120)), int(rng.integers(3 * P, 90))
+    w, h = w - w % 2, h - h % 2                                              # a coarser level of half the size exists
+    ia, ib, _ = gen_synth.make_pair(w, h, 13100 + seed, noc)
+    p = oppoint(2, w, h, noc=noc).copy(sc_f=0, sc_l=0, p_samp_s=P, imgpadding=P, patove=float(rng.choice([0.0, 0.4, 0.75])),
+                                       max_iter=int(rng.integers(1, 14)), costfct=int(rng.integers(0, 3)),
+                                       patnorm=int(rng.integers(0, 2)), res_thresh=float(rng.choice([0.0, 2.0])),
+                                       dp_thresh=float(rng.choice([0.05, 0.3])), dr_thresh=float(rng.choice([0.95, 0.6])))
+    p.min_iter = int(rng.integers(0, p.max_iter + 1))
+    p.width, p.height = w, h
+    pa, pb = orc.build_pyramid(p, ia), orc.build_pyramid(p, ib)
+    prev = rand_planes(rng, h // 2, w // 2, 2, scale=float(rng.choice([0.3, 2.0, 8.0])))
+    prev[0, 0] = (-2.0 * w, 0.0)
+    prev[-1, -1] = (w, h)
+    rp, rflow = orc.patchgrid_level(p, 0, pa[0][0], pa[1][0], pa[2][0], pb[0][0], prev)
+    gp, gflow = gpu.patchgrid_level(p, 0, pa[0][0][None], pa[1][0][None], pa[2][0][None], pb[0][0][None], prev[None])
+    assert_bits_equal(gp[0], rp, f"seed {seed}: patch displacements {w}x{h} P={P} noc={noc}")
+    assert_bits_equal(gflow[0], rflow, f"seed {seed}: dense flow")
