@@ -207,6 +207,7 @@ def main():
 
     def step():
         if e2e:  # secondary scope: raw frames -> pyramids -> path -> full-resolution flow, everything in HBM
+            batch.join(stream)  # a pipelined sub-batch of the previous step may still be reading the pyramids
             batch.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
         batch.run(stream)
         if e2e:
