@@ -174,6 +174,11 @@ def main():
     rank, world, local_rank = shard.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
+    # developer switches for exercising the multi-rank control flow on a one-GPU box (tests only; the driver's
+    # launch uses one GPU per rank over RCCL): all ranks on device 0, gloo instead of nccl
+    backend = os.environ.get("OFDIS_BENCH_BACKEND", "nccl")
+    if os.environ.get("OFDIS_BENCH_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     L = capi.lib()
     capi.check(L.ofdis_set_device(local_rank))
@@ -181,8 +186,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the max-over-ranks tensor lives
 
     def barrier():
         shard.barrier(dist, torch.cuda.synchronize)
@@ -221,7 +230,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, dist, dev)
+    elapsed = shard.max_over_ranks(elapsed, dist, red_dev)
     fps = shard.throughput([B] * world, args.steps, elapsed)
 
     result = None

@@ -98,3 +98,26 @@ def test_two_ranks_gloo(tmp_path):
         ia, ib, _ = gen_synth.make_pair(256, 128, shard.frame_seed(1234, g))
         pa, pb = O.build_pyramid(p, ia), O.build_pyramid(p, ib)
         assert np.array_equal(got[g], O.flow(p, pa[0], pa[1], pa[2], pb[0])), g
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_control_flow(gpu):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), on a
+    one-GPU box: both ranks share device 0 and rendezvous over gloo (developer switches in bench.py) -- the barrier /
+    max-over-ranks / rank-0 report path is the one the RCCL run takes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OFDIS_BENCH_BACKEND="gloo", OFDIS_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch", "64", "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_frames_per_step"] == 128
+    assert d["parity_check"].startswith("bit-exact")
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
