@@ -359,3 +359,13 @@ def test_random_batches_from_u8(gpu, orc, seed):
     for slot, k in enumerate(order):
         assert_bits_equal(out[slot], refs[k], f"seed {seed} slot {slot}/{nfr} (frame {k}) {w}x{h} op{opp} noc={noc}")
         assert_bits_equal(full[slot], orc.upsample_crop(p, refs[k], w, h), f"seed {seed} slot {slot} full resolution")
+
+
+@pytest.mark.parametrize("env", ["OFDIS_NO_GRAY8", "OFDIS_NO_FUSED"])
+def test_fallback_kernels_at_the_benchmark_geometry(gpu, orc, monkeypatch, env):
+    """The generic patch kernel (8 lanes per patch) and the unfused TV path (tiled system kernel + wavefront SOR) must
+    give the same bits as the specialised kernels they stand in for; the switches exist for this test."""
+    monkeypatch.setenv(env, "1")
+    p, pa, pb, _, _ = synth_case(1024, 436, 1600, 1, 2, 1)
+    got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
+    assert_bits_equal(got, orc.flow(p, pa[0], pa[1], pa[2], pb[0]), f"{env}=1")
