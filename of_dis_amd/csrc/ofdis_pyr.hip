@@ -33,6 +33,18 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(const uint8_t* __restrict
     const int f = (int)(r / h);
     const uint8_t* s = src + (size_t)f * wo * ho * noc;
     unsigned sum = 0;
+    // fast path (gray, block of at least 4 columns entirely inside the frame, 4-byte aligned rows): whole words,
+    // v_sad_u8 against 0 adds the four bytes of a word in one instruction; neighbouring threads read neighbouring words
+    const int bx0 = x * bs - left, by0 = y * bs - top;
+    if (noc == 1 && bs >= 4 && ((wo | bx0) & 3) == 0 && bx0 >= 0 && bx0 + bs <= wo && by0 >= 0 && by0 + bs <= ho &&
+        (((size_t)f * wo * ho) & 3) == 0 && ((uintptr_t)src & 3) == 0) {
+      const unsigned* s32 = reinterpret_cast<const unsigned*>(s + (size_t)by0 * wo + bx0);
+      const int wpr = wo >> 2;
+      for (int yy = 0; yy < bs; ++yy)
+        for (int q = 0; q < (bs >> 2); ++q) sum = __builtin_amdgcn_sad_u8(s32[(size_t)yy * wpr + q], 0u, sum);
+      dst[idx] = (float)sum * scale;
+      continue;
+    }
     for (int yy = 0; yy < bs; ++yy) {
       const int sy = clampi(y * bs + yy - top, 0, ho - 1);
       for (int xx = 0; xx < bs; ++xx) {
