@@ -984,6 +984,9 @@ int ofdis_test_wave_sum(const float* in, float* out, int n, void* stream) {
   return OFDIS_OK;
 }
 
+// test hook (not declared in ofdis.h; host only, needs no GPU): the squared outlier threshold of the patch kernels
+float ofdis_test_outlier_sq(float t) { return outlier_sq_threshold(t); }
+
 // test hook (not declared in ofdis.h): trimmed divide / sqrt next to the compiler's IEEE expansion
 int ofdis_test_div_sqrt(const float* a, const float* b, float* out, int n, void* stream) {
   HIPCHK(launch_div_sqrt_test(a, b, out, n, (hipStream_t)stream));

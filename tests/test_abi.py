@@ -106,3 +106,20 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libofdis_hip.so")
     with pytest.raises(capi.OfdisError):
         capi.lib()
+
+
+def test_outlier_threshold_is_the_exact_square_root_boundary():
+    """The patch kernels test ||d||^2 > X instead of sqrt(||d||^2) > t (patch.cpp:199): X must be the largest float
+    whose correctly rounded square root is <= t, for every patch size's t = P/2 and for awkward values."""
+    import numpy as np
+    L = capi.lib()
+    L.ofdis_test_outlier_sq.restype = C.c_float
+    L.ofdis_test_outlier_sq.argtypes = [C.c_float]
+    f32 = np.float32
+    for t in [1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 13.0, 0.1, 0.7, 1e-3, 123.456, 3.4e18, 1e-19, 0.0]:
+        t = f32(t)
+        X = f32(L.ofdis_test_outlier_sq(t))
+        up = np.nextafter(X, f32(np.inf))
+        assert np.sqrt(X) <= t, (t, X)
+        assert np.sqrt(up) > t, (t, X, up)
+    assert np.isnan(L.ofdis_test_outlier_sq(float("nan")))
