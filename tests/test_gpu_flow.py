@@ -15,6 +15,9 @@ CASES = [
     pytest.param((1024, 436), 1, 0, id="op1-1024x436"),
 ]
 
+# ad-hoc campaigns: OFDIS_TEST_SEED_OFFSET=<n> shifts every seeded random draw below
+_SEED_OFFSET = int(__import__("os").environ.get("OFDIS_TEST_SEED_OFFSET", "0"))
+
 
 @pytest.mark.parametrize("size,opp,tv", CASES)
 def test_flow_dropin_bit_exact(gpu, orc, size, opp, tv):
@@ -287,7 +290,7 @@ def test_random_configurations(gpu, orc, seed):
     (lanes per patch, masked / full patches, fused / tiled / multi-wave / serial solvers) against the restatement."""
     import gen_synth
     from of_dis_amd.params import oppoint, padded_size
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(7000 + seed + _SEED_OFFSET)
     w, h, noc, over = _random_config(rng)
     ia, ib, _ = gen_synth.make_pair(w, h, 7100 + seed, noc)
     p = oppoint(2, w, h, noc=noc).copy(**over)
@@ -304,7 +307,7 @@ def test_random_configurations_modes(gpu, seed):
     fourth with both), against the reference compiled in that mode."""
     import gen_synth
     from of_dis_amd.params import oppoint, padded_size
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(9000 + seed + _SEED_OFFSET)
     w, h, noc, over = _random_config(rng)
     stereo = seed % 2 == 1
     over["usefbcon"] = 1 if (not stereo or seed % 4 == 3) else 0
@@ -331,7 +334,7 @@ def test_random_batches_from_u8(gpu, orc, seed):
     result: every frame against the restatement run on the oracle's host pyramid."""
     import gen_synth
     from of_dis_amd.params import oppoint, padded_size
-    rng = np.random.default_rng(15000 + seed)
+    rng = np.random.default_rng(15000 + seed + _SEED_OFFSET)
     noc = 3 if seed % 4 == 3 else 1
     w, h = int(rng.integers(90, 400)), int(rng.integers(70, 300))
     nfr = int(rng.integers(1, 14))

@@ -12,6 +12,9 @@ from common import assert_bits_equal, rand_planes, synth_case
 pytestmark = pytest.mark.gpu
 _f32 = np.float32
 
+# ad-hoc campaigns: OFDIS_TEST_SEED_OFFSET=<n> shifts every seeded random draw below
+_SEED_OFFSET = int(__import__("os").environ.get("OFDIS_TEST_SEED_OFFSET", "0"))
+
 
 def test_wave_sum_order(gpu, orc):
     rng = np.random.default_rng(0)
@@ -230,7 +233,7 @@ def test_random_varref_levels(gpu, orc, seed):
     RGB), random TV parameters and a random incoming flow with out-of-image displacements."""
     import gen_synth
     from of_dis_amd.params import oppoint
-    rng = np.random.default_rng(12000 + seed)
+    rng = np.random.default_rng(12000 + seed + _SEED_OFFSET)
     noc = 3 if seed % 6 == 5 else 1
     w = int(rng.integers(16, 140)) if seed % 5 else int(rng.integers(5, 16))
     h = int(rng.integers(4, 65)) if seed % 7 else int(rng.integers(65, 150))
@@ -256,7 +259,7 @@ def test_random_patchgrid_levels(gpu, orc, seed):
     sends some patches out of bounds at the start and others over the outlier threshold."""
     import gen_synth
     from of_dis_amd.params import oppoint
-    rng = np.random.default_rng(13000 + seed)
+    rng = np.random.default_rng(13000 + seed + _SEED_OFFSET)
     noc = 3 if seed % 4 == 3 else 1
     P = int(rng.choice([4, 8, 8, 8, 12, 6]))
     w, h = int(rng.integers(3 * P, 120)), int(rng.integers(3 * P, 90))
