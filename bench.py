@@ -275,7 +275,7 @@ def main():
                             "(profiles/traffic.json). The two dominant kernels (tv_fused, patch_optimize) are VALU-issue "
                             "bound (PMC: profiles/*pmc_sq*), not HBM bound; see DESIGN.md section 4"}
         result = {
-            "metric": "frames/sec at 1024x436 op-point-2 (INT)", "value": round(fps, 1), "unit": "frames/s",
+            "metric": "frames/sec at 1024\u00d7436 op-point-2 (INT)", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -308,6 +308,27 @@ def main():
                     "MISMATCH vs oracle: mean EPE %.3g" % oracle.epe_stats(ref, got)[0]
             except Exception as e:  # the checker is optional for the measurement
                 result["parity_check"] = f"not run ({type(e).__name__}: {e})"
+        if world == 1 and tv and not e2e:
+            # BASELINE.json also lists the same operating point with the refinement switched off (configs[1]); report it
+            # next to the headline (configs[2], TV on -- what operating point 2 is in the reference, run_dense.cpp:259-265)
+            try:
+                p_off = oppoint(2, WIDTH, HEIGHT, noc=1, usetvref=False, verbosity=0)
+                b_off = capi.Batch(p_off, B)
+                b_off.set_pipeline(args.pipeline)
+                b_off.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
+                for _ in range(args.warmup):
+                    b_off.run(stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    b_off.run(stream)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                b_off.close()
+                result["tv_off"] = {"workload": "same, TV off (BASELINE.json configs[1])", "value": round(B * args.steps / dt, 1),
+                                    "unit": "frames/s", "ms_per_step": round(dt / args.steps * 1e3, 4)}
+            except Exception as e:
+                result["tv_off"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.cpu_seconds > 0:
             try:
                 result["cpu_baseline"] = cpu_baseline(p, batch, min(16, B), args.cpu_seconds)
