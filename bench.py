@@ -130,8 +130,18 @@ def cpu_baseline(p, batch, nsample, budget_s):
                 planes[k][l] = arr
         frames.append(planes)
     pq = p.copy(verbosity=0)
-    for planes in frames[:2]:  # warm-up
-        R.flow(pq, planes[0], planes[1], planes[2], planes[3])
+    # the metric's second half: end-point error of the HIP result against the reference's own output (its plain,
+    # sequential-sum build -- NOT the defined-order build the bit-exact check uses), in full-resolution pixels: the
+    # .flo is this flow times 2^sc_l before an interpolation that cannot increase a difference
+    err = []
+    for f, planes in enumerate(frames):  # also the warm-up
+        ref = R.flow(pq, planes[0], planes[1], planes[2], planes[3])
+        got = batch.download(f)
+        err.append(np.sqrt(((got.astype(np.float64) - ref.astype(np.float64)) ** 2).sum(-1)) * (1 << p.sc_l))
+    err = np.stack(err)
+    epe = {"mean_px": float(err.mean()), "max_px": float(err.max()), "frac_above_1e-3": float((err > 1e-3).mean()),
+           "frames": len(frames), "against": "reference CPU build with sequential sums" if kind == "reference"
+           else "C restatement with sequential sums"}
     n_eval, t0 = 0, time.perf_counter()
     best = 1e9
     while True:
@@ -144,7 +154,7 @@ def cpu_baseline(p, batch, nsample, budget_s):
             break
     el = time.perf_counter() - t0
     return {"value": round(n_eval / el, 2), "unit": "frames/s", "cores": 1, "kind": kind,
-            "best_ms_per_frame": round(best * 1e3, 4),
+            "best_ms_per_frame": round(best * 1e3, 4), "epe_vs_reference": epe,
             "sample": f"{n_eval} OFClass-scope evaluations over {nsample} distinct frames of this batch, "
                       f"{el:.1f} s on one of {os.cpu_count()} host cores"}
 
