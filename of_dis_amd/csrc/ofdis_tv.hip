@@ -61,45 +61,62 @@ __device__ __forceinline__ void nt_store(f4 v, f4* p) { __builtin_nontemporal_st
 __device__ __forceinline__ f4 nt_load(const f4* p) { return *p; }
 __device__ __forceinline__ void nt_store(f4 v, f4* p) { *p = v; }
 #endif
+// grid = (blocks per frame, frame): no 64-bit index arithmetic; a thread walks its frame in steps of the block row and
+// requests the flow of its NEXT position before it gathers the taps of the current one (two dependent memory phases
+// per pixel otherwise serialise: flow -> tap addresses -> taps)
 template <bool PADDED, int VEC>
 __global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a) {
   const int w = a.t.w, h = a.t.h, noc = a.t.noc;
   const int npx = w * h;
-  const long long total = (long long)npx * a.t.nframes / VEC;
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
-    const long long idx = q * VEC;
-    const int frame = (int)(idx / npx);
-    const int o = (int)(idx - (long long)frame * npx);
-    const int j = o / w, i = o - j * w;
-    if constexpr (VEC == 4) {
-      const f4 fxv = nt_load(reinterpret_cast<const f4*>(a.wx + idx));
-      const f4 fyv = nt_load(reinterpret_cast<const f4*>(a.wy + idx));
-      const float4 fx = make_float4(fxv.x, fxv.y, fxv.z, fxv.w), fy = make_float4(fyv.x, fyv.y, fyv.z, fyv.w);
+  const int frame = blockIdx.y;
+  const size_t fo = (size_t)frame * npx;
+  const int nq = npx / VEC;  // VEC divides w
+  const int stride = gridDim.x * 256;
+  int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  if constexpr (VEC == 4) {
+    f4 fxv = nt_load(reinterpret_cast<const f4*>(a.wx + fo) + q);
+    f4 fyv = nt_load(reinterpret_cast<const f4*>(a.wy + fo) + q);
+    for (; q < nq; q += stride) {
+      const int qn = q + stride;
+      f4 nfx = fxv, nfy = fyv;
+      if (qn < nq) {
+        nfx = nt_load(reinterpret_cast<const f4*>(a.wx + fo) + qn);
+        nfy = nt_load(reinterpret_cast<const f4*>(a.wy + fo) + qn);
+      }
+      const int o = q * 4;
+      const int j = o / w, i = o - j * w;
       float4 m;
       float r0[3], r1[3], r2[3], r3[3];
-      warp_pixel<PADDED>(a, frame, i + 0, j, fx.x, fy.x, m.x, r0);
-      warp_pixel<PADDED>(a, frame, i + 1, j, fx.y, fy.y, m.y, r1);
-      warp_pixel<PADDED>(a, frame, i + 2, j, fx.z, fy.z, m.z, r2);
-      warp_pixel<PADDED>(a, frame, i + 3, j, fx.w, fy.w, m.w, r3);
-      nt_store((f4){m.x, m.y, m.z, m.w}, reinterpret_cast<f4*>(a.mask + idx));
+      warp_pixel<PADDED>(a, frame, i + 0, j, fxv.x, fyv.x, m.x, r0);
+      warp_pixel<PADDED>(a, frame, i + 1, j, fxv.y, fyv.y, m.y, r1);
+      warp_pixel<PADDED>(a, frame, i + 2, j, fxv.z, fyv.z, m.z, r2);
+      warp_pixel<PADDED>(a, frame, i + 3, j, fxv.w, fyv.w, m.w, r3);
+      nt_store((f4){m.x, m.y, m.z, m.w}, reinterpret_cast<f4*>(a.mask + fo + o));
       for (int c = 0; c < noc; ++c)
         nt_store((f4){r0[c], r1[c], r2[c], r3[c]}, reinterpret_cast<f4*>(a.dst + ((size_t)frame * noc + c) * npx + o));
-    } else {
+      fxv = nfx;
+      fyv = nfy;
+    }
+  } else {
+    for (; q < nq; q += stride) {
+      const int j = q / w, i = q - j * w;
       float m, r[3];
-      warp_pixel<PADDED>(a, frame, i, j, a.wx[idx], a.wy[idx], m, r);
-      a.mask[idx] = m;
-      for (int c = 0; c < noc; ++c) a.dst[((size_t)frame * noc + c) * npx + o] = r[c];
+      warp_pixel<PADDED>(a, frame, i, j, a.wx[fo + q], a.wy[fo + q], m, r);
+      a.mask[fo + q] = m;
+      for (int c = 0; c < noc; ++c) a.dst[((size_t)frame * noc + c) * npx + q] = r[c];
     }
   }
 }
 
 hipError_t launch_warp(const WarpArgs& a, hipStream_t s) {
   const bool v4 = (a.t.w % 4) == 0;
-  const long long total = (long long)a.t.w * a.t.h * a.t.nframes / (v4 ? 4 : 1);
-  long long blocks = (total + 255) / 256;
-  static const long long cap = getenv("OFDIS_WARP_GRID") ? atoll(getenv("OFDIS_WARP_GRID")) : 4096;  // 256 CUs x 16
-  if (blocks > cap) blocks = cap;  // grid-stride beyond that: several 16-byte loads in flight per thread
-  const dim3 g((unsigned)blocks), b(256);
+  if (a.t.nframes > 65535) return hipErrorInvalidValue;
+  const int nq = a.t.w * a.t.h / (v4 ? 4 : 1);
+  // about 4 positions per thread for large frames (the flow prefetch needs a next position), one block row otherwise
+  int bx = (nq + 255) / 256;
+  if (bx > 8) bx = (bx + 3) / 4;
+  const dim3 g((unsigned)bx, (unsigned)a.t.nframes), b(256);
   if (a.src_padded) {
     if (v4) hipLaunchKernelGGL((warp_kernel<true, 4>), g, b, 0, s, a);
     else hipLaunchKernelGGL((warp_kernel<true, 1>), g, b, 0, s, a);
