@@ -23,10 +23,13 @@ namespace ofdis {
 // warped value(s) and the mask; the four bilinear taps come from the frame's own padded plane, which is
 // L2-resident (41 KB at op-point 2).  VEC = pixels per thread: 4 consecutive x (16-byte loads/stores of
 // wx, wy, dst, mask) when w % 4 == 0, else 1.
-template <bool PADDED>
+// NOC is a compile-time constant so that the channel loops unroll and the taps of the (four) pixels a thread handles are
+// all requested before the first one is used; with a run-time channel count every pixel's loads were waited for in turn.
+template <bool PADDED, int NOC>
 __device__ __forceinline__ void warp_pixel(const WarpArgs& a, int frame, int i, int j, float fx, float fy, float& m,
                                            float* out /*[noc]*/) {
-  const int w = a.t.w, h = a.t.h, noc = a.t.noc;
+  const int w = a.t.w, h = a.t.h;
+  constexpr int noc = NOC;
   const float xx = i + fx;
   const float yy = j + fy;
   const int x = (int)floorf(xx), y = (int)floorf(yy);
@@ -34,6 +37,7 @@ __device__ __forceinline__ void warp_pixel(const WarpArgs& a, int frame, int i, 
   m = (xx >= 0 && xx <= (float)(w - 1) && yy >= 0 && yy <= (float)(h - 1)) ? 1.0f : 0.0f;
   const int x1 = clampi(x, 0, w - 1), x2 = clampi(x + 1, 0, w - 1);
   const int y1 = clampi(y, 0, h - 1), y2 = clampi(y + 1, 0, h - 1);
+#pragma unroll
   for (int c = 0; c < noc; ++c) {
     float s11, s12, s21, s22;
     if (PADDED) {
@@ -64,9 +68,10 @@ __device__ __forceinline__ void nt_store(f4 v, f4* p) { *p = v; }
 // grid = (blocks per frame, frame): no 64-bit index arithmetic; a thread walks its frame in steps of the block row and
 // requests the flow of its NEXT position before it gathers the taps of the current one (two dependent memory phases
 // per pixel otherwise serialise: flow -> tap addresses -> taps)
-template <bool PADDED, int VEC>
+template <bool PADDED, int VEC, int NOC>
 __global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a) {
-  const int w = a.t.w, h = a.t.h, noc = a.t.noc;
+  const int w = a.t.w, h = a.t.h;
+  constexpr int noc = NOC;
   const int npx = w * h;
   const int frame = blockIdx.y;
   const size_t fo = (size_t)frame * npx;
@@ -88,11 +93,12 @@ __global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a) {
       const int j = o / w, i = o - j * w;
       float4 m;
       float r0[3], r1[3], r2[3], r3[3];
-      warp_pixel<PADDED>(a, frame, i + 0, j, fxv.x, fyv.x, m.x, r0);
-      warp_pixel<PADDED>(a, frame, i + 1, j, fxv.y, fyv.y, m.y, r1);
-      warp_pixel<PADDED>(a, frame, i + 2, j, fxv.z, fyv.z, m.z, r2);
-      warp_pixel<PADDED>(a, frame, i + 3, j, fxv.w, fyv.w, m.w, r3);
+      warp_pixel<PADDED, NOC>(a, frame, i + 0, j, fxv.x, fyv.x, m.x, r0);
+      warp_pixel<PADDED, NOC>(a, frame, i + 1, j, fxv.y, fyv.y, m.y, r1);
+      warp_pixel<PADDED, NOC>(a, frame, i + 2, j, fxv.z, fyv.z, m.z, r2);
+      warp_pixel<PADDED, NOC>(a, frame, i + 3, j, fxv.w, fyv.w, m.w, r3);
       nt_store((f4){m.x, m.y, m.z, m.w}, reinterpret_cast<f4*>(a.mask + fo + o));
+#pragma unroll
       for (int c = 0; c < noc; ++c)
         nt_store((f4){r0[c], r1[c], r2[c], r3[c]}, reinterpret_cast<f4*>(a.dst + ((size_t)frame * noc + c) * npx + o));
       fxv = nfx;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a) {
     for (; q < nq; q += stride) {
       const int j = q / w, i = q - j * w;
       float m, r[3];
-      warp_pixel<PADDED>(a, frame, i, j, a.wx[fo + q], a.wy[fo + q], m, r);
+      warp_pixel<PADDED, NOC>(a, frame, i, j, a.wx[fo + q], a.wy[fo + q], m, r);
       a.mask[fo + q] = m;
       for (int c = 0; c < noc; ++c) a.dst[((size_t)frame * noc + c) * npx + q] = r[c];
     }
@@ -117,13 +123,20 @@ hipError_t launch_warp(const WarpArgs& a, hipStream_t s) {
   int bx = (nq + 255) / 256;
   if (bx > 8) bx = (bx + 3) / 4;
   const dim3 g((unsigned)bx, (unsigned)a.t.nframes), b(256);
+#define OFDIS_WARP_LAUNCH(P, V)                                                                          \
+  do {                                                                                                   \
+    if (a.t.noc == 1) hipLaunchKernelGGL((warp_kernel<P, V, 1>), g, b, 0, s, a);                       \
+    else hipLaunchKernelGGL((warp_kernel<P, V, 3>), g, b, 0, s, a);                                    \
+  } while (0)
+  if (a.t.noc != 1 && a.t.noc != 3) return hipErrorInvalidValue;
   if (a.src_padded) {
-    if (v4) hipLaunchKernelGGL((warp_kernel<true, 4>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((warp_kernel<true, 1>), g, b, 0, s, a);
+    if (v4) OFDIS_WARP_LAUNCH(true, 4);
+    else OFDIS_WARP_LAUNCH(true, 1);
   } else {
-    if (v4) hipLaunchKernelGGL((warp_kernel<false, 4>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((warp_kernel<false, 1>), g, b, 0, s, a);
+    if (v4) OFDIS_WARP_LAUNCH(false, 4);
+    else OFDIS_WARP_LAUNCH(false, 1);
   }
+#undef OFDIS_WARP_LAUNCH
   return hipGetLastError();
 }
 
@@ -132,12 +145,14 @@ hipError_t launch_warp(const WarpArgs& a, hipStream_t s) {
 // on the global side, conflict-free on the LDS side), processed row-major 4 px per thread so that the
 // bilinear taps stay local and the warped image is stored with 16-byte writes, and the mask is
 // transposed back through LDS.
+template <int NOC>
 __global__ __launch_bounds__(256) void warp_diag_kernel(const WarpArgs a) {
   constexpr int TW = 32, TH = 32;
   __shared__ __attribute__((aligned(16))) float wx_t[TH * TW];
   __shared__ __attribute__((aligned(16))) float wy_t[TH * TW];
   __shared__ __attribute__((aligned(16))) float m_t[TH * TW];
-  const int w = a.t.w, h = a.t.h, noc = a.t.noc;
+  const int w = a.t.w, h = a.t.h;
+  constexpr int noc = NOC;
   const int npx = w * h;
   const int tiles_x = (w + TW - 1) / TW;
   int frame, tile;
@@ -172,10 +187,11 @@ __global__ __launch_bounds__(256) void warp_diag_kernel(const WarpArgs a) {
       for (int k = 0; k < 4; ++k) {
         m[k] = 0.0f;
         r[k][0] = r[k][1] = r[k][2] = 0.0f;
-        if (x + k < w) warp_pixel<true>(a, frame, x + k, y, fxs[k], fys[k], m[k], r[k]);
+        if (x + k < w) warp_pixel<true, NOC>(a, frame, x + k, y, fxs[k], fys[k], m[k], r[k]);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) m_t[ry * TW + q4 + k] = m[k];
+#pragma unroll
       for (int c = 0; c < noc; ++c) {
         float* d = a.dst + ((size_t)frame * noc + c) * npx + (size_t)y * w + x;
         if (x + 3 < w && (w & 3) == 0) {
@@ -200,7 +216,9 @@ __global__ __launch_bounds__(256) void warp_diag_kernel(const WarpArgs a) {
 hipError_t launch_warp_diag(const WarpArgs& a, hipStream_t s) {
   if (!a.src_padded) return hipErrorInvalidValue;
   const int tiles = ((a.t.w + 31) / 32) * ((a.t.h + 31) / 32);
-  hipLaunchKernelGGL(warp_diag_kernel, dim3(((a.t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, a);
+  if (a.t.noc == 1) hipLaunchKernelGGL(warp_diag_kernel<1>, dim3(((a.t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, a);
+  else if (a.t.noc == 3) hipLaunchKernelGGL(warp_diag_kernel<3>, dim3(((a.t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, a);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
