@@ -58,77 +58,63 @@ __device__ __forceinline__ void warp_pixel(const WarpArgs& a, int frame, int i, 
 }
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-#ifdef OFDIS_WARP_NT
+// The row-major kernel streams: flow planes are read once, the warped image and the mask written once -- non-temporal
+// hints measured 4.49 -> 4.73 TB/s on 587 MB launches.  (Inside the fused-TV pipeline the flow was written by the
+// previous kernel and still sits in L2 / Infinity Cache: there the hints cost 10 %, so warp_diag_kernel does not use them.)
 __device__ __forceinline__ f4 nt_load(const f4* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void nt_store(f4 v, f4* p) { __builtin_nontemporal_store(v, p); }
-#else
-__device__ __forceinline__ f4 nt_load(const f4* p) { return *p; }
-__device__ __forceinline__ void nt_store(f4 v, f4* p) { *p = v; }
-#endif
-// grid = (blocks per frame, frame): no 64-bit index arithmetic; a thread walks its frame in steps of the block row and
-// requests the flow of its NEXT position before it gathers the taps of the current one (two dependent memory phases
-// per pixel otherwise serialise: flow -> tap addresses -> taps)
+
+// grid = (column chunks, row groups, frame), block = TX x (256/TX) threads with TX a power of two >= w/VEC (<= 256):
+// pixel coordinates come from shifts and masks -- no division, no 64-bit index arithmetic.
 template <bool PADDED, int VEC, int NOC>
-__global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a) {
+__global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a, const int tx_shift) {
   const int w = a.t.w, h = a.t.h;
   constexpr int noc = NOC;
   const int npx = w * h;
-  const int frame = blockIdx.y;
+  const int frame = blockIdx.z;
   const size_t fo = (size_t)frame * npx;
-  const int nq = npx / VEC;  // VEC divides w
-  const int stride = gridDim.x * 256;
-  int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= nq) return;
+  const int tx = threadIdx.x & ((1 << tx_shift) - 1), ty = threadIdx.x >> tx_shift;
+  const int i = ((blockIdx.x << tx_shift) + tx) * VEC;
+  const int j = blockIdx.y * (256 >> tx_shift) + ty;
+  if (i >= w || j >= h) return;
+  const int o = j * w + i;
   if constexpr (VEC == 4) {
-    f4 fxv = nt_load(reinterpret_cast<const f4*>(a.wx + fo) + q);
-    f4 fyv = nt_load(reinterpret_cast<const f4*>(a.wy + fo) + q);
-    for (; q < nq; q += stride) {
-      const int qn = q + stride;
-      f4 nfx = fxv, nfy = fyv;
-      if (qn < nq) {
-        nfx = nt_load(reinterpret_cast<const f4*>(a.wx + fo) + qn);
-        nfy = nt_load(reinterpret_cast<const f4*>(a.wy + fo) + qn);
-      }
-      const int o = q * 4;
-      const int j = o / w, i = o - j * w;
-      float4 m;
-      float r0[3], r1[3], r2[3], r3[3];
-      warp_pixel<PADDED, NOC>(a, frame, i + 0, j, fxv.x, fyv.x, m.x, r0);
-      warp_pixel<PADDED, NOC>(a, frame, i + 1, j, fxv.y, fyv.y, m.y, r1);
-      warp_pixel<PADDED, NOC>(a, frame, i + 2, j, fxv.z, fyv.z, m.z, r2);
-      warp_pixel<PADDED, NOC>(a, frame, i + 3, j, fxv.w, fyv.w, m.w, r3);
-      nt_store((f4){m.x, m.y, m.z, m.w}, reinterpret_cast<f4*>(a.mask + fo + o));
+    const f4 fxv = nt_load(reinterpret_cast<const f4*>(a.wx + fo + o));
+    const f4 fyv = nt_load(reinterpret_cast<const f4*>(a.wy + fo + o));
+    float4 m;
+    float r0[3], r1[3], r2[3], r3[3];
+    warp_pixel<PADDED, NOC>(a, frame, i + 0, j, fxv.x, fyv.x, m.x, r0);
+    warp_pixel<PADDED, NOC>(a, frame, i + 1, j, fxv.y, fyv.y, m.y, r1);
+    warp_pixel<PADDED, NOC>(a, frame, i + 2, j, fxv.z, fyv.z, m.z, r2);
+    warp_pixel<PADDED, NOC>(a, frame, i + 3, j, fxv.w, fyv.w, m.w, r3);
+    nt_store((f4){m.x, m.y, m.z, m.w}, reinterpret_cast<f4*>(a.mask + fo + o));
 #pragma unroll
-      for (int c = 0; c < noc; ++c)
-        nt_store((f4){r0[c], r1[c], r2[c], r3[c]}, reinterpret_cast<f4*>(a.dst + ((size_t)frame * noc + c) * npx + o));
-      fxv = nfx;
-      fyv = nfy;
-    }
+    for (int c = 0; c < noc; ++c)
+      nt_store((f4){r0[c], r1[c], r2[c], r3[c]}, reinterpret_cast<f4*>(a.dst + ((size_t)frame * noc + c) * npx + o));
   } else {
-    for (; q < nq; q += stride) {
-      const int j = q / w, i = q - j * w;
-      float m, r[3];
-      warp_pixel<PADDED, NOC>(a, frame, i, j, a.wx[fo + q], a.wy[fo + q], m, r);
-      a.mask[fo + q] = m;
-      for (int c = 0; c < noc; ++c) a.dst[((size_t)frame * noc + c) * npx + q] = r[c];
-    }
+    float m, r[3];
+    warp_pixel<PADDED, NOC>(a, frame, i, j, a.wx[fo + o], a.wy[fo + o], m, r);
+    a.mask[fo + o] = m;
+#pragma unroll
+    for (int c = 0; c < noc; ++c) a.dst[((size_t)frame * noc + c) * npx + o] = r[c];
   }
 }
 
 hipError_t launch_warp(const WarpArgs& a, hipStream_t s) {
   const bool v4 = (a.t.w % 4) == 0;
-  if (a.t.nframes > 65535) return hipErrorInvalidValue;
-  const int nq = a.t.w * a.t.h / (v4 ? 4 : 1);
-  // about 4 positions per thread for large frames (the flow prefetch needs a next position), one block row otherwise
-  int bx = (nq + 255) / 256;
-  if (bx > 8) bx = (bx + 3) / 4;
-  const dim3 g((unsigned)bx, (unsigned)a.t.nframes), b(256);
+  if (a.t.nframes > 65535 || (a.t.noc != 1 && a.t.noc != 3)) return hipErrorInvalidValue;
+  const int cols = a.t.w / (v4 ? 4 : 1);
+  int tx_shift = 0;
+  while ((1 << tx_shift) < cols && tx_shift < 8) ++tx_shift;
+  const int rows_per_block = 256 >> tx_shift;
+  const dim3 g((unsigned)((cols + (1 << tx_shift) - 1) >> tx_shift), (unsigned)((a.t.h + rows_per_block - 1) / rows_per_block),
+               (unsigned)a.t.nframes), b(256);
+  if (g.y > 65535) return hipErrorInvalidValue;
 #define OFDIS_WARP_LAUNCH(P, V)                                                                          \
   do {                                                                                                   \
-    if (a.t.noc == 1) hipLaunchKernelGGL((warp_kernel<P, V, 1>), g, b, 0, s, a);                       \
-    else hipLaunchKernelGGL((warp_kernel<P, V, 3>), g, b, 0, s, a);                                    \
+    if (a.t.noc == 1) hipLaunchKernelGGL((warp_kernel<P, V, 1>), g, b, 0, s, a, tx_shift);             \
+    else hipLaunchKernelGGL((warp_kernel<P, V, 3>), g, b, 0, s, a, tx_shift);                          \
   } while (0)
-  if (a.t.noc != 1 && a.t.noc != 3) return hipErrorInvalidValue;
   if (a.src_padded) {
     if (v4) OFDIS_WARP_LAUNCH(true, 4);
     else OFDIS_WARP_LAUNCH(true, 1);

@@ -16,8 +16,15 @@ for name, (B, noc, h, w) in {"op-2 level 3, 4096 pairs (gray)": (4096, 1, 56, 12
                              "1080p gray level 0, 64 pairs": (64, 1, 1088, 1920)}.items():
     g = torch.Generator(device=dev).manual_seed(1)
     src = torch.rand((B, noc, h, w), device=dev, generator=g) * 255
-    wx = torch.randn((B, h, w), device=dev, generator=g) * 2
-    wy = torch.randn((B, h, w), device=dev, generator=g) * 2
+    # a smooth displacement field (what densification + refinement produce), a few pixels in magnitude
+    yy, xx = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32), torch.arange(w, device=dev, dtype=torch.float32),
+                            indexing="ij")
+    ph = torch.rand((B, 1, 1), device=dev, generator=g) * 6.28
+    wx = 3.0 * torch.sin(xx / 37.0 + ph) + 1.5 * torch.cos(yy / 23.0) + 0.37
+    wy = 2.0 * torch.cos(xx / 41.0 - ph) - 1.0 * torch.sin(yy / 29.0) - 0.21
+    if len(sys.argv) > 1 and sys.argv[1] == "random":
+        wx = torch.randn((B, h, w), device=dev, generator=g) * 2
+        wy = torch.randn((B, h, w), device=dev, generator=g) * 2
     dst = torch.empty_like(src)
     mask = torch.empty_like(wx)
     s = torch.cuda.Stream()
