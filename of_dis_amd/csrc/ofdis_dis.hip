@@ -632,13 +632,16 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
   if (!active && !fb) return;
   const long long idx = (long long)frame * npx + i;
   int y, x;
+  // i / d by multiply-high with ceil(2^32 / d) (exact for i * d < 2^32, checked by the launcher; 0 = divide)
+  auto split = [&](int n, int d) { return a.idx_magic ? (int)__umulhi((unsigned)n, a.idx_magic) : n / d; };
   if (diag_enum) {  // coalesced stores
-    const int d = i / g.h;
+    const int d = split(i, g.h);
     y = i - d * g.h;
     x = d - y;
+    if (x < 0) x += g.w;          // 0 <= d < w, 0 <= y < h
     if (x < 0) x += g.w * ((-x + g.w - 1) / g.w);
   } else {
-    y = i / g.w;
+    y = split(i, g.w);
     x = i - y * g.w;
   }
   const int P = g.P, lb = -P / 2, ub = P / 2 - 1, st = g.steps, noc = g.noc;
@@ -743,7 +746,14 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
   }
 }
 
-hipError_t launch_densify(const DensifyArgs& a, hipStream_t s) {
+hipError_t launch_densify(const DensifyArgs& a_in, hipStream_t s) {
+  DensifyArgs a = a_in;
+  {
+    const bool diag_enum = !a.flow_aos && a.wx == nullptr && a.cg_p == nullptr;
+    const unsigned long long d = diag_enum ? a.g.h : a.g.w, npx = (unsigned long long)a.g.w * a.g.h;
+    // floor(n * ceil(2^32/d) / 2^32) == floor(n / d) for n * (d - 1) < 2^32 (n < npx here)
+    a.idx_magic = (d > 1 && npx * d < (1ull << 32)) ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u;
+  }
   // (A patch-major variant -- one wavefront per 32x32 tile accumulating in LDS, one contiguous 256-byte weight read per
   // patch -- was measured at twice the time of this gather: ~90 dependent LDS read-modify-write rounds per tile.)
   const int blocks_per_frame = (a.g.w * a.g.h + 255) / 256;

@@ -40,6 +40,7 @@ struct DensifyArgs {
   float* wy_diag;
   // forward-backward merging (usefbcon, patchgrid.cpp:277-375): the complementary grid's results, or null
   int stereo;               // one flow channel: flow_aos is [B][h][w], wy / wy_diag are not written
+  unsigned idx_magic;       // set by launch_densify: ceil(2^32 / d) for the pixel-index split by d = h (diag order) or w
   const float* cg_p;        // [B][nop][2]
   const float* cg_pweight;  // [B][nop][novals]
 };
