@@ -62,4 +62,51 @@ __device__ __forceinline__ void densify_accumulate(const LevelGeom& g, const flo
     }
 }
 
+// The same sums for gray patches when at most C x C patches cover a pixel (C = ceil(P / steps); 2 at operating points
+// 1 and 2): the candidate patches are enumerated with clamped indices so that ALL weight and displacement loads are
+// requested before the first is used (the loop above waits for each patch in turn), then accumulated in the same
+// order, skipping the candidates that do not exist.  Same additions in the same order => same bits.
+template <int C>
+__device__ __forceinline__ void densify_accumulate_gray(const LevelGeom& g, const float* __restrict__ pf,
+                                                        const float* __restrict__ pwf, int x, int y, float& we, float& fu,
+                                                        float& fv) {
+  const int P = g.P, lb = -P / 2, ub = P / 2 - 1, st = g.steps;
+  const unsigned magic = g.steps_magic;
+  auto div_st = [&](int n) { return magic ? (int)__umulhi((unsigned)n, magic) : n; };
+  int gx_lo = (x - ub - g.offw + st - 1);
+  gx_lo = gx_lo < 0 ? 0 : div_st(gx_lo);
+  int gx_hi = x - lb - g.offw;
+  gx_hi = gx_hi < 0 ? -1 : div_st(gx_hi);
+  if (gx_hi > g.nopw - 1) gx_hi = g.nopw - 1;
+  int gy_lo = (y - ub - g.offh + st - 1);
+  gy_lo = gy_lo < 0 ? 0 : div_st(gy_lo);
+  int gy_hi = y - lb - g.offh;
+  gy_hi = gy_hi < 0 ? -1 : div_st(gy_hi);
+  if (gy_hi > g.noph - 1) gy_hi = g.noph - 1;
+  float pw[C * C], p0[C * C], p1[C * C];
+  bool ok[C * C];
+#pragma unroll
+  for (int a = 0; a < C; ++a)
+#pragma unroll
+    for (int b = 0; b < C; ++b) {
+      const int gx = gx_lo + a, gy = gy_lo + b;
+      ok[a * C + b] = (gx <= gx_hi) & (gy <= gy_hi);
+      const int gxc = min(gx, g.nopw - 1), gyc = min(gy, g.noph - 1);  // gx_lo, gy_lo >= 0
+      const int ip = gxc * g.noph + gyc;
+      const int kx = x - (gxc * st + g.offw) - lb, ky = y - (gyc * st + g.offh) - lb;
+      const int pidx = min(max(ky * P + kx, 0), P * P - 1);  // in range for every existing candidate
+      pw[a * C + b] = pwf[(size_t)ip * g.novals + pidx];
+      p0[a * C + b] = pf[2 * ip];
+      p1[a * C + b] = pf[2 * ip + 1];
+    }
+#pragma unroll
+  for (int k = 0; k < C * C; ++k) {
+    const float absw = div_rn(1.0f, fmaxf(2.0f, pw[k]));
+    const float nwe = we + absw, nfu = fu + p0[k] * absw, nfv = fv + p1[k] * absw;
+    we = ok[k] ? nwe : we;
+    fu = ok[k] ? nfu : fu;
+    fv = ok[k] ? nfv : fv;
+  }
+}
+
 }  // namespace ofdis

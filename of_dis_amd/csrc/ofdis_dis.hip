@@ -646,8 +646,14 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
   }
   const int P = g.P, lb = -P / 2, ub = P / 2 - 1, st = g.steps, noc = g.noc;
   float we = 0.0f, fu = 0.0f, fv = 0.0f;
-  if (active)
-    densify_accumulate(g, a.p + (size_t)frame * g.nop * 2, a.pweight + (size_t)frame * g.nop * g.novals, x, y, we, fu, fv);
+  if (active) {
+    const float* pf = a.p + (size_t)frame * g.nop * 2;
+    const float* pwf = a.pweight + (size_t)frame * g.nop * g.novals;
+    if (g.noc == 1 && g.P <= 2 * g.steps)  // at most 2 x 2 covering patches (uniform)
+      densify_accumulate_gray<2>(g, pf, pwf, x, y, we, fu, fv);
+    else
+      densify_accumulate(g, pf, pwf, x, y, we, fu, fv);
+  }
   if (fb) {  // block-uniform
     __shared__ FbCand cand[256];
     __shared__ int wave_cnt[4];
