@@ -1,18 +1,21 @@
 // ofdis_dis.hip -- Dense Inverse Search kernels for gfx950 (CDNA4).
 //
-//   patch_optimize_kernel : one 64-lane wavefront per patch runs the whole inverse-compositional
-//                           Gauss-Newton loop of the reference in registers
+//   patch_optimize_*      : the whole inverse-compositional Gauss-Newton loop of a patch in registers, several
+//                           patches per wavefront
 //                           (patchgrid.cpp:98-141,195-211; patch.cpp:57-402).
 //   densify_kernel        : AggregateFlowDense (patchgrid.cpp:213-275,377-397) as a gather that
 //                           visits a pixel's covering patches in the reference's scatter order.
 //
 // Mapping.  The reference's patch vector has novals = noc*P*P entries, ordered (row, col, channel)
-// (patch.cpp:306-324).  Lane l of the wave owns entries l, l+64, l+128, ... (M per lane, template
-// parameter), so for the gray P=8 operating points one lane is exactly one patch pixel and the
-// template T, its gradients Tx,Ty, the residual and the weights never leave VGPRs.  The five
-// reductions per iteration (mean, Tx.r, Ty.r, |r|) are DPP/permlane butterflies (ofdis_dev.h);
-// no LDS is used.  The bilinear taps are plain global loads from the padded level image, which is
-// 41 KB at op-point 2 and therefore L1/L2 resident; blocks are mapped so that all patches of a
+// (patch.cpp:306-324).  A patch is owned by LPP lanes of a wavefront:
+//   * gray P = 8 (operating points 1, 2; patch_optimize_gray8_kernel): 4 lanes per patch, 16 patches per wavefront,
+//     a lane holds two adjacent patch columns (16 entries) -- see the comment at that kernel;
+//   * other patches of at most 64 entries: 8 lanes per patch (generic kernel, M = 1);
+//   * larger patches (P = 12, RGB): one patch per wavefront, lane l owns entries l, l+64, ... (M per lane).
+// The template T, its gradients Tx, Ty, the residual and the weights never leave VGPRs; the reductions of an
+// iteration (mean, Tx.r, Ty.r, |r|) are in-lane sums plus DPP / permlane steps in the documented order
+// (ofdis_dev.h, DESIGN.md "Reduction order"); no LDS is used.  The bilinear taps are loads from the padded level
+// image, which is 41 KB at op-point 2 and therefore L1/L2 resident; blocks are mapped so that all patches of a
 // frame run on one XCD (its L2 then holds that frame's four planes once).
 #include <math.h>
 #include <stdlib.h>
