@@ -104,7 +104,7 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes);
 void ofdis_batch_destroy(ofdis_batch* b);
 
 /* device pointers to the context-owned input planes of level l: kind 0 = image A, 1 = A_dx,
- * 2 = A_dy, 3 = image B.  The caller fills them (hipMemcpy, its own kernels, ofdis_batch_upload
+ * 2 = A_dy, 3 = image B (with usefbcon also 4 = B_dx, 5 = B_dy).  The caller fills them (hipMemcpy, its own kernels, ofdis_batch_upload
  * or ofdis_batch_build_pyramids_u8). */
 float* ofdis_batch_input(ofdis_batch* b, int level, int kind);
 size_t ofdis_batch_input_elems(const ofdis_batch* b, int level); /* floats per frame per plane */
@@ -139,7 +139,8 @@ int ofdis_batch_run(ofdis_batch* b, void* stream);
  * Do not modify the inputs of a pass before joining it.  Results are identical in either mode. */
 int ofdis_batch_set_pipeline(ofdis_batch* b, int sub_batches);
 int ofdis_batch_join(ofdis_batch* b, void* stream);
-/* device pointer to the result, [nframes][h>>sc_l][w>>sc_l][2] */
+/* device pointer to the result, [nframes][h>>sc_l][w>>sc_l][2] ([..][1] in stereo-depth mode); in pipelined mode valid on
+ * a stream after ofdis_batch_join(b, stream) */
 const float* ofdis_batch_flow(const ofdis_batch* b);
 /* device pointer to the dense flow of an intermediate level (for per-level parity tests) */
 const float* ofdis_batch_level_flow(const ofdis_batch* b, int level);
