@@ -1,23 +1,41 @@
 #!/usr/bin/env python3
 """Benchmark of the OF_DIS hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--tv on|off]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--tv on|off] [--total-frames T]
 
 A "step" is one pass of the whole hot path (OFC::OFClass scope: per-level DIS search + densification
-+ TV-L1 refinement, pyramids already resident in HBM) over one batch of B synthetic 1024x436 frame
-pairs at operating point 2 (run_OF_INT).  One process per GPU; frames are independent, so ranks
-share nothing (weak scaling: every rank processes its own batch; torch.distributed is used for the
-start/stop barrier and the max-over-ranks time only).  Rank 0 prints ONE JSON line.
++ TV-L1 refinement, pyramids already resident in HBM) over one batch of synthetic 1024x436 frame pairs at
+operating point 2 (run_OF_INT).  One process per GPU; frames are independent, so ranks share nothing on the data
+path: torch.distributed (RCCL on GPUs) carries the start/stop barriers, the max-over-ranks time and the small
+per-frame checksum report.  Rank 0 prints ONE JSON line.
+
+Launch.  `python bench.py --gpus N` started as a plain process spawns the N ranks itself (one per GPU, rendezvous
+on 127.0.0.1); started under torch.distributed.run (RANK / WORLD_SIZE in the environment) it is one of the ranks.
+
+Scaling modes.  Default = weak: every rank owns --batch pairs per step.  --total-frames T = strong (BASELINE.json
+configs[4]: a fixed batch of T pairs cut into contiguous per-rank shares, of_dis_amd.shard.frame_range).  In both
+modes a frame's content depends on its GLOBAL index only, and rank 0 re-computes frames of the other ranks on its
+own GPU and compares checksums: results must be bit-identical to the one-GPU run.
 
 The JSON carries, besides the contract fields:
-  roofline      the kernel class that takes the most time, algorithmic bytes / measured time
-  kernels       the same figures for every kernel class (incl. the warp kernel of the north star)
-  cpu_baseline  the reference CPU path (oracle/_ref, built from the reference sources) timed on one
-                host core over a bounded sample of the same frames
+  roofline, roofline_valu   the kernel class that takes the most time: algorithmic bytes / measured time against the HBM
+                    peak, and its VALU instruction count (PMC, profiles/) against the issue peak
+  kernels           the same HBM figures for every kernel class (incl. the in-pipeline warp kernel)
+  warp_standalone   the north star's warp-kernel bar: ofdis_image_warp alone on a launch that moves >> 10 MB
+  cpu_baseline      the reference CPU path (oracle/_ref, built from the reference sources) timed on one host core over
+                    a bounded sample of the same frames, with the end-point error of the HIP flow against it
+  tv_off            BASELINE configs[1] (same operating point, refinement off)
+  batch512          BASELINE configs[4]: 512 pairs in total, sharded over the ranks of this run
+  small_batch       64 pairs per step on one GPU (the per-GPU share of configs[4] at 8 GPUs)
+  dropin_latency    ofdis_flow(): one pair per call, host pyramids in, host flow out
+  e2e               secondary scope: 8-bit frames in HBM -> pyramids -> flow -> full-resolution flow in HBM
+  config4           BASELINE configs[3]: run_OF_RGB 1920x1080, L1 cost, 50 iterations, TV on
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,27 +45,26 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
 WIDTH, HEIGHT = 1024, 436
+CHUNK = 32             # synthetic frames are generated in aligned chunks of 32 global indices, one seed per chunk
 
 
-def synth_frames_torch(n, w, h, seed, device):
-    """n seeded band-limited 8-bit frame pairs, generated on the GPU (tools/gen_synth.py recipe:
-    multi-scale Gaussian-filtered noise, smooth analytic flow, second frame by cubic back-warp)."""
+def synth_chunk_torch(chunk_index, w, h, base_seed, device, channels=1):
+    """The CHUNK synthetic frame pairs with global indices [chunk_index*CHUNK, (chunk_index+1)*CHUNK), generated on
+    the GPU (tools/gen_synth.py recipe: multi-scale Gaussian-filtered noise, smooth analytic flow, second frame by
+    cubic back-warp).  Depends on (base_seed, chunk_index) only: a frame is the same problem on whichever rank it lands."""
     import math
     import torch
     import torch.nn.functional as F
     M = 64
     H, W = h + 2 * M, w + 2 * M
     g = torch.Generator(device=device)
-    g.manual_seed(seed)
-
+    g.manual_seed(base_seed + chunk_index)
     # Gaussian filtering as a product in the Fourier domain (periodic, like scipy's mode="wrap")
     fy = torch.fft.fftfreq(H, device=device).view(H, 1)
     fx = torch.fft.rfftfreq(W, device=device).view(1, W // 2 + 1)
     f2 = fy * fy + fx * fx
     transfer = sum(amp * sigma * torch.exp(-2.0 * math.pi ** 2 * sigma ** 2 * f2)
                    for sigma, amp in ((3.0, 1.0), (8.0, 1.5), (20.0, 2.0)))
-
-    out_a, out_b = [], []
     ys, xs = torch.meshgrid(torch.arange(h, device=device, dtype=torch.float32),
                             torch.arange(w, device=device, dtype=torch.float32), indexing="ij")
     u = 6 + 4 * torch.sin(2 * math.pi * 0.7 * ys / h + 0.3) + 2 * torch.cos(2 * math.pi * 1.1 * xs / w)
@@ -55,18 +72,32 @@ def synth_frames_torch(n, w, h, seed, device):
     gx = (xs - u + M) / (W - 1) * 2 - 1
     gy = (ys - v + M) / (H - 1) * 2 - 1
     grid = torch.stack([gx, gy], -1)[None]
-    chunk = 32
-    for i in range(0, n, chunk):
-        m = min(chunk, n - i)
-        # (one noise field filtered by the sum of the three Gaussians: same spectrum family as the numpy
-        # recipe's sum of three independently filtered fields; band-limited, |flow| <= 12 px)
-        noise = torch.randn(m, 1, H, W, device=device, generator=g)
-        tex = torch.fft.irfft2(torch.fft.rfft2(noise) * transfer, s=(H, W))
-        tex = (tex - tex.mean((2, 3), keepdim=True)) / tex.std((2, 3), keepdim=True) * 45.0 + 128.0
-        a = tex[:, :, M:M + h, M:M + w]
-        b = F.grid_sample(tex, grid.expand(m, -1, -1, -1), mode="bicubic", padding_mode="border", align_corners=True)
-        out_a.append(a.round().clamp(0, 255).to(torch.uint8)[:, 0].contiguous())
-        out_b.append(b.round().clamp(0, 255).to(torch.uint8)[:, 0].contiguous())
+    # (one noise field filtered by the sum of the three Gaussians: same spectrum family as the numpy recipe's sum of
+    # three independently filtered fields; band-limited, |flow| <= 12 px)
+    noise = torch.randn(CHUNK * channels, 1, H, W, device=device, generator=g)
+    tex = torch.fft.irfft2(torch.fft.rfft2(noise) * transfer, s=(H, W))
+    tex = (tex - tex.mean((2, 3), keepdim=True)) / tex.std((2, 3), keepdim=True) * 45.0 + 128.0
+    a = tex[:, :, M:M + h, M:M + w]
+    b = F.grid_sample(tex, grid.expand(CHUNK * channels, -1, -1, -1), mode="bicubic", padding_mode="border",
+                      align_corners=True)
+
+    def pack(t):  # [CHUNK*channels,1,h,w] -> [CHUNK,h,w(,channels)] u8, channel-interleaved like a decoded image
+        t = t.round().clamp(0, 255).to(torch.uint8)[:, 0]
+        if channels == 1:
+            return t.contiguous()
+        return t.view(CHUNK, channels, h, w).permute(0, 2, 3, 1).contiguous()
+    return pack(a), pack(b)
+
+
+def synth_frames_range(lo, hi, w, h, base_seed, device, channels=1):
+    """Frames with global indices [lo, hi) as two u8 tensors."""
+    import torch
+    out_a, out_b = [], []
+    for c in range(lo // CHUNK, (hi + CHUNK - 1) // CHUNK):
+        a, b = synth_chunk_torch(c, w, h, base_seed, device, channels)
+        s0, s1 = max(lo, c * CHUNK) - c * CHUNK, min(hi, (c + 1) * CHUNK) - c * CHUNK
+        out_a.append(a[s0:s1])
+        out_b.append(b[s0:s1])
     return torch.cat(out_a).contiguous(), torch.cat(out_b).contiguous()
 
 
@@ -108,55 +139,294 @@ def algorithmic_bytes(p, nframes, fused_tv=True):
     return out, launches
 
 
-def cpu_baseline(p, batch, nsample, budget_s):
+def frame_planes(capi, p, batch, f):
+    """The host pyramid [kind][level] of frame f of a batch context (copied back from HBM)."""
+    import numpy as np
+    L = capi.lib()
+    planes = [[None] * (p.sc_f + 1) for _ in range(4)]
+    for l in range(p.sc_l, p.sc_f + 1):
+        n = batch.input_elems(l)
+        for k in range(4):
+            arr = np.empty(p.plane_shape(l), np.float32)
+            capi.check(L.ofdis_memcpy_d2h(arr.ctypes.data, batch.input_ptr(l, k) + f * n * 4, n * 4))
+            planes[k][l] = arr
+    return planes
+
+
+def cpu_baseline(p, batch, nsample, budget_s, mode="int"):
     """Reference CPU path (one thread) on `nsample` frames of this batch; pyramids copied back from HBM."""
-    import ctypes as C
     import numpy as np
     import oracle
     from of_dis_amd import capi
-    kind = "reference" if oracle.have_ref("int", False) else "port"
-    R = oracle.ref("int", False) if kind == "reference" else oracle.c_oracle()
+    kind = "reference" if oracle.have_ref(mode, False) else "port"
+    R = oracle.ref(mode, False) if kind == "reference" else oracle.c_oracle()
     if kind == "port":
         R.set_reduce_order(False)
-    L = capi.lib()
-    frames = []
-    for f in range(nsample):
-        planes = [[None] * (p.sc_f + 1) for _ in range(4)]
-        for l in range(p.sc_l, p.sc_f + 1):
-            n = batch.input_elems(l)
-            for k in range(4):
-                arr = np.empty(p.plane_shape(l), np.float32)
-                capi.check(L.ofdis_memcpy_d2h(arr.ctypes.data, batch.input_ptr(l, k) + f * n * 4, n * 4))
-                planes[k][l] = arr
-        frames.append(planes)
+    frames = [frame_planes(capi, p, batch, f) for f in range(nsample)]
     pq = p.copy(verbosity=0)
     # the metric's second half: end-point error of the HIP result against the reference's own output (its plain,
     # sequential-sum build -- NOT the defined-order build the bit-exact check uses), in full-resolution pixels: the
     # .flo is this flow times 2^sc_l before an interpolation that cannot increase a difference
     err = []
+    t_first = time.perf_counter()
     for f, planes in enumerate(frames):  # also the warm-up
         ref = R.flow(pq, planes[0], planes[1], planes[2], planes[3])
         got = batch.download(f)
         err.append(np.sqrt(((got.astype(np.float64) - ref.astype(np.float64)) ** 2).sum(-1)) * (1 << p.sc_l))
+    t_first = time.perf_counter() - t_first
     err = np.stack(err)
     epe = {"mean_px": float(err.mean()), "max_px": float(err.max()), "frac_above_1e-3": float((err > 1e-3).mean()),
            "frames": len(frames), "against": "reference CPU build with sequential sums" if kind == "reference"
            else "C restatement with sequential sums"}
     n_eval, t0 = 0, time.perf_counter()
     best = 1e9
-    while True:
+    while time.perf_counter() - t0 < budget_s - t_first / max(1, len(frames)):
         for planes in frames:
             t1 = time.perf_counter()
             R.flow(pq, planes[0], planes[1], planes[2], planes[3])
             best = min(best, time.perf_counter() - t1)
             n_eval += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
     el = time.perf_counter() - t0
-    return {"value": round(n_eval / el, 2), "unit": "frames/s", "cores": 1, "kind": kind,
+    if n_eval == 0:  # the budget only covered the first pass (large frames): that pass is the sample
+        n_eval, el, best = len(frames), t_first, t_first / len(frames)
+    return {"value": round(n_eval / el, 3), "unit": "frames/s", "cores": 1, "kind": kind,
             "best_ms_per_frame": round(best * 1e3, 4), "epe_vs_reference": epe,
             "sample": f"{n_eval} OFClass-scope evaluations over {nsample} distinct frames of this batch, "
                       f"{el:.1f} s on one of {os.cpu_count()} host cores"}
+
+
+def frame_checksums(capi, torch, batch, p, n, dev):
+    """One 64-bit checksum per frame of the batch's result (sum of the flow's bit patterns, position weighted)."""
+    w, h = p.level_size(p.sc_l)
+    out = torch.empty((n, h * w * 2), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()  # the pass ran on the bench's own stream
+    batch.join(None)
+    capi.check(capi.lib().ofdis_sync(None))
+    capi.check(capi.lib().ofdis_memcpy_d2d(out.data_ptr(), batch.flow_ptr(), out.numel() * 4, None))
+    capi.check(capi.lib().ofdis_sync(None))
+    wgt = (torch.arange(h * w * 2, device=dev, dtype=torch.int64) % 8191) + 1
+    return (out.to(torch.int64) * wgt).sum(1).cpu().tolist()
+
+
+def timed_steps(torch, fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def kernel_table(capi, torch, batch, p, B, stream, nrep=3):
+    """Per-kernel-class HIP-event times of `nrep` un-pipelined passes against the algorithmic bytes."""
+    batch.timing(True)
+    for _ in range(nrep):
+        batch.run(stream)
+    torch.cuda.synchronize()
+    abytes, _ = algorithmic_bytes(p, B, fused_tv=not os.environ.get("OFDIS_NO_FUSED"))
+    kernels = {}
+    for k, name in enumerate(capi.K_NAMES):
+        ms, n = batch.kernel_time(k)
+        if n == 0:
+            continue
+        per_step_ms = ms / nrep
+        gbs = abytes[name] / (per_step_ms * 1e-3) / 1e9
+        kernels[name] = {"launches_per_step": n // nrep, "ms_per_step": round(per_step_ms, 4),
+                         "avg_launch_us": round(ms / n * 1e3, 2),
+                         "algorithmic_MB_per_step": round(abytes[name] / 1e6, 2),
+                         "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    batch.timing(False)
+    return kernels
+
+
+# ------------------------------------------------------------------------------------------------ secondary blocks
+def block_small_batch(capi, torch, p, batch, ia, ib, stream, dev, args):
+    """64 pairs per step on one GPU: the per-GPU share of BASELINE configs[4] at 8 GPUs (latency-bound regime)."""
+    n = 64
+    b = capi.Batch(p, n)
+    b.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
+    dt = timed_steps(torch, lambda: b.run(stream), 100, 10)
+    same = frame_checksums(capi, torch, b, p, n, dev) == frame_checksums(capi, torch, batch, p, n, dev)
+    b.close()
+    return {"workload": "64 pairs per step, one GPU, launch-graph replay, multi-wave fused TV", "value": round(n / dt, 1),
+            "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "bit_identical_to_large_batch": bool(same)}
+
+
+def block_dropin_latency(capi, torch, p, batch, ia, ib, stream, dev, args):
+    """ofdis_flow(): the constructor's drop-in, one pair per call, host pyramids in, host flow out (synchronous)."""
+    import ctypes as C
+    import numpy as np
+    L = capi.lib()
+    planes = frame_planes(capi, p, batch, 0)
+    n = p.sc_f + 1
+    arrs = [capi._ptr_array(planes[k], n) for k in range(4)]
+    nullarr = C.cast(None, C.POINTER(capi.FP))
+    w, h = p.level_size(p.sc_l)
+    out = np.zeros((h, w, 2), np.float32)
+    outp = out.ctypes.data_as(capi.FP)
+    pp = C.byref(p)
+
+    def call():
+        capi.check(L.ofdis_flow(pp, arrs[0], arrs[1], arrs[2], arrs[3], nullarr, nullarr, outp, None))
+    for _ in range(5):
+        call()
+    k = 300
+    t0 = time.perf_counter()
+    for _ in range(k):
+        call()
+    dt = (time.perf_counter() - t0) / k
+    same = np.array_equal(out, batch.download(0))
+    L.ofdis_flow_cache_clear()
+    return {"workload": "ofdis_flow(): one 1024x436 op-2 pair per call, 245 KB host pyramid in, 57 KB host flow out, "
+                        "synchronous (cached context, pinned staging, launch-graph replay)",
+            "value": round(1.0 / dt, 1), "unit": "pairs/s", "ms_per_call": round(dt * 1e3, 4),
+            "bit_identical_to_batched": bool(same)}
+
+
+def block_warp_standalone(capi, torch, p, batch, ia, ib, stream, dev, args):
+    """The north star's warp-kernel bar (>= 60 % of the HBM roofline): ofdis_image_warp alone on the level-3 planes of
+    4096 pairs (587 MB of algorithmic traffic per launch), timed with events on the launch stream."""
+    L = capi.lib()
+    B, noc, h, w = 4096, 1, 56, 128
+    g = torch.Generator(device=dev).manual_seed(1)
+    src = torch.rand((B, noc, h, w), device=dev, generator=g) * 255
+    yy, xx = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32),
+                            torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+    ph = torch.rand((B, 1, 1), device=dev, generator=g) * 6.28
+    wx = (3.0 * torch.sin(xx / 37.0 + ph) + 1.5 * torch.cos(yy / 23.0) + 0.37).contiguous()
+    wy = (2.0 * torch.cos(xx / 41.0 - ph) - 1.0 * torch.sin(yy / 29.0) - 0.21).contiguous()
+    dst, mask = torch.empty_like(src), torch.empty_like(wx)
+    a = (dst.data_ptr(), mask.data_ptr(), src.data_ptr(), wx.data_ptr(), wy.data_ptr(), w, h, noc, B, stream)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        capi.check(L.ofdis_image_warp(*a))
+    n = 20
+    ts = torch.cuda.ExternalStream(stream, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(ts)
+    for _ in range(n):
+        capi.check(L.ofdis_image_warp(*a))
+    e1.record(ts)
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    byt = B * h * w * (8 + 4 * noc + 4 * noc + 4)
+    gbs = byt / (us * 1e-6) / 1e9
+    return {"kernel": "warp_kernel (ofdis_image_warp, row-major packed planes)", "bound": "hbm",
+            "workload": f"{B} level-3 planes of 128x56, gray: {byt / 1e6:.0f} MB algorithmic per launch (20 B/px)",
+            "avg_launch_us": round(us, 2), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+
+def block_e2e(capi, torch, p, batch, ia, ib, stream, dev, args):
+    """Secondary scope: 8-bit frames resident in HBM -> padding, pyramid, Sobel -> path -> x2^sc_l upsample + crop to the
+    full-resolution flow in HBM (run_dense.cpp:130-178,298-344,391-414 without file I/O)."""
+    B = args.batch_frames
+    full = torch.empty((B, HEIGHT, WIDTH, 2), dtype=torch.float32, device=dev)
+
+    def step():
+        batch.join(stream)
+        batch.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
+        batch.run(stream)
+        batch.upsample(WIDTH, HEIGHT, out_ptr=full.data_ptr(), stream=stream)
+    dt = timed_steps(torch, step, max(3, args.steps // 2), 1)
+    # the two streaming kernels either side of the path, alone (events on the launch stream)
+    ts = torch.cuda.ExternalStream(stream, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    batch.join(stream)
+    ev[0].record(ts)
+    batch.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
+    ev[1].record(ts)
+    batch.upsample(WIDTH, HEIGHT, out_ptr=full.data_ptr(), stream=stream)
+    ev[2].record(ts)
+    torch.cuda.synchronize()
+    t_pyr, t_up = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    # algorithmic bytes: u8 frames in once, the level planes out (A: image + 2 gradients, B: image); flow in, full flow out
+    pyr_b = 2 * B * WIDTH * HEIGHT
+    for l in range(p.sc_l, p.sc_f + 1):
+        th, tw, _ = p.plane_shape(l)
+        pyr_b += B * 4 * th * tw * 4
+    w3, h3 = p.level_size(p.sc_l)
+    up_b = B * (w3 * h3 * 8 + WIDTH * HEIGHT * 8)
+    del full
+    return {"workload": "8-bit frames in HBM -> pyramids -> flow -> full-resolution flow in HBM (secondary scope)",
+            "value": round(B / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4),
+            "build_pyramids": {"ms": round(t_pyr, 4), "algorithmic_MB": round(pyr_b / 1e6, 1),
+                               "achieved_GBs": round(pyr_b / t_pyr / 1e6, 1), "frac_of_hbm_peak": round(pyr_b / t_pyr / 1e6 / HBM_PEAK_GBS, 4)},
+            "upsample_crop": {"ms": round(t_up, 4), "algorithmic_MB": round(up_b / 1e6, 1),
+                              "achieved_GBs": round(up_b / t_up / 1e6, 1), "frac_of_hbm_peak": round(up_b / t_up / 1e6 / HBM_PEAK_GBS, 4)}}
+
+
+def block_config4(capi, torch, p, batch, ia, ib, stream, dev, args):
+    """BASELINE configs[3]: run_OF_RGB operating-point-4 geometry on 1920x1080, L1 cost, 50 iterations, TV on
+    (CLI: run_OF_RGB a b out 6 1 50 50 0.05 0.95 0 12 0.75 0 1 1 1 10 10 5 1 3 1.6 2)."""
+    from of_dis_amd.params import oppoint
+    W4, H4, n = 1920, 1080, 8
+    p4 = oppoint(4, W4, H4, noc=3, verbosity=0).copy(costfct=1, max_iter=50, min_iter=50)
+    xa, xb = synth_frames_range(0, n, W4, H4, 4242, dev, channels=3)
+    b4 = capi.Batch(p4, n)
+    torch.cuda.synchronize()
+    b4.build_pyramids_u8(xa.data_ptr(), xb.data_ptr(), W4, H4, stream)
+    dt = timed_steps(torch, lambda: b4.run(stream), 3, 1)
+    kernels = kernel_table(capi, torch, b4, p4, n, stream, nrep=1)
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    out = {"workload": f"run_OF_RGB 1920x1080 (padded 1920x1088, levels 6-1), patch 12 overlap 0.75, L1 cost, 50 GN "
+                       f"iterations, TV on (7..2 inner its x 3 SOR sweeps); {n} pairs per step, OFClass scope",
+           "value": round(n / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "ms_per_frame": round(dt / n * 1e3, 3),
+           "roofline": {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"]},
+           "kernels": kernels}
+    if args.cpu_seconds > 0:
+        try:
+            out["cpu_baseline"] = cpu_baseline(p4, b4, 1, 1.0, mode="rgb")
+            out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "kind": "unavailable", "sample": f"{type(e).__name__}: {e}"}
+    b4.close()
+    return out
+
+
+BLOCKS = [("small_batch", block_small_batch), ("dropin_latency", block_dropin_latency),
+          ("warp_standalone", block_warp_standalone), ("e2e", block_e2e), ("config4", block_config4)]
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` as a plain process: start the N ranks (this file again, one per GPU) and wait.
+    Rank 0 inherits stdout and prints the JSON line."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OFDIS_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs:
+            for pr in list(procs):
+                code = pr.poll()
+                if code is None:
+                    continue
+                procs.remove(pr)
+                if code != 0:  # one rank failed: the others would wait in a barrier for ever
+                    rc = rc or code
+                    for other in procs:
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            pr.kill()
+    return rc
 
 
 def main():
@@ -164,16 +434,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="frame pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=4096, help="frame pairs per GPU per step (weak scaling)")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="strong scaling: this many pairs per step in total, cut into contiguous per-rank shares "
+                         "(BASELINE configs[4]: 512)")
     ap.add_argument("--tv", choices=["on", "off"], default="on")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary blocks (small_batch, e2e, config4, ...)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="ofdis_batch_set_pipeline: sub-batches on internal streams, consecutive steps overlap (1 = off)")
     ap.add_argument("--scope", choices=["ofclass", "e2e"], default="ofclass",
                     help="ofclass (the metric): pyramids resident in HBM -> level flow.  e2e (secondary, DESIGN.md 5): "
                          "8-bit frames resident in HBM -> pyramids -> flow -> full-resolution flow in HBM")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -187,16 +464,19 @@ def main():
     # developer switches for exercising the multi-rank control flow on a one-GPU box (tests only; the driver's
     # launch uses one GPU per rank over RCCL): all ranks on device 0, gloo instead of nccl
     backend = os.environ.get("OFDIS_BENCH_BACKEND", "nccl")
+    L = capi.lib()
+    ndev = L.ofdis_device_count()
     if os.environ.get("OFDIS_BENCH_SHARE_GPU"):
         local_rank = 0
+    elif world > ndev:
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} HIP device(s) visible (one GPU per rank)")
     torch.cuda.set_device(local_rank)
-    L = capi.lib()
     capi.check(L.ofdis_set_device(local_rank))
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        if backend == "nccl":  # RCCL
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -208,15 +488,22 @@ def main():
 
     tv = args.tv == "on"
     p = oppoint(2, WIDTH, HEIGHT, noc=1, usetvref=tv, verbosity=0)
-    B = args.batch
-    # weak scaling: rank r owns global frames [r*B, (r+1)*B); its generator is seeded by its first frame
-    ia, ib = synth_frames_torch(B, WIDTH, HEIGHT, shard.frame_seed(1234, rank * B), dev)
+    strong = args.total_frames > 0
+    if strong:
+        lo, hi = shard.frame_range(args.total_frames, rank, world)
+    else:
+        lo, hi = rank * args.batch, (rank + 1) * args.batch
+    B = hi - lo
+    if B < 1:
+        raise SystemExit(f"rank {rank}: no frames to process (total {args.total_frames} over {world} ranks)")
+    ia, ib = synth_frames_range(lo, hi, WIDTH, HEIGHT, 1234, dev)
     # a dedicated (non-default) stream: launches on HIP's legacy null stream carry implicit cross-stream
     # synchronisation and measure ~30 us slower per launch on this stack
     tstream = torch.cuda.Stream(device=dev)
     stream = tstream.cuda_stream
     batch = capi.Batch(p, B)
-    batch.set_pipeline(args.pipeline)
+    pipeline = args.pipeline if B >= 1024 else 1  # small shares: one stream, launch-graph replay instead
+    batch.set_pipeline(pipeline)
     torch.cuda.synchronize()  # frames were generated on torch's default stream
     batch.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
     torch.cuda.synchronize()
@@ -241,36 +528,69 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dist, red_dev)
-    fps = shard.throughput([B] * world, args.steps, elapsed)
+    counts = shard.gather_objects(B, dist, world)
+    fps = shard.throughput(counts, args.steps, elapsed)
+
+    # ---- every rank: checksums of its frames' results; rank 0 re-computes other ranks' frames and compares
+    sums = frame_checksums(capi, torch, batch, p, B, dev)
+    all_sums = shard.gather_objects((lo, sums), dist, world)
+    mg_check = None
+    if rank == 0 and world > 1:
+        compared, bad = 0, 0
+        for r in range(1, world):
+            rlo, rsums = all_sums[r]
+            n = len(rsums) if strong else min(len(rsums), CHUNK)  # weak mode: a sample (the first chunk) per rank
+            xa, xb = synth_frames_range(rlo, rlo + n, WIDTH, HEIGHT, 1234, dev)
+            bx = capi.Batch(p, n)
+            torch.cuda.synchronize()
+            bx.build_pyramids_u8(xa.data_ptr(), xb.data_ptr(), WIDTH, HEIGHT, stream)
+            bx.run(stream)
+            mine = frame_checksums(capi, torch, bx, p, n, dev)
+            bx.close()
+            compared += n
+            bad += sum(int(a != b) for a, b in zip(mine, rsums[:n]))
+        mg_check = {"frames_compared": compared, "mismatches": bad, "bit_identical_to_1gpu": bad == 0,
+                    "how": "rank 0 re-computed " + ("every frame" if strong else f"the first {CHUNK} frames")
+                           + " of each other rank on its own GPU and compared per-frame checksums of the flow bits"}
+
+    # ---- BASELINE configs[4]: 512 pairs in total over the ranks of this run (a secondary block in every mode)
+    batch512 = None
+    if not args.no_extras and not e2e and tv:
+        total = 512
+        slo, shi = shard.frame_range(total, rank, world)
+        n5 = shi - slo
+        fits = shard.gather_objects(1 <= n5 <= B, dist, world)  # the same decision on every rank (collectives below)
+        if all(fits):
+            b5 = capi.Batch(p, n5)
+            torch.cuda.synchronize()
+            # (timing only: the first n5 frames this rank already holds)
+            b5.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
+            for _ in range(max(3, args.warmup)):
+                b5.run(stream)
+            k5 = max(20, args.steps)
+            barrier()
+            t5 = time.perf_counter()
+            for _ in range(k5):
+                b5.run(stream)
+            barrier()
+            e5 = shard.max_over_ranks(time.perf_counter() - t5, dist, red_dev)
+            b5.close()
+            batch512 = {"workload": "BASELINE configs[4]: 512 independent 1024x436 pairs per step, contiguous shares "
+                                    f"over {world} GPU(s) ({n5} pairs on rank 0)", "value": round(total * k5 / e5, 1),
+                        "unit": "frames/s", "ms_per_step": round(e5 / k5 * 1e3, 4), "steps": k5, "scaling": "strong"}
 
     result = None
     if rank == 0:
         # ---- per-kernel timing with HIP events on the launch stream (separate, untimed pass)
-        nrep = 3
-        batch.timing(True)
-        for _ in range(nrep):
-            batch.run(stream)
-        torch.cuda.synchronize()
-        abytes, _ = algorithmic_bytes(p, B, fused_tv=not os.environ.get("OFDIS_NO_FUSED"))
-        kernels = {}
-        for k, name in enumerate(capi.K_NAMES):
-            ms, n = batch.kernel_time(k)
-            if n == 0:
-                continue
-            per_step_ms = ms / nrep
-            gbs = abytes[name] / (per_step_ms * 1e-3) / 1e9
-            kernels[name] = {"launches_per_step": n // nrep, "ms_per_step": round(per_step_ms, 4),
-                             "avg_launch_us": round(ms / n * 1e3, 2),
-                             "algorithmic_MB_per_step": round(abytes[name] / 1e6, 2),
-                             "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
-        batch.timing(False)
+        kernels = kernel_table(capi, torch, batch, p, B, stream)
         # HBM traffic per step from the PMC counters (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, calibrated in
         # profiles/r01_pmc_calibration.txt), collected by tools/pmc_traffic.py for this batch size
-        traffic = {}
+        traffic, valu = {}, {}
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj.get("batch") == B and tj.get("tv") == args.tv:
                 traffic = tj["bytes_per_step"]
+                valu = tj.get("valu_insts_per_step", {})
         except Exception:
             pass
         for name, k in kernels.items():
@@ -283,62 +603,81 @@ def main():
                     "note": "achieved = algorithmic bytes of all launches of this kernel class in one step / their "
                             "summed HIP-event time (bytes/s); traffic = PMC HBM bytes of the same launches per step "
                             "(profiles/traffic.json). The two dominant kernels (tv_fused, patch_optimize) are VALU-issue "
-                            "bound (PMC: profiles/*pmc_sq*), not HBM bound; see DESIGN.md section 4"}
+                            "bound, see roofline_valu and DESIGN.md section 4"}
+        # VALU-side roofline of the same kernel: wave64 VALU instructions issued per step (PMC SQ_INSTS_VALU,
+        # profiles/traffic.json) / its measured time, against SIMDs x clock / 2 (a wave64 VALU op occupies a
+        # gfx950 SIMD for two clocks, MI355X_MICROARCH.md); the clock is the sustained one observed under this load
+        roofline_valu = None
+        if dom in valu:
+            simds, clk_ghz = 256 * 4, tj.get("sustained_clock_ghz", 1.81)
+            peak = simds * clk_ghz / 2.0  # G wave-instructions / s
+            ach = valu[dom] / (kernels[dom]["ms_per_step"] * 1e-3) / 1e9
+            roofline_valu = {"kernel": dom, "bound": "valu_issue", "achieved": round(ach, 1), "peak": round(peak, 1),
+                             "unit": "G wave64-VALU-instructions/s", "frac": round(ach / peak, 4),
+                             "valu_insts_per_step": valu[dom], "sustained_clock_ghz": clk_ghz,
+                             "note": "instruction count from rocprofv3 --pmc SQ_INSTS_VALU (profiles/), time from this run"}
         result = {
-            "metric": "frames/sec at 1024\u00d7436 op-point-2 (INT)", "value": round(fps, 1), "unit": "frames/s",
+            "metric": "frames/sec at 1024×436 op-point-2 (INT)", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"run_OF_INT op-point-2, 1024x436 (padded 1024x448, levels 5-3), patch 8 overlap 0.4, "
                                    f"12 GN iterations, TV {'on (6/5/4 inner its, 3 SOR sweeps, alpha=gamma=10 delta=5)' if tv else 'off'}; "
                                    + ("end-to-end scope: 8-bit frames in HBM -> pyramids -> flow -> full-resolution flow in HBM (secondary)"
                                       if e2e else "OFClass scope, pyramids resident in HBM"),
-                       "frames_per_gpu_per_step": B, "global_frames_per_step": B * world,
+                       "frames_per_gpu_per_step": counts[0] if len(set(counts)) == 1 else counts,
+                       "global_frames_per_step": sum(counts),
                        "parallelism": f"frame-sharded x{world}", "tv": args.tv,
-                       "pipeline": f"{args.pipeline} sub-batches per GPU on internal HIP streams, consecutive steps "
-                                   f"overlap inside the timed region" if args.pipeline > 1 else "off"},
+                       "ranks": {"world_size": dist.get_world_size() if dist is not None else 1,
+                                 "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if dist is not None else "none",
+                                 "launch": "self-spawned by bench.py --gpus" if os.environ.get("OFDIS_BENCH_SPAWNED") else
+                                           ("torch.distributed.run" if world > 1 else "single process")},
+                       "pipeline": f"{pipeline} sub-batches per GPU on internal HIP streams, consecutive steps "
+                                   f"overlap inside the timed region" if pipeline > 1 else "off (launch-graph replay)"},
             "roofline": roofline, "kernels": kernels,
         }
+        if roofline_valu:
+            result["roofline_valu"] = roofline_valu
+        if mg_check:
+            result["multi_gpu_check"] = mg_check
+        if batch512:
+            result["batch512"] = batch512
         if not args.no_parity:
             try:
                 import oracle
                 O = oracle.c_oracle()
                 O.set_reduce_order(True)
                 f = B - 1
-                planes = [[None] * (p.sc_f + 1) for _ in range(4)]
-                for l in range(p.sc_l, p.sc_f + 1):
-                    n = batch.input_elems(l)
-                    for k in range(4):
-                        arr = np.empty(p.plane_shape(l), np.float32)
-                        capi.check(L.ofdis_memcpy_d2h(arr.ctypes.data, batch.input_ptr(l, k) + f * n * 4, n * 4))
-                        planes[k][l] = arr
+                planes = frame_planes(capi, p, batch, f)
                 ref = O.flow(p, planes[0], planes[1], planes[2], planes[3])
                 got = batch.download(f)
                 result["parity_check"] = "bit-exact vs oracle (frame %d)" % f if np.array_equal(ref, got) else \
                     "MISMATCH vs oracle: mean EPE %.3g" % oracle.epe_stats(ref, got)[0]
             except Exception as e:  # the checker is optional for the measurement
                 result["parity_check"] = f"not run ({type(e).__name__}: {e})"
+        extras = world == 1 and tv and not e2e and not args.no_extras
         if world == 1 and tv and not e2e:
             # BASELINE.json also lists the same operating point with the refinement switched off (configs[1]); report it
             # next to the headline (configs[2], TV on -- what operating point 2 is in the reference, run_dense.cpp:259-265)
             try:
                 p_off = oppoint(2, WIDTH, HEIGHT, noc=1, usetvref=False, verbosity=0)
                 b_off = capi.Batch(p_off, B)
-                b_off.set_pipeline(args.pipeline)
+                b_off.set_pipeline(pipeline)
                 b_off.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
-                for _ in range(args.warmup):
-                    b_off.run(stream)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    b_off.run(stream)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t1
+                dt = timed_steps(torch, lambda: b_off.run(stream), args.steps, args.warmup)
                 b_off.close()
-                result["tv_off"] = {"workload": "same, TV off (BASELINE.json configs[1])", "value": round(B * args.steps / dt, 1),
-                                    "unit": "frames/s", "ms_per_step": round(dt / args.steps * 1e3, 4)}
+                result["tv_off"] = {"workload": "same, TV off (BASELINE.json configs[1])", "value": round(B / dt, 1),
+                                    "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4)}
             except Exception as e:
                 result["tv_off"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        if extras:
+            args.batch_frames = B
+            for name, fn in BLOCKS:
+                try:
+                    result[name] = fn(capi, torch, p, batch, ia, ib, stream, dev, args)
+                except Exception as e:
+                    result[name] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.cpu_seconds > 0:
             try:
                 result["cpu_baseline"] = cpu_baseline(p, batch, min(16, B), args.cpu_seconds)

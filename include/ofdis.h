@@ -89,6 +89,11 @@ int ofdis_flow(const ofdis_params* p,
                const float* const* im_a, const float* const* im_a_dx, const float* const* im_a_dy,
                const float* const* im_b, const float* const* im_b_dx, const float* const* im_b_dy,
                float* outflow, const float* initflow);
+/* ofdis_flow keeps the device contexts of the last few parameter sets (buffers, a stream, pinned staging, the captured
+ * launch graph) so that a loop over frame pairs -- the reference's usage, one constructor per pair -- pays for them
+ * once; calls are serialised internally.  ofdis_flow_cache_clear() releases them (e.g. before hipDeviceReset or at
+ * shutdown); the next ofdis_flow() builds a fresh one. */
+void ofdis_flow_cache_clear(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched, device-resident form (the throughput path).
@@ -100,6 +105,7 @@ int ofdis_flow(const ofdis_params* p,
  * ------------------------------------------------------------------------------------------- */
 typedef struct ofdis_batch ofdis_batch;
 
+/* nframes: 1..65535.  All device memory of the context is one allocation. */
 int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes);
 void ofdis_batch_destroy(ofdis_batch* b);
 
@@ -108,13 +114,16 @@ void ofdis_batch_destroy(ofdis_batch* b);
  * or ofdis_batch_build_pyramids_u8). */
 float* ofdis_batch_input(ofdis_batch* b, int level, int kind);
 size_t ofdis_batch_input_elems(const ofdis_batch* b, int level); /* floats per frame per plane */
-/* copy one frame's host pyramid (the ofdis_flow() layout) into slot `frame` */
+/* copy one frame's host pyramid (the ofdis_flow() layout) into slot `frame`.  Like every upload below this ENQUEUES
+ * copies on `stream`: the host arrays must stay valid and unchanged until the stream has been synchronised
+ * (ofdis_sync). */
 int ofdis_batch_upload(ofdis_batch* b, int frame, const float* const* im_a, const float* const* im_a_dx,
                        const float* const* im_a_dy, const float* const* im_b, void* stream);
 /* build all input planes of levels sc_l..sc_f on the device from raw 8-bit frames
  * (run_dense.cpp:130-178,298-311,326-344 restated on device): img_a/img_b are device pointers to
  * [nframes][height_org][width_org][noc] uint8; padding to params.width x params.height is applied
- * as the reference does (replicate, floor/ceil split). */
+ * as the reference does (replicate, floor/ceil split).  Exact (bit-identical to the fp32 OpenCV arithmetic of the
+ * reference for 8-bit input) for sc_f <= 7; larger sc_f returns OFDIS_ERR_UNSUPPORTED. */
 int ofdis_batch_build_pyramids_u8(ofdis_batch* b, const uint8_t* img_a, const uint8_t* img_b, int width_org,
                                   int height_org, void* stream);
 
@@ -139,6 +148,11 @@ int ofdis_batch_run(ofdis_batch* b, void* stream);
  * Do not modify the inputs of a pass before joining it.  Results are identical in either mode. */
 int ofdis_batch_set_pipeline(ofdis_batch* b, int sub_batches);
 int ofdis_batch_join(ofdis_batch* b, void* stream);
+/* Launch-graph replay: the schedule of a context never changes, so an un-pipelined ofdis_batch_run can replay it as one
+ * hipGraph launch instead of ~18 kernel launches (matters for small batches and the single-pair drop-in).
+ * mode -1 = automatic (the default: captured at the second pass of a context), 0 = never, 1 = from the first pass.
+ * Results are identical; timing mode, verbosity > 0 and pipelined mode always launch directly. */
+int ofdis_batch_set_graph(ofdis_batch* b, int mode);
 /* device pointer to the result, [nframes][h>>sc_l][w>>sc_l][2] ([..][1] in stereo-depth mode); in pipelined mode valid on
  * a stream after ofdis_batch_join(b, stream) */
 const float* ofdis_batch_flow(const ofdis_batch* b);

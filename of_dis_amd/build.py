@@ -19,7 +19,7 @@ ROOT = os.path.dirname(HERE)
 HIP_SOURCES = ["ofdis_dis.hip", "ofdis_tv.hip", "ofdis_sor.hip", "ofdis_fused.hip", "ofdis_de.hip", "ofdis_pyr.hip", "ofdis_capi.hip"]
 # -ffp-contract=off: every fp32 operation separately rounded, like the reference's SSE path.
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-            "-Wall", "-Wno-unused-function"]
+            "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
 
 
 # No SLP vectorisation: gfx950's SIMDs are 32 lanes wide, so a packed v_pk_*_f32 occupies the issue port about as

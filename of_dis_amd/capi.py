@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "ofdis_batch_level_flow", "ofdis_batch_download", "ofdis_batch_upsample", "ofdis_batch_timing", "ofdis_batch_kernel_time",
     "ofdis_image_warp", "ofdis_get_derivatives", "ofdis_tv_system", "ofdis_sor_coupled", "ofdis_patchgrid_level",
     "ofdis_varref_level", "ofdis_dev_alloc", "ofdis_dev_free", "ofdis_memcpy_h2d", "ofdis_memcpy_d2h", "ofdis_memcpy_d2d", "ofdis_sync",
+    "ofdis_batch_set_graph", "ofdis_flow_cache_clear",
 ]
 
 
@@ -84,11 +85,15 @@ def lib():
         L.ofdis_batch_upsample.argtypes = [VP, VP, C.c_int, C.c_int, VP]
         L.ofdis_batch_set_pipeline.argtypes = [VP, C.c_int]
         L.ofdis_batch_join.argtypes = [VP, VP]
+        L.ofdis_batch_set_graph.argtypes = [VP, C.c_int]
+        L.ofdis_flow_cache_clear.restype = None
         L.ofdis_batch_upload_b_gradients.argtypes = [VP, C.c_int, C.POINTER(FP), C.POINTER(FP), VP]
         L.ofdis_batch_initflow_elems.restype = C.c_size_t
         L.ofdis_batch_initflow_elems.argtypes = [VP]
         L.ofdis_batch_set_initflow.argtypes = [VP, VP]
         L.ofdis_batch_upload_initflow.argtypes = [VP, C.c_int, FP, VP]
+        L.ofdis_test_set_fused_mw_max.argtypes = [C.c_int]
+        L.ofdis_test_set_fused_mw_max.restype = None
         L.ofdis_test_wave_sum.argtypes = [VP, VP, C.c_int, VP]
         L.ofdis_test_div_sqrt.argtypes = [VP, VP, VP, C.c_int, VP]
         _lib = L
@@ -295,6 +300,7 @@ class Batch:
         a = _f(initflow)
         assert a.size == lib().ofdis_batch_initflow_elems(self.h), (a.shape, lib().ofdis_batch_initflow_elems(self.h))
         check(lib().ofdis_batch_upload_initflow(self.h, frame, a.ctypes.data_as(FP), stream))
+        check(lib().ofdis_sync(stream))  # `a` may be a temporary: the copy must have read it before it goes away
 
     def set_initflow(self, dev_ptr):
         check(lib().ofdis_batch_set_initflow(self.h, dev_ptr))
@@ -307,6 +313,9 @@ class Batch:
 
     def set_pipeline(self, sub_batches):
         check(lib().ofdis_batch_set_pipeline(self.h, sub_batches))
+
+    def set_graph(self, mode):
+        check(lib().ofdis_batch_set_graph(self.h, mode))
 
     def join(self, stream=None):
         check(lib().ofdis_batch_join(self.h, stream))

@@ -8,6 +8,7 @@
 #include <sys/time.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -115,7 +116,20 @@ struct ofdis_batch {
   float *w_im2 = nullptr, *derivs = nullptr, *sys = nullptr;
   float *wx_d = nullptr, *wy_d = nullptr, *mask_d = nullptr;  // diag-layout copies for the fused TV kernel
   std::vector<float*> pyr_tmp;       // unpadded level images (ofdis_batch_build_pyramids_u8), lazily allocated
+  // device memory: requests are collected (dalloc) and served from ONE hipMalloc per commit (dcommit) -- a context is
+  // one allocation (two with the u8 pyramid scratch), and the input planes form one contiguous region [in_base,
+  // in_base + in_bytes) in (level, kind) order so that a single-frame context is uploaded with one copy (ofdis_flow)
+  struct Req { float** slot; size_t bytes; };
+  std::vector<Req> pending;
   std::vector<void*> allocs;
+  char* in_base = nullptr;
+  size_t in_bytes = 0;
+  // hipGraph replay of the launch schedule (ofdis_batch_set_graph)
+  int graph_mode = -1;                   // -1 auto, 0 off, 1 on
+  long runs = 0;                         // un-pipelined passes so far
+  hipGraphExec_t graph_exec = nullptr;
+  const float* graph_initflow = nullptr; // the warm-start pointer the captured graph was built with
+  hipStream_t cap_stream = nullptr;      // capture stream
   // sub-batches on internal streams (ofdis_batch_run)
   std::vector<hipStream_t> sub_streams;  // streams of sub-batches 1..S-1 (sub-batch 0 runs on the caller's stream)
   std::vector<hipEvent_t> sub_done;
@@ -132,12 +146,29 @@ struct ofdis_batch {
 
 namespace {
 
-int dalloc(ofdis_batch* b, float** ptr, size_t elems) {
+int dalloc(ofdis_batch* b, float** ptr, size_t elems) {  // request; served by dcommit()
+  *ptr = nullptr;
+  const size_t bytes = ((elems ? elems : 1) * sizeof(float) + 255) & ~(size_t)255;
+  b->pending.push_back({ptr, bytes});
+  return OFDIS_OK;
+}
+int dcommit(ofdis_batch* b) {
+  size_t total = 0;
+  for (auto& r : b->pending) total += r.bytes;
+  if (!total) return OFDIS_OK;
   void* d = nullptr;
-  hipError_t e = hipMalloc(&d, (elems ? elems : 1) * sizeof(float));
-  if (e != hipSuccess) return hipfail(e, "hipMalloc");
+  hipError_t e = hipMalloc(&d, total);
+  if (e != hipSuccess) {
+    b->pending.clear();
+    return hipfail(e, "hipMalloc");
+  }
   b->allocs.push_back(d);
-  *ptr = (float*)d;
+  char* c = (char*)d;
+  for (auto& r : b->pending) {
+    *r.slot = (float*)c;
+    c += r.bytes;
+  }
+  b->pending.clear();
   return OFDIS_OK;
 }
 
@@ -376,10 +407,14 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
   for (int k = 0; k < 6; ++k) b->in[k].assign(b->nlevels, nullptr);
   b->flow.assign(b->nlevels, nullptr);
   b->flow_bw.assign(b->nlevels, nullptr);
+  if (nframes > 65535)  // launch_warp / launch_upsample_crop carry the frame in grid.z
+    { delete b; return fail(OFDIS_ERR_UNSUPPORTED, "at most 65535 frames per batch context"); }
   rc = OFDIS_OK;
+  for (int i = 0; i < b->nlevels && !rc; ++i)  // the input planes first: one contiguous region in (level, kind) order
+    for (int k = 0; k < nin && !rc; ++k) rc = dalloc(b, &b->in[k][i], b->geom[i].plane_elems * nframes);
+  for (auto& r : b->pending) b->in_bytes += r.bytes;
   for (int i = 0; i < b->nlevels && !rc; ++i) {
     const LevelGeom& g = b->geom[i];
-    for (int k = 0; k < nin && !rc; ++k) rc = dalloc(b, &b->in[k][i], g.plane_elems * nframes);
     if (!rc) rc = dalloc(b, &b->flow[i], (size_t)g.w * g.h * b->nop * nframes);
     if (!rc && p->usefbcon && i > 0) rc = dalloc(b, &b->flow_bw[i], (size_t)g.w * g.h * 2 * nframes);
   }
@@ -407,6 +442,8 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
       if (!rc) rc = dalloc(b, &b->mask_d, npx);
     }
   }
+  if (!rc) rc = dcommit(b);
+  if (!rc) b->in_base = (char*)b->in[0][0];
   if (rc) {
     ofdis_batch_destroy(b);
     return rc == OFDIS_ERR_DEVICE ? OFDIS_ERR_NOMEM : rc;
@@ -423,6 +460,8 @@ void ofdis_batch_destroy(ofdis_batch* b) {
   }
   for (hipEvent_t ev : b->sub_done) (void)hipEventDestroy(ev);
   if (b->sub_start) (void)hipEventDestroy(b->sub_start);
+  if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
+  if (b->cap_stream) (void)hipStreamDestroy(b->cap_stream);
   for (void* d : b->allocs) (void)hipFree(d);
   for (int k = 0; k < OFDIS_K_COUNT; ++k)
     for (auto& e : b->ev[k]) {
@@ -483,7 +522,8 @@ int ofdis_batch_build_pyramids_u8(ofdis_batch* b, const uint8_t* img_a, const ui
   if (width_org < 1 || height_org < 1 || width_org > p.width || height_org > p.height || p.width - width_org >= sc ||
       p.height - height_org >= sc)
     return fail(OFDIS_ERR_INVALID, "params.width/height are not the 2^sc_f padding of the original size");
-  if (p.sc_f > 8) return fail(OFDIS_ERR_UNSUPPORTED, "exact fp32 pyramid needs sc_f <= 8");
+  // level l images need 8+2l bits, the Sobel partial sums 10+2l: exact in fp32 up to l = 7 (ofdis_pyr.hip)
+  if (p.sc_f > 7) return fail(OFDIS_ERR_UNSUPPORTED, "exact fp32 pyramid needs sc_f <= 7");
   hipStream_t s = (hipStream_t)stream;
   if (b->pyr_tmp.empty()) {
     b->pyr_tmp.assign(b->nlevels, nullptr);
@@ -492,6 +532,7 @@ int ofdis_batch_build_pyramids_u8(ofdis_batch* b, const uint8_t* img_a, const ui
       int rc = dalloc(b, &b->pyr_tmp[i], (size_t)g.w * g.h * g.noc * b->nframes);
       if (rc) return rc;
     }
+    if (int rc = dcommit(b)) { b->pyr_tmp.clear(); return rc; }
   }
   for (int which = 0; which < 2; ++which) {
     const uint8_t* src = which ? img_b : img_a;
@@ -549,6 +590,7 @@ ofdis_batch frame_view(const ofdis_batch& b, int f0, int n) {
 }
 
 int run_levels(ofdis_batch* b, hipStream_t s);
+int run_graph_or_levels(ofdis_batch* b, hipStream_t s);
 
 }  // namespace
 
@@ -572,8 +614,14 @@ int ofdis_batch_set_pipeline(ofdis_batch* b, int sub_batches) {
 int ofdis_batch_join(ofdis_batch* b, void* stream) {
   if (!b) return fail(OFDIS_ERR_INVALID, "batch is NULL");
   if (!b->join_pending) return OFDIS_OK;
-  for (hipEvent_t ev : b->sub_done) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, ev, 0));
+  for (hipEvent_t ev : b->sub_done) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, ev, 0));  // never-recorded events are complete
   b->join_pending = false;
+  return OFDIS_OK;
+}
+
+int ofdis_batch_set_graph(ofdis_batch* b, int mode) {
+  if (!b || mode < -1 || mode > 1) return fail(OFDIS_ERR_INVALID, "mode must be -1 (auto), 0 (off) or 1 (on)");
+  b->graph_mode = mode;
   return OFDIS_OK;
 }
 
@@ -584,30 +632,34 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
   if (b->nframes < 2 * S) S = 1;
   if (S == 1) {
     int rc = ofdis_batch_join(b, stream);  // a previous pipelined pass may still be running
-    return rc ? rc : run_levels(b, s);
+    if (rc) return rc;
+    return run_graph_or_levels(b, s);
   }
   if (!b->sub_start) HIPCHK(hipEventCreateWithFlags(&b->sub_start, hipEventDisableTiming));
   while ((int)b->sub_streams.size() < S - 1) {
     hipStream_t st;
-    hipEvent_t ev;
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     b->sub_streams.push_back(st);
+  }
+  while ((int)b->sub_done.size() < S) {  // one per sub-batch, the caller's stream included: a join may happen on
+    hipEvent_t ev;                        // another stream than the run
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     b->sub_done.push_back(ev);
   }
   HIPCHK(hipEventRecord(b->sub_start, s));  // fork: the internal streams see everything enqueued on `s` so far
+  b->join_pending = true;                   // from here on sub-streams may carry work, whatever happens below
   const int per = (b->nframes + S - 1) / S;
   int rc = OFDIS_OK;
   for (int k = S - 1; k >= 0 && !rc; --k) {  // sub-batch 0 last, on the caller's stream
     const int f0 = k * per, n = std::min(per, b->nframes - f0);
-    if (n <= 0) continue;
-    ofdis_batch v = frame_view(*b, f0, n);
     hipStream_t sk = k ? b->sub_streams[k - 1] : s;
-    if (k) HIPCHK(hipStreamWaitEvent(sk, b->sub_start, 0));
-    rc = run_levels(&v, sk);
-    if (k && !rc) HIPCHK(hipEventRecord(b->sub_done[k - 1], sk));
+    if (n > 0) {
+      ofdis_batch v = frame_view(*b, f0, n);
+      if (k) HIPCHK(hipStreamWaitEvent(sk, b->sub_start, 0));
+      rc = run_levels(&v, sk);
+    }
+    if (!rc) HIPCHK(hipEventRecord(b->sub_done[k], sk));
   }
-  b->join_pending = true;
   return rc;
 }
 
@@ -720,6 +772,46 @@ int run_levels(ofdis_batch* b, hipStream_t s) {
   return OFDIS_OK;
 }
 
+// The launch schedule of a context is fixed (same kernels, same pointers every pass), so from its second un-pipelined
+// pass on it is replayed as ONE hipGraph launch instead of ~18 kernel launches and a few memsets: for small batches
+// (and the single-pair drop-in) the host-side launch cost is a visible share of a pass.  Off when timing or TIME lines
+// are requested (they synchronise between stages), in pipelined mode (the sub-batches are deliberately not joined),
+// with OFDIS_NO_GRAPH, or after a capture failure -- the direct launches are always the fallback.
+int run_graph_or_levels(ofdis_batch* b, hipStream_t s) {
+  static const bool env_off = getenv("OFDIS_NO_GRAPH") != nullptr;
+  const bool want = b->graph_mode != 0 && !env_off && !b->timing && b->p.verbosity == 0 && (b->graph_mode == 1 || b->runs >= 1);
+  b->runs++;
+  if (!want) return run_levels(b, s);
+  if (b->graph_exec && b->graph_initflow != b->initflow) {
+    (void)hipGraphExecDestroy(b->graph_exec);
+    b->graph_exec = nullptr;
+  }
+  if (!b->graph_exec) {
+    if (!b->cap_stream && hipStreamCreateWithFlags(&b->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+      b->graph_mode = 0;
+      return run_levels(b, s);
+    }
+    hipGraph_t g = nullptr;
+    bool ok = hipStreamBeginCapture(b->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      const int rc = run_levels(b, b->cap_stream);
+      const hipError_t e = hipStreamEndCapture(b->cap_stream, &g);
+      ok = rc == OFDIS_OK && e == hipSuccess && g != nullptr;
+    }
+    if (ok) ok = hipGraphInstantiate(&b->graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
+    if (g) (void)hipGraphDestroy(g);
+    if (!ok) {
+      (void)hipGetLastError();
+      b->graph_exec = nullptr;
+      b->graph_mode = 0;
+      return run_levels(b, s);
+    }
+    b->graph_initflow = b->initflow;
+  }
+  HIPCHK(hipGraphLaunch(b->graph_exec, s));
+  return OFDIS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -760,6 +852,7 @@ int ofdis_batch_upload_initflow(ofdis_batch* b, int frame, const float* initflow
   const size_t n = ofdis_batch_initflow_elems(b);
   if (!b->initflow_own) {
     int rc = dalloc(b, &b->initflow_own, n * b->nframes);
+    if (!rc) rc = dcommit(b);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(b->initflow_own, 0, n * b->nframes * sizeof(float), (hipStream_t)stream));
   }
@@ -803,22 +896,118 @@ int ofdis_batch_kernel_time(ofdis_batch* b, int k, double* ms_sum, long* launche
 }
 
 // ------------------------------------------------------------------------------------ drop-in
+}  // extern "C"
+
+namespace {
+
+// The reference constructs one OFClass per frame pair (run_dense.cpp:391-400) and a video loop calls it again and again
+// with the same parameters.  Creating a device context per call would cost more than the computation, so ofdis_flow keeps
+// the contexts of the last few parameter sets (per device): device buffers in one allocation, a stream, pinned staging
+// for one upload of the whole pyramid and the download of the flow, and (from the second call on) the captured launch
+// graph.  Calls are serialised by a mutex -- the reference's constructor is single-threaded and synchronous too.
+struct FlowCtx {
+  ofdis_params p;
+  int device = -1;
+  ofdis_batch* b = nullptr;
+  hipStream_t s = nullptr;
+  char* stage = nullptr;  // pinned: [in_bytes of input planes][flow]
+  size_t flow_bytes = 0;
+  unsigned long stamp = 0;
+};
+std::mutex g_flow_mutex;
+std::vector<FlowCtx> g_flow_cache;
+unsigned long g_flow_stamp = 0;
+constexpr size_t kFlowCacheEntries = 4;
+
+void flow_ctx_release(FlowCtx& c) {
+  if (c.s) (void)hipStreamSynchronize(c.s);
+  if (c.b) ofdis_batch_destroy(c.b);
+  if (c.stage) (void)hipHostFree(c.stage);
+  if (c.s) (void)hipStreamDestroy(c.s);
+  c = FlowCtx();
+}
+
+int flow_ctx_get(const ofdis_params* p, FlowCtx** out) {
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  for (auto& c : g_flow_cache)
+    if (c.device == dev && memcmp(&c.p, p, sizeof(*p)) == 0) {
+      c.stamp = ++g_flow_stamp;
+      *out = &c;
+      return OFDIS_OK;
+    }
+  FlowCtx c;
+  int rc = ofdis_batch_create(&c.b, p, 1);
+  if (rc) return rc;
+  c.p = *p;
+  c.device = dev;
+  const LevelGeom& g0 = c.b->geom[0];
+  c.flow_bytes = (size_t)g0.w * g0.h * c.b->nop * sizeof(float);
+  hipError_t e = hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c.stage, c.b->in_bytes + c.flow_bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    flow_ctx_release(c);
+    return hipfail(e, "ofdis_flow context");
+  }
+  if (g_flow_cache.size() >= kFlowCacheEntries) {  // evict the least recently used
+    size_t lru = 0;
+    for (size_t i = 1; i < g_flow_cache.size(); ++i)
+      if (g_flow_cache[i].stamp < g_flow_cache[lru].stamp) lru = i;
+    flow_ctx_release(g_flow_cache[lru]);
+    g_flow_cache.erase(g_flow_cache.begin() + lru);
+  }
+  c.stamp = ++g_flow_stamp;
+  g_flow_cache.push_back(c);
+  *out = &g_flow_cache.back();
+  return OFDIS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ofdis_flow_cache_clear(void) {
+  std::lock_guard<std::mutex> lock(g_flow_mutex);
+  for (auto& c : g_flow_cache) flow_ctx_release(c);
+  g_flow_cache.clear();
+}
+
 int ofdis_flow(const ofdis_params* p, const float* const* im_a, const float* const* im_a_dx,
                const float* const* im_a_dy, const float* const* im_b, const float* const* im_b_dx,
                const float* const* im_b_dy, float* outflow, const float* initflow) {
   if (!outflow) return fail(OFDIS_ERR_INVALID, "outflow is NULL");
-  if (p && p->usefbcon && (!im_b_dx || !im_b_dy))  // otherwise never read
-    return fail(OFDIS_ERR_INVALID, "usefbcon needs the gradient pyramids of the second image");
-  ofdis_batch* b = nullptr;
-  int rc = ofdis_batch_create(&b, p, 1);
+  int rc = check_params(p);
   if (rc) return rc;
-  rc = ofdis_batch_upload(b, 0, im_a, im_a_dx, im_a_dy, im_b, nullptr);
-  if (!rc && p->usefbcon) rc = ofdis_batch_upload_b_gradients(b, 0, im_b_dx, im_b_dy, nullptr);
-  if (!rc && initflow) rc = ofdis_batch_upload_initflow(b, 0, initflow, nullptr);
-  if (!rc) rc = ofdis_batch_run(b, nullptr);
-  if (!rc) rc = ofdis_batch_download(b, 0, outflow, nullptr);
-  ofdis_batch_destroy(b);
-  return rc;
+  if (!im_a || !im_a_dx || !im_a_dy || !im_b) return fail(OFDIS_ERR_INVALID, "pyramid array is NULL");
+  if (p->usefbcon && (!im_b_dx || !im_b_dy))  // otherwise never read
+    return fail(OFDIS_ERR_INVALID, "usefbcon needs the gradient pyramids of the second image");
+  std::lock_guard<std::mutex> lock(g_flow_mutex);
+  FlowCtx* c = nullptr;
+  rc = flow_ctx_get(p, &c);
+  if (rc) return rc;
+  ofdis_batch* b = c->b;
+  // the whole pyramid through pinned staging in one copy (the planes mirror the device layout)
+  const float* const* src[6] = {im_a, im_a_dx, im_a_dy, im_b, im_b_dx, im_b_dy};
+  const int nin = p->usefbcon ? 6 : 4;
+  for (int l = p->sc_l; l <= p->sc_f; ++l)
+    for (int k = 0; k < nin; ++k) {
+      if (!src[k][l]) return fail(OFDIS_ERR_INVALID, "pyramid level pointer is NULL");
+      memcpy(c->stage + ((char*)b->in[k][l - p->sc_l] - b->in_base), src[k][l], b->g(l).plane_elems * sizeof(float));
+    }
+  HIPCHK(hipMemcpyAsync(b->in_base, c->stage, b->in_bytes, hipMemcpyHostToDevice, c->s));
+  if (initflow) {
+    rc = ofdis_batch_upload_initflow(b, 0, initflow, c->s);
+    if (!rc) HIPCHK(hipStreamSynchronize(c->s));  // the caller's array is pageable and may go away after the call
+  } else {
+    b->initflow = nullptr;  // a previous call on this context may have warm-started
+  }
+  if (!rc) rc = ofdis_batch_run(b, c->s);
+  if (rc) return rc;
+  char* out_stage = c->stage + b->in_bytes;
+  HIPCHK(hipMemcpyAsync(out_stage, b->flow[0], c->flow_bytes, hipMemcpyDeviceToHost, c->s));
+  HIPCHK(hipStreamSynchronize(c->s));
+  memcpy(outflow, out_stage, c->flow_bytes);
+  return OFDIS_OK;
 }
 
 // ------------------------------------------------------------------------------------ per-function
@@ -954,9 +1143,10 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
     if (!rc) rc = dalloc(&b, &b.wy_d, npx);
     if (!rc) rc = dalloc(&b, &b.mask_d, npx);
   }
+  if (!rc && p->selectmode == 2) rc = dalloc(&b, &b.uu, npx);
+  if (!rc) rc = dcommit(&b);
   if (!rc && p->selectmode == 2) {  // one channel: wx = flow, wy = 0
     b.nop = 1;
-    rc = dalloc(&b, &b.uu, npx);
     hipError_t e = hipMemcpyAsync(b.wx, flow, npx * sizeof(float), hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(b.wy, 0, npx * sizeof(float), s);
     if (e != hipSuccess) rc = hipfail(e, "stereo flow copy");
@@ -986,6 +1176,10 @@ int ofdis_test_wave_sum(const float* in, float* out, int n, void* stream) {
 
 // test hook (not declared in ofdis.h; host only, needs no GPU): the squared outlier threshold of the patch kernels
 float ofdis_test_outlier_sq(float t) { return outlier_sq_threshold(t); }
+
+// test hook (not declared in ofdis.h): wavefront budget of the multi-wave fused TV kernel (0 = single-wave kernel only,
+// large = multi-wave whenever the iteration count allows, < 0 = default)
+void ofdis_test_set_fused_mw_max(int waves) { set_tv_fused_mw_max(waves); }
 
 // test hook (not declared in ofdis.h): trimmed divide / sqrt next to the compiler's IEEE expansion
 int ofdis_test_div_sqrt(const float* a, const float* b, float* out, int n, void* stream) {

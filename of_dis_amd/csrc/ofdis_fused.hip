@@ -28,9 +28,22 @@
 // the fill/drain bubble of the skewed sweep from every iteration but the first and last:
 // n_inner*w + h steps instead of n_inner*(w + h).
 //
+// Small batches (MW = true, "multi-wave"): with fewer wavefronts than SIMDs the kernel above is bound by the latency of
+// ONE wavefront walking n_inner*w + h diagonal steps (1.1 ms for the three levels of operating point 2), whatever the
+// batch size.  The fixed-point iterations of a level form a second pipeline: iteration k+1 needs, around a pixel, only
+// du/dv of iteration k, and those are final 2(NS-1) steps after sweep 0 passed.  So a WORKGROUP of n_inner wavefronts
+// takes one frame group, wavefront k runs iteration k and trails wavefront k-1 by MW_LAG diagonal steps; the du/dv rows
+// travel from wavefront k to k+1 through an LDS ring (8 rows deep, indexed by the unwrapped step number, so the two
+// visits of a wrapped diag row never alias), one workgroup barrier per step keeps the wavefronts in lock step.  Steps per
+// level: w + h + (n_inner-1)*MW_LAG instead of n_inner*w + h (221 / 139 / 103 instead of 568 / 348 / 206 at 1024x436
+// op-2).  Same arithmetic, same order: bit-identical results.  The launcher picks this variant while the batch leaves
+// SIMDs idle (launch_tv_fused).
+//
 // Border rules: horizontal neighbours are clamped exactly as the reference's shifted row copies
 // (image.c:436-464); for the 3-tap vertical filter the clamped form c0*s0 + c1*s0 + c2*s1 has the same
 // value as the reference's folded (c0+c1)*s0 + c2*s1 because c1 = -0 (image.c:376-399).
+#include <stdlib.h>
+
 #include "ofdis_kernels.h"
 #include "ofdis_tvmath.h"
 
@@ -97,9 +110,15 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
 // every such system has at least one positive edge weight (quarter_alpha > 0 is a launch condition, a pixel is
 // never first and last column at once), so det >= (sum of weights)^2 > 0; the slot ring starts with a unit
 // diagonal and unit weights.
-template <int NS, bool BRIGHT>
-__global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const int R) {
+constexpr int MW_LAG = 10;      // steps between consecutive iterations' wavefronts: PDW + 2*(NS-1) + 1 for NS = 3
+constexpr int MW_MAX_ITERS = 8;  // wavefronts per workgroup (= fixed-point iterations handled by the multi-wave variant)
+constexpr int MW_RING = 8;       // LDS rows per producer wavefront
+
+template <int NS, bool BRIGHT, bool MW>
+__global__ __launch_bounds__(MW ? 64 * MW_MAX_ITERS : 256) void tv_fused_kernel(const FusedArgs a, const int R) {
   constexpr int U = 6;
+  // du/dv rows handed from the wavefront of iteration k to the wavefront of iteration k+1: [k][step & 7][lane]
+  __shared__ float2 xring[MW ? (MW_MAX_ITERS - 1) * MW_RING * 64 : 1];
   // prefetch distances: the W row (wx,wy,du,dv) of diag row t+PDW and the D row (8 derivatives + mask) of row t+PDD are
   // requested at step t; first uses are rows t+3 (uu, vv) and t+1 (data term).  (5, 3) = two steps of slack, 141 VGPRs,
   // 3 wavefronts per SIMD; (4, 2) = one step of slack, 128 VGPRs, 4 wavefronts per SIMD measured the same kernel time
@@ -110,10 +129,14 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
 #endif
   constexpr int PDW = OFDIS_FUSED_PDW, PDD = OFDIS_FUSED_PDD;
   static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
+  static_assert(!MW || MW_LAG >= PDW + 2 * (NS - 1) + 1, "a row must be published before the next iteration prefetches it");
   const int w = a.t.w, h = a.t.h;
   const int npx = w * h;
   const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  // MW: one frame group per workgroup, wavefront `it` runs fixed-point iteration `it` of n_iters
+  const int it = MW ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  const int n_iters = MW ? (int)(blockDim.x >> 6) : 1;
+  const int wid = MW ? (int)blockIdx.x : __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int G = 64 / R;  // frames per wavefront
   const int f0 = wid * G;
   if (f0 >= a.t.nframes) return;  // whole wave idle (uniform)
@@ -165,9 +188,20 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
   auto wrap = [&](int r) { r %= w; return r < 0 ? r + w : r; };
   auto next_row = [&](int r) { return (r + 1 == w) ? 0 : r + 1; };
   const int row_bytes = h * 4;
-  auto load_w = [&](FRow& r, int drow) {
+  // tau = unwrapped step number of the row (MW only): the LDS ring slot
+  auto load_w = [&](FRow& r, int drow, int tau) {
     const int o = drow * row_bytes;
-    r.wx = ldf(rsWx, vo1, o); r.wy = ldf(rsWy, vo1, o); r.du = ldf(rsU, vo1, o); r.dv = ldf(rsV, vo1, o);
+    r.wx = ldf(rsWx, vo1, o); r.wy = ldf(rsWy, vo1, o);
+    if constexpr (MW) {
+      if (it == 0) {  // first fixed-point iteration: du = dv = 0 (image_erase, refine_variational.cpp:186-187)
+        r.du = 0.0f; r.dv = 0.0f;
+      } else {
+        const float2 v = xring[((it - 1) * MW_RING + (tau & (MW_RING - 1))) * 64 + lane];
+        r.du = v.x; r.dv = v.y;
+      }
+    } else {
+      r.du = ldf(rsU, vo1, o); r.dv = ldf(rsV, vo1, o);
+    }
   };
   auto load_d = [&](FDer& r, int drow) {
     const int o = drow * row_bytes;
@@ -179,30 +213,40 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
   // ring index of diag row rho is (rho + 3) mod ring size; the loop variable is k = t + 3, u = k % 6,
   // so row t + c sits at index (u + c) % size.
   // prologue: W rows -1, 0, 1 (indices 2, 3, 4)
-  load_w(W[2], wrap(-1));
-  load_w(W[3], wrap(0));
-  if (PDW == 5) load_w(W[4], wrap(1));
+  if constexpr (MW) {  // the ring of this wavefront's successor starts with zeros (finite: see "Border handling")
+#pragma unroll
+    for (int q = 0; q < MW_RING; ++q)
+      if (it < MW_MAX_ITERS - 1) xring[(it * MW_RING + q) * 64 + lane] = make_float2(0.0f, 0.0f);
+    __syncthreads();
+    for (int n = 0; n < it * MW_LAG; ++n) __syncthreads();  // trail the previous iteration by MW_LAG steps
+  }
+  load_w(W[2], wrap(-1), -1);
+  load_w(W[3], wrap(0), 0);
+  if (PDW == 5) load_w(W[4], wrap(1), 1);
   // du, dv are zero before the first fixed-point iteration (refine_variational.cpp:186-187): the kernel never reads
   // them during its first pass over the columns, so the caller does not have to clear them
-  W[2].du = W[2].dv = W[3].du = W[3].dv = W[4].du = W[4].dv = 0.0f;
+  if (!MW) W[2].du = W[2].dv = W[3].du = W[3].dv = W[4].du = W[4].dv = 0.0f;
   int rowW = wrap(PDW - 3);  // next W row to load (row t+PDW at t = -3)
+  int tauW = PDW - 3;        // ... and its unwrapped step number
   int rowD = wrap(PDD - 3);  // next D row to load (row t+PDD at t = -3)
   int srow = wrap(-3 - 2 * (NS - 1));  // row finished by the last sweep at step t = -3
   int x2 = wrap(-1 - j);               // this lane's x on diag row t+2 (per lane)
   bool x1_last = (wrap(-2 - j) == w - 1);  // row t+1 is this lane's last column
 
-  const int wtot = a.n_inner * w;  // columns per lane over all iterations
+  const int wtot = (MW ? 1 : a.n_inner) * w;  // columns per lane over all iterations of this wavefront
   const int tend = (wtot - 1) + (h - 1) + 2 * (NS - 1);
   int ig = -3 - j - 2 * (NS - 1);  // global column (over all iterations) the last sweep finishes at step t
-  bool first_w = true;             // row t+5 at t = -3 is column 2 - j: first iteration (w >= 16)
+  bool first_w = !MW;              // row t+5 at t = -3 is column 2 - j: first iteration (w >= 16)
+  int taus = -3 - 2 * (NS - 1);    // unwrapped step number of the row the last sweep finishes (MW)
   for (int k0 = 0; k0 <= tend + 3; k0 += U) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // step t = k0 + u - 3; up to U-1 steps past tend are executed: every pixel is then out of range
       // ---- (1) loads: W row t+5, D row t+3
-      load_w(W[(u + PDW) % 6], rowW);
+      load_w(W[(u + PDW) % 6], rowW, tauW);
       rowW = next_row(rowW);
-      if (first_w) {  // this lane's column on row t+5 still belongs to the first iteration: du = dv = 0 (image_erase)
+      ++tauW;
+      if (!MW && first_w) {  // this lane's column on row t+5 still belongs to the first iteration: du = dv = 0 (image_erase)
         W[(u + PDW) % 6].du = 0.0f;
         W[(u + PDW) % 6].dv = 0.0f;
       }
@@ -301,13 +345,17 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
         nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
       }
       {
-        first_w = ig + (PDW + 1 + 2 * (NS - 1)) < w;  // for the next step's row
-        if (row_ok && ig >= 0 && ig < wtot) {
+        if (!MW) first_w = ig + (PDW + 1 + 2 * (NS - 1)) < w;  // for the next step's row
+        if (MW && it < n_iters - 1) {  // hand the row to the next iteration's wavefront (lanes outside their columns
+          // publish finite values nobody reads as a pixel: the reader's lane is outside its columns at the same step number)
+          xring[(it * MW_RING + (taus & (MW_RING - 1))) * 64 + lane] = make_float2(nu[NS - 1], nv[NS - 1]);
+        } else if (row_ok && ig >= 0 && ig < wtot) {
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nu[NS - 1]), rsU, vo1, srow * row_bytes, 0);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nv[NS - 1]), rsV, vo1, srow * row_bytes, 0);
         }
         srow = next_row(srow);
         ++ig;
+        ++taus;
       }
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -316,7 +364,11 @@ __global__ __launch_bounds__(256) void tv_fused_kernel(const FusedArgs a, const 
       }
       x1_last = x2_last;
       x2 = x2_last ? 0 : x2 + 1;
+      if constexpr (MW) __syncthreads();  // the row published in this step is read by the next wavefront >= 1 step later
     }
+  }
+  if constexpr (MW) {  // keep the barrier count equal for all wavefronts of the workgroup
+    for (int n = 0; n < (n_iters - 1 - it) * MW_LAG; ++n) __syncthreads();
   }
 }
 
@@ -329,6 +381,20 @@ bool tv_fused_params_ok(float qa, float hd3, float hg3) {
   return qa > 0.0f && ok(qa) && ok(hd3) && ok(hg3);  // qa == 0: no smoothness at all, singular systems possible
 }
 
+// Wavefront budget of the multi-wave variant: it is chosen while (frame groups x iterations) stays below this many
+// wavefronts, i.e. while the single-wave mapping would leave most SIMDs (1024 on MI355X) without work.
+// OFDIS_FUSED_MW_MAX overrides it (0 = never use the multi-wave variant); read once.
+static int g_mw_max = -1;  // -1: not initialised
+static int mw_max_waves() {
+  if (g_mw_max < 0) {
+    const char* e = getenv("OFDIS_FUSED_MW_MAX");
+    g_mw_max = e ? atoi(e) : 2048;
+    if (g_mw_max < 0) g_mw_max = 0;
+  }
+  return g_mw_max;
+}
+void set_tv_fused_mw_max(int waves) { g_mw_max = waves; }  // test hook / tuning: < 0 = back to the default
+
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s) {
   if (!tv_fused_supported(a.t, a.iterations) || a.n_inner < 1 ||
       !tv_fused_params_ok(a.quarter_alpha, a.half_delta_over3, a.half_gamma_over3))
@@ -339,9 +405,13 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s) {
   const int waves = (a.t.nframes + G - 1) / G;
   const int blocks = (waves + 3) / 4;
   const bool bright = a.half_delta_over3 != 0.0f;
-#define OFDIS_FUSED_LAUNCH(NS)                                                                        \
-  if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true>), dim3(blocks), dim3(256), 0, s, a, R);  \
-  else hipLaunchKernelGGL((tv_fused_kernel<NS, false>), dim3(blocks), dim3(256), 0, s, a, R)
+  const bool mw = a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS && (long long)waves * a.n_inner <= mw_max_waves();
+#define OFDIS_FUSED_LAUNCH(NS)                                                                                        \
+  if (mw) {                                                                                                           \
+    if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, true>), dim3(waves), dim3(64 * a.n_inner), 0, s, a, R); \
+    else hipLaunchKernelGGL((tv_fused_kernel<NS, false, true>), dim3(waves), dim3(64 * a.n_inner), 0, s, a, R);       \
+  } else if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, false>), dim3(blocks), dim3(256), 0, s, a, R);     \
+  else hipLaunchKernelGGL((tv_fused_kernel<NS, false, false>), dim3(blocks), dim3(256), 0, s, a, R)
   switch (a.iterations) {
     case 1: OFDIS_FUSED_LAUNCH(1); break;
     case 2: OFDIS_FUSED_LAUNCH(2); break;

@@ -126,6 +126,8 @@ bool tv_fused_supported(const TvGeom& t, int iterations);
 // the fused kernel's trimmed divisions (ofdis_dev.h) need the three weights to be 0 or of ordinary magnitude
 bool tv_fused_params_ok(float quarter_alpha, float half_delta_over3, float half_gamma_over3);
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s);
+// wavefront budget below which the multi-wave (iteration-pipelined) variant is launched; < 0 restores the default
+void set_tv_fused_mw_max(int waves);
 
 // layout conversion of `nplanes` planes of w x h (row-major <-> diag); used by the per-function entry
 // points, whose public interface is row-major

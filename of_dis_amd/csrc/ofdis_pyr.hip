@@ -5,8 +5,10 @@
 // gradients) by imgpadding.
 //
 // Exactness.  For 8-bit input every level-l value is the mean of a 2^l x 2^l block of integers: a
-// dyadic rational with at most 8+2l significant bits, exactly representable in fp32 for l <= 8, and
-// every Sobel/8 value likewise (3 more bits).  All fp32 sums involved are therefore exact, so the
+// dyadic rational with at most 8+2l significant bits, and every Sobel partial sum (two differences, one doubled) one
+// with at most 10+2l: exactly representable in fp32 for l <= 7 -- the launcher's limit (at l = 8 the 26-bit partial
+// sums would round, and OpenCV's f1*(S0+S2) + f0*S1 and this file's (d0 + 2*d1) + d2 could differ in the last bit).
+// All fp32 sums involved are therefore exact, so the
 // hierarchical 2x2 means OpenCV computes, an integer block sum scaled by 4^-l, and any summation
 // order give bit-identical results.  Only levels sc_l..sc_f are materialised (the reference builds
 // all of 0..sc_f, run_dense.cpp:132, and never reads the rest), and image B gets no gradients (never

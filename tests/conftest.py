@@ -39,3 +39,13 @@ def orc():
     o = oracle.c_oracle()
     o.set_reduce_order(True)
     return o
+
+
+@pytest.fixture(params=["single-wave", "multi-wave"])
+def tv_variant(gpu, request):
+    """Both mappings of the fused TV kernel (ofdis_fused.hip): one wavefront walking all fixed-point iterations of a
+    frame group, or a workgroup with one wavefront per iteration (the small-batch variant the launcher would pick by
+    itself for these test sizes).  Bit-identical results are required of both."""
+    gpu.lib().ofdis_test_set_fused_mw_max(0 if request.param == "single-wave" else 1 << 30)
+    yield request.param
+    gpu.lib().ofdis_test_set_fused_mw_max(-1)

@@ -39,7 +39,7 @@ def test_flow_dropin_bit_exact(gpu, orc, size, opp, tv):
     assert oracle.epe_stats(full, gt)[0] < 1.0
 
 
-def test_batch_matches_single_and_is_deterministic(gpu, orc):
+def test_batch_matches_single_and_is_deterministic(gpu, orc, tv_variant):
     """Frames are independent: a frame's result must not depend on its batch slot or neighbours."""
     cases = [synth_case(1024, 436, 1234 + k, 1, 2, 1) for k in range(3)]
     p = cases[0][0]
@@ -75,6 +75,63 @@ def test_upsample_crop_on_device(gpu, orc, size, opp):
     b.close()
     for k in range(2):
         assert_bits_equal(full[k], orc.upsample_crop(p, low[k], w, h), f"full-resolution flow, frame {k}")
+
+
+@pytest.mark.parametrize("mode", [-1, 0, 1])
+def test_launch_graph_replay(gpu, orc, mode):
+    """ofdis_batch_set_graph: the schedule replayed as one hipGraph launch (automatic mode captures at the second pass)
+    must give the bits of the direct launches, also after the inputs or the warm start of the context changed."""
+    cases = [synth_case(1024, 436, 1700 + k, 1, 2, 1) for k in range(3)]
+    p = cases[0][0]
+    refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
+    b = gpu.Batch(p, 3)
+    b.set_graph(mode)
+    for k, (_, pa, pb, _, _) in enumerate(cases):
+        b.upload(k, pa[0], pa[1], pa[2], pb[0])
+    for rep in range(4):
+        b.run()
+        out = b.download_all()
+        for k in range(3):
+            assert_bits_equal(out[k], refs[k], f"graph mode {mode}, pass {rep}, frame {k}")
+    # new inputs in the same buffers: the replayed graph must see them
+    _, pa, pb, _, _ = cases[2]
+    b.upload(0, pa[0], pa[1], pa[2], pb[0])
+    b.run()
+    assert_bits_equal(b.download_all()[0], refs[2], "replay after re-upload")
+    # a warm start changes a kernel argument: the graph is rebuilt
+    w, h = p.level_size(p.sc_f)
+    init = (np.random.default_rng(5).standard_normal((h // 2, w // 2, 2)) * 0.5).astype(np.float32)
+    b.upload_initflow(1, init)
+    b.run()
+    c = cases[1]
+    assert_bits_equal(b.download_all()[1], orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0], initflow=init), "warm start")
+    b.set_initflow(None)
+    b.run()
+    assert_bits_equal(b.download_all()[1], refs[1], "warm start off again")
+    b.close()
+
+
+def test_dropin_context_cache(gpu, orc):
+    """ofdis_flow keeps device contexts between calls (one per parameter set): repeated calls, alternating parameter
+    sets, more sets than cache entries, warm start on / off on a cached context, and a cleared cache."""
+    sizes = [(1024, 436), (640, 480), (320, 240), (256, 128), (512, 256), (384, 192)]
+    cases = [synth_case(w, h, 1800 + i, 1, 2, 1) for i, (w, h) in enumerate(sizes)]
+    refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
+    for rnd in range(3):
+        for i, (p, pa, pb, _, _) in enumerate(cases):   # six parameter sets > four cache entries: evictions
+            assert_bits_equal(gpu.flow(p, pa[0], pa[1], pa[2], pb[0]), refs[i], f"round {rnd}, set {i}")
+    p, pa, pb, _, _ = cases[0]
+    for rep in range(5):                                 # the same context again and again (graph replay from call 2)
+        assert_bits_equal(gpu.flow(p, pa[0], pa[1], pa[2], pb[0]), refs[0], f"repeat {rep}")
+    p2, qa, qb, _, _ = synth_case(1024, 436, 1900, 1, 2, 1)   # same parameters, other images: same context
+    assert_bits_equal(gpu.flow(p2, qa[0], qa[1], qa[2], qb[0]), orc.flow(p2, qa[0], qa[1], qa[2], qb[0]), "other pair")
+    w, h = p.level_size(p.sc_f)
+    init = (np.random.default_rng(7).standard_normal((h // 2, w // 2, 2)) * 0.5).astype(np.float32)
+    assert_bits_equal(gpu.flow(p, pa[0], pa[1], pa[2], pb[0], initflow=init),
+                      orc.flow(p, pa[0], pa[1], pa[2], pb[0], initflow=init), "warm start on a cached context")
+    assert_bits_equal(gpu.flow(p, pa[0], pa[1], pa[2], pb[0]), refs[0], "cold again on the same context")
+    gpu.lib().ofdis_flow_cache_clear()
+    assert_bits_equal(gpu.flow(p, pa[0], pa[1], pa[2], pb[0]), refs[0], "after ofdis_flow_cache_clear")
 
 
 def test_initflow_warm_start(gpu, orc):

@@ -179,7 +179,7 @@ def test_patchgrid_levels(gpu, orc, size, opp, tv):
 
 
 @pytest.mark.parametrize("size", [(1024, 436), (640, 480)])
-def test_varref_levels(gpu, orc, size):
+def test_varref_levels(gpu, orc, size, tv_variant):
     p, pa, pb, _, _ = synth_case(size[0], size[1], 1234, 1, 2, 1)
     rng = np.random.default_rng(6)
     for l in range(p.sc_f, p.sc_l - 1, -1):
@@ -196,7 +196,7 @@ def test_varref_levels(gpu, orc, size):
     (25.0, 4.0, 1.0, 1, 1, 1.0),      # one sweep, plain Gauss-Seidel
     (1e-13, 10.0, 5.0, 1, 3, 1.6),    # weight below the fused kernel's range: the unfused path must take over
 ])
-def test_varref_parameter_variants(gpu, orc, alpha, gamma, delta, innerit, solverit, sor):
+def test_varref_parameter_variants(gpu, orc, alpha, gamma, delta, innerit, solverit, sor, tv_variant):
     p, pa, pb, _, _ = synth_case(320, 240, 77, 1, 2, 1)
     p.tv_alpha, p.tv_gamma, p.tv_delta = alpha, gamma, delta
     p.tv_innerit, p.tv_solverit, p.tv_sor = innerit, solverit, sor
@@ -210,7 +210,7 @@ def test_varref_parameter_variants(gpu, orc, alpha, gamma, delta, innerit, solve
 
 
 @pytest.mark.parametrize("w,h", [(38, 38), (64, 64), (56, 56), (24, 24), (16, 16), (40, 38), (36, 40), (17, 33), (64, 60)])
-def test_varref_square_and_near_square_levels(gpu, orc, w, h):
+def test_varref_square_and_near_square_levels(gpu, orc, w, h, tv_variant):
     """The fused TV kernel's fill phase once produced an all-zero system (0/0) for the lane whose first fill pixel is a
     last-column pixel of the last image row -- exactly when w == h -- and 0 * NaN then poisoned that row."""
     import gen_synth
@@ -228,7 +228,7 @@ def test_varref_square_and_near_square_levels(gpu, orc, w, h):
 
 
 @pytest.mark.parametrize("seed", range(48))
-def test_random_varref_levels(gpu, orc, seed):
+def test_random_varref_levels(gpu, orc, seed, tv_variant):
     """Random level geometry (mostly in the fused kernel's range: gray, 2 <= h <= 64, w >= 16; some outside it and some
     RGB), random TV parameters and a random incoming flow with out-of-image displacements."""
     import gen_synth

@@ -27,6 +27,26 @@ def test_frame_range_partitions():
         shard.frame_range(10, 2, 2)
 
 
+def test_bench_frames_depend_on_global_index_only():
+    """bench.py's synthetic frames: a frame's content is a function of its global index, whatever range it is generated in
+    (so a frame is the same problem on whichever rank it lands)."""
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    dev = torch.device("cpu")
+    a0, b0 = bench.synth_frames_range(0, 70, 64, 48, 1234, dev)
+    a1, b1 = bench.synth_frames_range(30, 70, 64, 48, 1234, dev)
+    a2, b2 = bench.synth_frames_range(33, 34, 64, 48, 1234, dev)
+    assert a0.shape == (70, 48, 64) and a0.dtype == torch.uint8
+    assert torch.equal(a0[30:], a1) and torch.equal(b0[30:], b1)
+    assert torch.equal(a0[33:34], a2) and torch.equal(b0[33:34], b2)
+    assert not torch.equal(a0[0], a0[1]) and not torch.equal(a0[0], b0[0])
+    c, _ = bench.synth_frames_range(0, 2, 64, 48, 99, dev, channels=3)
+    assert c.shape == (2, 48, 64, 3)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -100,24 +120,69 @@ def test_two_ranks_gloo(tmp_path):
         assert np.array_equal(got[g], O.flow(p, pa[0], pa[1], pa[2], pb[0])), g
 
 
-@pytest.mark.gpu
-def test_bench_two_ranks_control_flow(gpu):
-    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), on a
-    one-GPU box: both ranks share device 0 and rendezvous over gloo (developer switches in bench.py) -- the barrier /
-    max-over-ranks / rank-0 report path is the one the RCCL run takes."""
+def _bench_env(gpu):
+    """Two ranks need two GPUs for RCCL (it refuses two ranks on one device); on a one-GPU box the developer switches of
+    bench.py put both ranks on device 0 and rendezvous over gloo -- the same control flow otherwise."""
+    if gpu.lib().ofdis_device_count() >= 2:
+        return dict(os.environ), "rccl (torch.distributed nccl)"
+    return dict(os.environ, OFDIS_BENCH_BACKEND="gloo", OFDIS_BENCH_SHARE_GPU="1"), "gloo"
+
+
+def _run_bench(cmd, env):
     import json
     import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, OFDIS_BENCH_BACKEND="gloo", OFDIS_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--batch", "64", "--cpu-seconds", "0"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                      # exactly one JSON line, from rank 0
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_under_torchrun(gpu):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env, backend = _bench_env(gpu)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch", "64", "--cpu-seconds", "0", "--no-extras"]
+    d = _run_bench(cmd, env)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_frames_per_step"] == 128
+    assert d["config"]["ranks"] == {"world_size": 2, "backend": backend, "launch": "torch.distributed.run"}
     assert d["parity_check"].startswith("bit-exact")
+    assert d["multi_gpu_check"]["bit_identical_to_1gpu"] and d["multi_gpu_check"]["frames_compared"] == 32
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` as a PLAIN process (no torchrun): it starts one rank per GPU itself, the ranks
+    rendezvous, and one JSON line with n_gpus = 2 comes back."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env, backend = _bench_env(gpu)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    d = _run_bench([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                    "--batch", "96", "--cpu-seconds", "0", "--no-extras"], env)
+    assert d["n_gpus"] == 2 and d["config"]["global_frames_per_step"] == 192
+    assert d["config"]["ranks"] == {"world_size": 2, "backend": backend, "launch": "self-spawned by bench.py --gpus"}
+    assert d["multi_gpu_check"]["bit_identical_to_1gpu"]
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_partition(gpu):
+    """BASELINE configs[4] in small: a FIXED batch (--total-frames) cut into contiguous per-rank shares; every frame of
+    the other rank is re-computed on rank 0's GPU and must have the same bits."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env, _ = _bench_env(gpu)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    d = _run_bench([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--total-frames", "75", "--steps", "2",
+                    "--warmup", "1", "--cpu-seconds", "0", "--no-extras"], env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["global_frames_per_step"] == 75 and d["config"]["frames_per_gpu_per_step"] == [38, 37]
+    assert d["multi_gpu_check"] == {**d["multi_gpu_check"], "frames_compared": 37, "mismatches": 0, "bit_identical_to_1gpu": True}
+    assert d["parity_check"].startswith("bit-exact")
