@@ -153,7 +153,7 @@ def frame_planes(capi, p, batch, f):
     return planes
 
 
-def cpu_baseline(p, batch, nsample, budget_s, mode="int"):
+def cpu_baseline(p, batch, nsample, budget_s, mode="int", org=(WIDTH, HEIGHT)):
     """Reference CPU path (one thread) on `nsample` frames of this batch; pyramids copied back from HBM."""
     import numpy as np
     import oracle
@@ -165,18 +165,33 @@ def cpu_baseline(p, batch, nsample, budget_s, mode="int"):
     frames = [frame_planes(capi, p, batch, f) for f in range(nsample)]
     pq = p.copy(verbosity=0)
     # the metric's second half: end-point error of the HIP result against the reference's own output (its plain,
-    # sequential-sum build -- NOT the defined-order build the bit-exact check uses), in full-resolution pixels: the
-    # .flo is this flow times 2^sc_l before an interpolation that cannot increase a difference
-    err = []
-    t_first = time.perf_counter()
+    # sequential-sum build -- NOT the defined-order build the bit-exact check uses).  The metric is defined on the .flo,
+    # i.e. AFTER x2^sc_l, bilinear upsampling and cropping (run_dense.cpp:406-414): the HIP side goes through
+    # ofdis_batch_upsample on the device, the reference side through the oracle's restatement of cv::resize (pinned by
+    # tests/test_upsample_pin.py), both at the original resolution.
+    small = capi.Batch(p, len(frames))
+    for f, planes in enumerate(frames):
+        small.upload(f, planes[0], planes[1], planes[2], planes[3])
+    small.run()
+    wo, ho = org
+    got_full = small.upsample(wo, ho)
+    got_low = small.download_all()
+    small.close()
+    O = oracle.c_oracle()
+    err, err_low = [], []
+    t_first = 0.0
     for f, planes in enumerate(frames):  # also the warm-up
+        t1 = time.perf_counter()
         ref = R.flow(pq, planes[0], planes[1], planes[2], planes[3])
-        got = batch.download(f)
-        err.append(np.sqrt(((got.astype(np.float64) - ref.astype(np.float64)) ** 2).sum(-1)) * (1 << p.sc_l))
-    t_first = time.perf_counter() - t_first
-    err = np.stack(err)
+        t_first += time.perf_counter() - t1
+        ref_full = O.upsample_crop(p, ref, wo, ho)
+        err.append(np.sqrt(((got_full[f].astype(np.float64) - ref_full.astype(np.float64)) ** 2).sum(-1)))
+        err_low.append(np.sqrt(((got_low[f].astype(np.float64) - ref.astype(np.float64)) ** 2).sum(-1)) * (1 << p.sc_l))
+    err, err_low = np.stack(err), np.stack(err_low)
     epe = {"mean_px": float(err.mean()), "max_px": float(err.max()), "frac_above_1e-3": float((err > 1e-3).mean()),
-           "frames": len(frames), "against": "reference CPU build with sequential sums" if kind == "reference"
+           "frames": len(frames), "where": f"full-resolution flow ({wo}x{ho}) after x{1 << p.sc_l} upsample + crop, as written to the .flo",
+           "at_computed_level_scaled": {"mean_px": float(err_low.mean()), "max_px": float(err_low.max())},
+           "against": "reference CPU build with sequential sums" if kind == "reference"
            else "C restatement with sequential sums"}
     n_eval, t0 = 0, time.perf_counter()
     best = 1e9
@@ -379,7 +394,7 @@ def block_config4(capi, torch, p, batch, ia, ib, stream, dev, args):
            "kernels": kernels}
     if args.cpu_seconds > 0:
         try:
-            out["cpu_baseline"] = cpu_baseline(p4, b4, 1, 1.0, mode="rgb")
+            out["cpu_baseline"] = cpu_baseline(p4, b4, 1, 1.0, mode="rgb", org=(W4, H4))
             out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "kind": "unavailable", "sample": f"{type(e).__name__}: {e}"}

@@ -87,6 +87,13 @@ def build(force=False, verbose=False):
                 _run(["g++", "-O2", "-std=c++17", "-Wall", f"-DOFDIS_NOC={noc}", f"-DOFDIS_MODE={mode}", "-I",
                       os.path.join(ROOT, "include")]
                      + host_srcs + ["-o", exe, "-L", LIBDIR, "-lofdis_hip", "-lz", "-Wl,-rpath,$ORIGIN"], verbose)
+    # the plain-C caller of the drop-in boundary (tests/c/dropin_test.c): compiled as C99 against include/ofdis.h
+    c_test = os.path.join(ROOT, "tests", "c", "dropin_test.c")
+    if os.path.exists(c_test):
+        exe = os.path.join(LIBDIR, "dropin_test")
+        if force or _newer(exe, [c_test, os.path.join(ROOT, "include", "ofdis.h"), so]):
+            _run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", "-D_POSIX_C_SOURCE=199309L", "-I",
+                  os.path.join(ROOT, "include"), c_test, "-o", exe, "-L", LIBDIR, "-lofdis_hip", "-Wl,-rpath,$ORIGIN"], verbose)
     return so
 
 

@@ -62,19 +62,25 @@ __device__ __forceinline__ float patch_sum(const float (&x)[M * (64 / LPP)], con
   }
 }
 
-// FULL: novals == 64*M, every entry slot is a real patch entry (the validity selects fold away);
+// NV: novals as a compile-time constant (0 = read it from the arguments): entry slots that are real patch entries in every
+//     lane then lose their validity selects (all of them when NV == 64*M), and the tuned instantiations (NV > 0) use the
+//     trimmed correctly-rounded divide / square root of ofdis_dev.h (same bits inside the operand ranges DESIGN.md
+//     "Divide and square root" states for the patch kernels: quotients whose numerators are sums of products of
+//     image-derived values, square roots of differences of such values);
 // COST: the cost function as a compile-time constant, or -1 to read it from the arguments.
-template <int M, int LPP, bool FULL, int COST>
+template <int M, int LPP, int NV, int COST>
 __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   constexpr int Q = 64 / LPP;  // patches per wavefront == accumulation chains per lane
   constexpr int E = M * Q;     // patch entries per lane
+  constexpr bool FULL = NV == 64 * M;
+  constexpr bool TRIM = NV > 0;
   const int costfct = COST >= 0 ? COST : a.costfct;
   const LevelGeom& g = a.g;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int blocks_per_frame = (g.nop + 4 * Q - 1) / (4 * Q);
   int frame, blk;
-  xcd_frame_map(blockIdx.x, blocks_per_frame, frame, blk);
+  xcd_frame_map(blockIdx.x, blocks_per_frame, a.nframes, frame, blk);
   if (frame >= a.nframes) return;  // block-uniform
   const int sub = lane / LPP;
   const int pl = lane % LPP;
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   if (Q == 1 && !live) return;
   if (!live) ip = g.nop - 1;     // idle lane group: shadows the last patch, never stores
 
-  const int noc = g.noc, P = g.P, tw = g.tmp_w, nv = g.novals;
+  const int noc = g.noc, P = g.P, tw = g.tmp_w, nv = NV > 0 ? NV : g.novals;
   const int lb = -P / 2;
   const size_t plane = g.plane_elems;
   const float* __restrict__ imA = a.im_a + (size_t)frame * plane;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   for (int e = 0; e < E; ++e) {
     const int k = (e / Q) * 64 + (e % Q) * LPP + pl;
     kidx[e] = k;
-    valid[e] = FULL ? true : (k < nv);
+    valid[e] = (NV > 0 && (e / Q) * 64 + 64 <= NV) ? true : (k < nv);  // compile-time true for whole 64-entry groups
     const int kk = valid[e] ? k : 0;
     const int c = kk % noc, q = kk / noc;
     const int col = q % P, row = q / P;
@@ -113,7 +119,8 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   const float fnv = (float)nv;
   const bool nv_pow2 = FULL ? ((M & (M - 1)) == 0) : ((nv & (nv - 1)) == 0);
   const float inv_nv = 1.0f / fnv;
-  auto div_nv = [&](float x) { return nv_pow2 ? x * inv_nv : x / fnv; };
+  const float rcp_nv = rcp_refined(fnv);
+  auto div_nv = [&](float x) { return nv_pow2 ? x * inv_nv : (TRIM ? div_by(x, fnv, rcp_nv) : x / fnv); };
 
   // ---- InitializePatch: template + gradients at the integer reference position (patch.cpp:287-332)
   float T[E], Tx[E], Ty[E];
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
   // ---- OptimizeIter (patch.cpp:159-212).  All state below is uniform per patch; the lane groups of a
   //      wave diverge like ordinary SIMT branches (every cross-lane operation used here stays inside
   //      the LPP lanes of one patch).
+  const float r00 = rcp_refined(l00), r11 = rcp_refined(l11);  // TRIM: shared by the four quotients of every solve
   float p0 = pin0, p1 = pin1;
   float ptx = rx + p0, pty = ry + p1;
   const float stx = ptx, sty = pty;
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     for (int e = 0; e < E; ++e) {
       float d = v[e] - T[e];
       if (costfct == 1) {
-        d = copysignf(sqrtf(fabsf(d)), d);
+        d = copysignf(TRIM ? sqrt_rn(fabsf(d)) : sqrtf(fabsf(d)), d);
       } else if (costfct == 2) {
         const float bsq = 5.0f * 5.0f, bsq2 = bsq * 2.0f;
         d = copysignf(sqrtf((sqrtf(1.0f + (d * d) / bsq) - 1.0f) * bsq2), d);
@@ -267,6 +275,13 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
       dp1 = 0.0f;
       p0 -= dp0;
       p0 = a.camlr == 0 ? ((0.0f < p0) ? 0.0f : p0) : ((p0 < 0.0f) ? 0.0f : p0);  // std::min / std::max (p, 0)
+    } else if (TRIM) {  // shared refined reciprocals, as in the gray 8x8 kernel
+      const float y0 = div_by(b0, l00, r00);
+      const float y1 = div_by(b1 - l10 * y0, l11, r11);
+      dp1 = div_by(y1, l11, r11);
+      dp0 = div_by(y0 - l10 * dp1, l00, r00);
+      p0 -= dp0;
+      p1 -= dp1;
     } else {
       const float y0 = b0 / l00;
       const float y1 = (b1 - l10 * y0) / l11;
@@ -368,7 +383,7 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
   const int wpb = blockDim.x >> 6;  // wavefronts per block
   const int blocks_per_frame = (g.nop + wpb * Q - 1) / (wpb * Q);
   int frame, blk;
-  xcd_frame_map(blockIdx.x, blocks_per_frame, frame, blk);
+  xcd_frame_map(blockIdx.x, blocks_per_frame, a.nframes, frame, blk);
   if (frame >= a.nframes) return;                // block-uniform
   if ((blk * wpb + wave) * Q >= g.nop) return;   // wave-uniform: no patch for this wavefront
   const int sub = lane / LPP;
@@ -587,17 +602,22 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   else if (M <= 1 && gray8)
     hipLaunchKernelGGL((patch_optimize_gray8_kernel<-1>), gd, bd, 0, s, a);
   else if (M <= 1 && full && a.costfct == 0)
-    hipLaunchKernelGGL((patch_optimize_kernel<1, 8, true, 0>), gd, bd, 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 8, 64, 0>), gd, bd, 0, s, a);
   else if (M <= 1 && full)
-    hipLaunchKernelGGL((patch_optimize_kernel<1, 8, true, -1>), gd, bd, 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 8, 64, -1>), gd, bd, 0, s, a);
   else if (M <= 1)
-    hipLaunchKernelGGL((patch_optimize_kernel<1, 8, false, -1>), gd, bd, 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<1, 8, 0, -1>), gd, bd, 0, s, a);
   else if (M <= 3)
-    hipLaunchKernelGGL((patch_optimize_kernel<3, 64, false, -1>), gd, bd, 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<3, 64, 0, -1>), gd, bd, 0, s, a);
+  // RGB 12x12 (operating points 3 and 4, BASELINE configs[3]): 432 entries, 6 full groups of 64 + 48
+  else if (a.g.novals == 432 && !a.stereo && a.costfct == 0 && !getenv("OFDIS_NO_RGB12"))
+    hipLaunchKernelGGL((patch_optimize_kernel<7, 64, 432, 0>), gd, bd, 0, s, a);
+  else if (a.g.novals == 432 && !a.stereo && a.costfct == 1 && !getenv("OFDIS_NO_RGB12"))
+    hipLaunchKernelGGL((patch_optimize_kernel<7, 64, 432, 1>), gd, bd, 0, s, a);
   else if (M <= 7)
-    hipLaunchKernelGGL((patch_optimize_kernel<7, 64, false, -1>), gd, bd, 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<7, 64, 0, -1>), gd, bd, 0, s, a);
   else if (M <= 12)
-    hipLaunchKernelGGL((patch_optimize_kernel<12, 64, false, -1>), gd, bd, 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_kernel<12, 64, 0, -1>), gd, bd, 0, s, a);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
@@ -626,7 +646,7 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
   const int npx = g.w * g.h;
   const int blocks_per_frame = (npx + 255) / 256;
   int frame, blk;
-  xcd_frame_map(blockIdx.x, blocks_per_frame, frame, blk);  // a frame's blocks share one XCD's L2
+  xcd_frame_map(blockIdx.x, blocks_per_frame, a.nframes, frame, blk);  // a frame's blocks share one XCD's L2
   if (frame >= a.nframes) return;
   const bool fb = a.cg_p != nullptr;
   const bool diag_enum = PLANAR && a.wx == nullptr && !fb;  // diag-only output: enumerate pixels in diag order

@@ -110,6 +110,13 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
 // every such system has at least one positive edge weight (quarter_alpha > 0 is a launch condition, a pixel is
 // never first and last column at once), so det >= (sum of weights)^2 > 0; the slot ring starts with a unit
 // diagonal and unit weights.
+// Workgroup barrier of the multi-wave variant's step loop.  Only LDS traffic crosses wavefronts there (the du/dv ring), so
+// only the LDS counter is drained: __syncthreads() also waits for vmcnt(0), i.e. for the global row loads that are
+// deliberately kept 3-5 steps in flight, and would expose one memory latency per step.
+__device__ __forceinline__ void mw_step_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 constexpr int MW_LAG = 10;      // steps between consecutive iterations' wavefronts: PDW + 2*(NS-1) + 1 for NS = 3
 constexpr int MW_MAX_ITERS = 8;  // wavefronts per workgroup (= fixed-point iterations handled by the multi-wave variant)
 constexpr int MW_RING = 8;       // LDS rows per producer wavefront
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(MW ? 64 * MW_MAX_ITERS : 256) void tv_fused_kernel(
       }
       x1_last = x2_last;
       x2 = x2_last ? 0 : x2 + 1;
-      if constexpr (MW) __syncthreads();  // the row published in this step is read by the next wavefront >= 1 step later
+      if constexpr (MW) mw_step_barrier();  // the row published in this step is read by the next wavefront >= 1 step later
     }
   }
   if constexpr (MW) {  // keep the barrier count equal for all wavefronts of the workgroup

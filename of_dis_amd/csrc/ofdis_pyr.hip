@@ -58,6 +58,56 @@ __global__ __launch_bounds__(256) void pyr_base_kernel(const uint8_t* __restrict
   }
 }
 
+// Streaming variant of pyr_base_kernel for gray frames whose rows and left padding are multiples of 16 bytes: a lane reads
+// 16 bytes per source row (one wavefront = 1 KB of a row per instruction), sums them per output block with v_sad_u8
+// (four bytes per instruction) over the BS rows of the block -- rows are clamped individually, so the replicate padding
+// at the top and bottom costs nothing -- and writes 16/BS adjacent outputs.  Same integers, same power-of-two scale:
+// bit-identical to the generic kernel.
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+template <int BS>
+__global__ __launch_bounds__(256) void pyr_base16_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                         int nframes, int wo, int ho, int W, int H, int l) {
+  constexpr int NOUT = 16 / BS;  // outputs per lane
+  const int w = W >> l, h = H >> l;
+  const int left = (W - wo) / 2, top = (H - ho) / 2;
+  const int chunks = W / 16;  // lanes per output row
+  const long long total = (long long)nframes * h * chunks;
+  const float scale = 1.0f / (float)(BS * BS);
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(idx % chunks);
+    long long r = idx / chunks;
+    const int y = (int)(r % h);
+    const int f = (int)(r / h);
+    // padded columns [16 ch, 16 ch + 16) = source columns clamped to the frame (whole chunk inside or outside)
+    int sx = ch * 16 - left;
+    const bool inside = sx >= 0 && sx + 16 <= wo;
+    const uint8_t* s = src + (size_t)f * wo * ho;
+    unsigned sum[NOUT];
+#pragma unroll
+    for (int q = 0; q < NOUT; ++q) sum[q] = 0;
+    if (inside) {
+#pragma unroll
+      for (int yy = 0; yy < BS; ++yy) {
+        const int sy = clampi(y * BS + yy - top, 0, ho - 1);
+        const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(s + (size_t)sy * wo + sx));
+        const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum[q * 4 / BS] = __builtin_amdgcn_sad_u8(wd[q], 0u, sum[q * 4 / BS]);
+      }
+    } else {  // chunk in the replicated left / right border: every column is the frame's first / last column
+      sx = sx < 0 ? 0 : wo - 1;
+      unsigned c = 0;
+      for (int yy = 0; yy < BS; ++yy) c += s[(size_t)clampi(y * BS + yy - top, 0, ho - 1) * wo + sx];
+#pragma unroll
+      for (int q = 0; q < NOUT; ++q) sum[q] = c * BS;
+    }
+    float* o = dst + ((size_t)f * h + y) * w + (size_t)ch * NOUT;
+#pragma unroll
+    for (int q = 0; q < NOUT; ++q) o[q] = (float)sum[q] * scale;
+  }
+}
+
 // next coarser level: 2x2 mean (cv::resize(.5,.5,INTER_LINEAR))
 __global__ __launch_bounds__(256) void pyr_down_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                        int nframes, int w, int h, int noc) {
@@ -133,6 +183,16 @@ static unsigned grid_for(long long total) {
 hipError_t launch_pyr_base(const uint8_t* src, float* dst, int nframes, int wo, int ho, int W, int H, int noc, int l,
                            hipStream_t s) {
   const long long total = (long long)nframes * (H >> l) * (W >> l) * noc;
+  const int left = (W - wo) / 2;
+  // 16-byte streaming variant: gray, rows / left padding / frame size / base address multiples of 16 bytes
+  if (noc == 1 && (l == 2 || l == 3 || l == 4) && (wo & 15) == 0 && (left & 15) == 0 && (W & 15) == 0 &&
+      (((size_t)wo * ho) & 15) == 0 && ((uintptr_t)src & 15) == 0) {
+    const long long lanes = (long long)nframes * (H >> l) * (W / 16);
+    if (l == 2) hipLaunchKernelGGL(pyr_base16_kernel<4>, dim3(grid_for(lanes)), dim3(256), 0, s, src, dst, nframes, wo, ho, W, H, l);
+    else if (l == 3) hipLaunchKernelGGL(pyr_base16_kernel<8>, dim3(grid_for(lanes)), dim3(256), 0, s, src, dst, nframes, wo, ho, W, H, l);
+    else hipLaunchKernelGGL(pyr_base16_kernel<16>, dim3(grid_for(lanes)), dim3(256), 0, s, src, dst, nframes, wo, ho, W, H, l);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(pyr_base_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, dst, nframes, wo, ho, W, H, noc, l);
   return hipGetLastError();
 }
@@ -153,8 +213,14 @@ hipError_t launch_pyr_planes(const float* src, float* img, float* dx, float* dy,
 // cv::resize bilinear for CV_32FC2: half-pixel centres, source index clamped with the fraction forced to 0 at
 // the borders, horizontal interpolation first.  2^lv_l is a power of two, so (X + 0.5) / s - 0.5 is exact in fp32.
 // One thread per output pixel, 8-byte stores; the source (57 KB per frame at op-point 2) is L2 resident.
-__device__ __forceinline__ float2 upsample_px(const float2* __restrict__ fl, int sw, int sy, int sy1, float fy, int X,
-                                              float inv, float scf, bool scale) {
+// grid = (x chunks of 512 pixels, groups of 2^sc_l output rows that share their two source rows, frame); a thread owns
+// two adjacent output columns (16 bytes per store): it interpolates them horizontally on the two source rows ONCE and then
+// writes the <= 2^sc_l rows of the group, which differ only in the vertical weight.  The output is written once
+// and never read by this library: non-temporal stores.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void upsample_h(const float2* __restrict__ fl, int sw, int sy, int sy1, int X, float inv,
+                                           float scf, bool scale, float2& r0, float2& r1) {
   float fx = ((float)X + 0.5f) * inv - 0.5f;
   int sx = (int)floorf(fx);
   fx -= (float)sx;
@@ -166,38 +232,53 @@ __device__ __forceinline__ float2 upsample_px(const float2* __restrict__ fl, int
     v00.x *= scf; v00.y *= scf; v01.x *= scf; v01.y *= scf;
     v10.x *= scf; v10.y *= scf; v11.x *= scf; v11.y *= scf;
   }
-  const float ax = 1.0f - fx, ay = 1.0f - fy;
-  const float r0x = v00.x * ax + v01.x * fx, r1x = v10.x * ax + v11.x * fx;
-  const float r0y = v00.y * ax + v01.y * fx, r1y = v10.y * ax + v11.y * fx;
-  return make_float2(r0x * ay + r1x * fy, r0y * ay + r1y * fy);
+  const float ax = 1.0f - fx;
+  r0 = make_float2(v00.x * ax + v01.x * fx, v00.y * ax + v01.y * fx);
+  r1 = make_float2(v10.x * ax + v11.x * fx, v10.y * ax + v11.y * fx);
 }
 
-// grid = (x chunks of 512 pixels, output row, frame); a thread writes two adjacent pixels (16 bytes)
 __global__ __launch_bounds__(256) void upsample_crop_kernel(const float2* __restrict__ flow, float2* __restrict__ out,
                                                             int sw, int sh, int sc_l, int left, int top, int wo, int ho) {
-  const int f = blockIdx.z, y = blockIdx.y;
+  const int f = blockIdx.z;
   const int x = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (x >= wo) return;
-  const float scf = (float)(1 << sc_l), inv = 1.0f / scf;
-  float fy = ((float)(y + top) + 0.5f) * inv - 0.5f;
-  int sy = (int)floorf(fy);
-  fy -= (float)sy;
-  if (sy < 0) { sy = 0; fy = 0.0f; }
-  if (sy >= sh - 1) { sy = sh - 1; fy = 0.0f; }
+  const int s = 1 << sc_l;
+  const float scf = (float)s, inv = 1.0f / scf;
+  // the padded rows with floor((Y + 0.5) / s - 0.5) = k are [k*s + s/2, k*s + s/2 + s); k = -1 (s > 1 only) and k = sh-1
+  // are the half groups at the borders, where the source row is clamped and the weight forced to 0
+  const int k = (int)blockIdx.y - (s > 1 ? 1 : 0);
+  const int Y0 = max(k * s + s / 2, top), Y1 = min(k * s + s / 2 + s, top + ho);  // rows of the group inside the crop
+  if (Y0 >= Y1) return;
+  float fy0 = ((float)Y0 + 0.5f) * inv - 0.5f;
+  int sy = (int)floorf(fy0);
+  const bool clamp_lo = sy < 0, clamp_hi = sy >= sh - 1;
+  if (clamp_lo) sy = 0;
+  if (clamp_hi) sy = sh - 1;
   const int sy1 = min(sy + 1, sh - 1);
   const float2* fl = flow + (size_t)f * sw * sh;
-  float2* o = out + ((size_t)f * ho + y) * wo + x;
-  const float2 a = upsample_px(fl, sw, sy, sy1, fy, x + left, inv, scf, sc_l > 0);
-  if (x + 1 < wo) {
-    const float2 b = upsample_px(fl, sw, sy, sy1, fy, x + 1 + left, inv, scf, sc_l > 0);
-    if ((wo & 1) == 0) {
-      *reinterpret_cast<float4*>(o) = make_float4(a.x, a.y, b.x, b.y);  // rows are 16-byte aligned when wo is even
+  float2 a0, a1, b0, b1;
+  upsample_h(fl, sw, sy, sy1, x + left, inv, scf, sc_l > 0, a0, a1);
+  const bool two = x + 1 < wo;
+  if (two) upsample_h(fl, sw, sy, sy1, x + 1 + left, inv, scf, sc_l > 0, b0, b1);
+  const bool vec = two && (wo & 1) == 0;  // rows are 16-byte aligned when wo is even
+  for (int Y = Y0; Y < Y1; ++Y) {
+    float fy = ((float)Y + 0.5f) * inv - 0.5f;
+    fy -= floorf(fy);
+    if (clamp_lo || clamp_hi) fy = 0.0f;
+    const float ay = 1.0f - fy;
+    float2* o = out + ((size_t)f * ho + (Y - top)) * wo + x;
+    const float2 a = make_float2(a0.x * ay + a1.x * fy, a0.y * ay + a1.y * fy);
+    if (two) {
+      const float2 b = make_float2(b0.x * ay + b1.x * fy, b0.y * ay + b1.y * fy);
+      if (vec) {
+        __builtin_nontemporal_store((f4v){a.x, a.y, b.x, b.y}, reinterpret_cast<f4v*>(o));
+      } else {
+        o[0] = a;
+        o[1] = b;
+      }
     } else {
       o[0] = a;
-      o[1] = b;
     }
-  } else {
-    o[0] = a;
   }
 }
 
@@ -236,7 +317,8 @@ hipError_t launch_upsample_crop(const float* flow, float* out, int nframes, int 
                        sc_l, left, top, wo, ho);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(upsample_crop_kernel, dim3((wo + 511) / 512, ho, nframes), dim3(256), 0, s, (const float2*)flow,
+  // row groups k = -1 .. sh-1 (k = 0 .. sh for sc_l = 0, the last one empty)
+  hipLaunchKernelGGL(upsample_crop_kernel, dim3((wo + 511) / 512, sh + 1, nframes), dim3(256), 0, s, (const float2*)flow,
                      (float2*)out, sw, sh, sc_l, left, top, wo, ho);
   return hipGetLastError();
 }

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void warp_diag_kernel(const WarpArgs a) {
   const int npx = w * h;
   const int tiles_x = (w + TW - 1) / TW;
   int frame, tile;
-  xcd_frame_map(blockIdx.x, tiles_x * ((h + TH - 1) / TH), frame, tile);
+  xcd_frame_map(blockIdx.x, tiles_x * ((h + TH - 1) / TH), a.t.nframes, frame, tile);
   if (frame >= a.t.nframes) return;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x0 = tx * TW, y0 = ty * TH;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
   const int npx = w * h;
   const int tiles_x = (w + DT_W - 1) / DT_W;
   int frame, tile;
-  xcd_frame_map(blockIdx.x, tiles_x * ((h + DT_H - 1) / DT_H), frame, tile);
+  xcd_frame_map(blockIdx.x, tiles_x * ((h + DT_H - 1) / DT_H), a.t.nframes, frame, tile);
   if (frame >= a.t.nframes) return;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x0 = tx * DT_W, y0 = ty * DT_H;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void tv_system_kernel(const SystemArgs a) {
   const int npx = w * h;
   const int tiles_x = (w + ST_W - 1) / ST_W;
   int frame, tile;
-  xcd_frame_map(blockIdx.x, tiles_x * ((h + ST_H - 1) / ST_H), frame, tile);
+  xcd_frame_map(blockIdx.x, tiles_x * ((h + ST_H - 1) / ST_H), a.t.nframes, frame, tile);
   if (frame >= a.t.nframes) return;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x0 = tx * ST_W, y0 = ty * ST_H;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void tv_finish_kernel(int w, int h, int nframe
   const int npx = w * h;
   const int tiles_x = (w + TW - 1) / TW;
   int frame, tile;
-  xcd_frame_map(blockIdx.x, tiles_x * ((h + TH - 1) / TH), frame, tile);
+  xcd_frame_map(blockIdx.x, tiles_x * ((h + TH - 1) / TH), nframes, frame, tile);
   if (frame >= nframes) return;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x0 = tx * TW, y0 = ty * TH;

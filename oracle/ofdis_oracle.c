@@ -882,9 +882,12 @@ void oracle_build_pyramid(const ofdis_params* p, const uint8_t* img_u8, int widt
 }
 
 /* run_dense.cpp:406-414: flowout *= 2^sc_l; cv::resize(x 2^sc_l, INTER_LINEAR); crop.
- * cv::resize bilinear for CV_32FC2 restated (half-pixel centres, source index clamped with the
- * fraction forced to 0 at the borders); OpenCV is not available here, so this restatement is not
- * cross-checked against the library. */
+ * cv::resize bilinear for CV_32FC2 restated from OpenCV's documented rule (resize.cpp, INTER_LINEAR: source
+ * coordinate (d + 0.5) * scale - 0.5 in double, cast to float, floor, fraction; index clamped with the fraction
+ * forced to 0 at both borders; horizontal pass S[sx]*(1-fx) + S[sx+1]*fx, then the vertical pass on two such rows).
+ * OpenCV itself is not available here; the restatement is pinned by tests/test_upsample_pin.py instead: exact
+ * hand vectors derived from that rule with rational arithmetic (bit-for-bit, all four borders and odd crops) and
+ * torch's OpenCV-compatible align_corners=False bilinear to a few ulp. */
 void oracle_upsample_crop(const ofdis_params* p, const float* flow, int width_org, int height_org, float* out) {
   const int s = 1 << p->sc_l;
   const int sw = p->width >> p->sc_l, sh = p->height >> p->sc_l;

@@ -14,6 +14,7 @@ from common import assert_bits_equal
 from of_dis_amd.params import oppoint
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "of_dis_amd", "lib")
 EXE = {1: os.path.join(ROOT, "of_dis_amd", "lib", "run_OF_INT"), 3: os.path.join(ROOT, "of_dis_amd", "lib", "run_OF_RGB")}
 
 
@@ -146,3 +147,50 @@ def test_run_de_int_stereo_binary(gpu, tmp_path):
     two = np.concatenate([core, core], axis=-1)           # the oracle's resize is per channel
     expect = O.upsample_crop(p.copy(selectmode=0), two, w, h)[..., 0]
     assert_bits_equal(read_pfm(fo), expect, "run_DE_INT .pfm vs reference core + oracle upsample")
+
+
+def _write_case(path, p, pa, pb, expect, init=None):
+    import ctypes as C
+    import struct
+    with open(path, "wb") as f:
+        f.write(struct.pack("<ii", 0x4F464449, C.sizeof(p)))
+        f.write(bytes(p))
+        f.write(struct.pack("<i", 1 if init is not None else 0))
+        for l in range(p.sc_l, p.sc_f + 1):
+            for pl in (pa[0][l], pa[1][l], pa[2][l], pb[0][l]):
+                f.write(np.ascontiguousarray(pl, np.float32).tobytes())
+        if init is not None:
+            f.write(np.ascontiguousarray(init, np.float32).tobytes())
+        f.write(np.ascontiguousarray(expect, np.float32).tobytes())
+
+
+def test_c_program_is_built():
+    assert os.access(os.path.join(LIB, "dropin_test"), os.X_OK)
+    r = subprocess.run([os.path.join(LIB, "dropin_test")], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_program_through_the_abi(gpu, tmp_path):
+    """tests/c/dropin_test.c: a C99 program that includes include/ofdis.h and calls ofdis_flow() the way the reference's
+    run_dense.cpp would call the constructor, on pyramids built by the oracle; the bytes of its result must be the
+    oracle's (gray with TV, RGB, and a warm start through the cached context)."""
+    import oracle
+    from common import synth_case
+    O = oracle.c_oracle()
+    O.set_reduce_order(True)
+    cases = []
+    p, pa, pb, _, _ = synth_case(1024, 436, 2100, 1, 2, 1)
+    cases.append(("gray", p, pa, pb, None))
+    w, h = p.level_size(p.sc_f)
+    init = (np.random.default_rng(9).standard_normal((h // 2, w // 2, 2)) * 0.5).astype(np.float32)
+    cases.append(("warm", p, pa, pb, init))
+    p3, qa, qb, _, _ = synth_case(320, 240, 2101, 3, 3, 1)
+    cases.append(("rgb", p3, qa, qb, None))
+    for name, pp, xa, xb, ini in cases:
+        expect = O.flow(pp, xa[0], xa[1], xa[2], xb[0], initflow=ini)
+        path = str(tmp_path / f"{name}.bin")
+        _write_case(path, pp, xa, xb, expect, ini)
+        r = subprocess.run([os.path.join(LIB, "dropin_test"), path, "5"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (name, r.stdout, r.stderr)
+        assert "OK" in r.stdout and "identical" in r.stdout, r.stdout

@@ -421,6 +421,49 @@ def test_random_batches_from_u8(gpu, orc, seed):
         assert_bits_equal(full[slot], orc.upsample_crop(p, refs[k], w, h), f"seed {seed} slot {slot} full resolution")
 
 
+@pytest.mark.parametrize("w,h,opp,lvl", [(1024, 436, 2, None), (1952, 1000, 2, None), (512, 200, 3, 2), (1008, 436, 2, None),
+                                         (1024, 436, 2, 0), (256, 112, 2, 1)])
+def test_streaming_pyramid_and_upsample_paths(gpu, orc, w, h, opp, lvl):
+    """ofdis_batch_build_pyramids_u8's 16-byte streaming base kernel (gray; rows, left padding and frame size multiples
+    of 16 bytes: finest level 3, 4 and 2 here, with replicated 16-byte chunks left and right for 1952 -> 1984)
+    next to sizes that take the generic kernel (1008: left padding 8), and ofdis_batch_upsample's row-group kernel for
+    x8, x4, x16, x2 and x1: planes and full-resolution flow against the oracle, bit for bit."""
+    import gen_synth
+    from of_dis_amd.params import oppoint, padded_size
+    p = oppoint(opp, w, h)
+    if lvl is not None:
+        p.sc_l = lvl
+    p.width, p.height = padded_size(w, h, p.sc_f)
+    frames = [gen_synth.make_pair(w, h, 16000 + k + w, 1)[:2] for k in range(2)]
+    nfr = 9
+    ia = np.stack([frames[k % 2][0] for k in range(nfr)])
+    ib = np.stack([frames[k % 2][1] for k in range(nfr)])
+    b = gpu.Batch(p, nfr)
+    da, db = gpu.Dev(ia), gpu.Dev(ib)
+    b.build_pyramids_u8(da.ptr, db.ptr, w, h)
+    gpu.check(gpu.lib().ofdis_sync(None))
+    pyr = [(orc.build_pyramid(p, fa), orc.build_pyramid(p, fb)) for fa, fb in frames]
+    for l in range(p.sc_l, p.sc_f + 1):
+        n = b.input_elems(l)
+        for kind in range(4):
+            got = gpu.Dev.__new__(gpu.Dev)
+            got.ptr, got.nbytes = b.input_ptr(l, kind), n * 4 * nfr
+            arr = gpu.Dev.get(got, (nfr,) + p.plane_shape(l))
+            got.ptr = None
+            for slot in (0, 1, nfr - 1):
+                ref = pyr[slot % 2][0][kind][l] if kind < 3 else pyr[slot % 2][1][0][l]
+                assert_bits_equal(arr[slot], ref, f"level {l} plane kind {kind} slot {slot}")
+    b.run()
+    out = b.download_all()
+    full = b.upsample(w, h)
+    b.close()
+    for slot in (0, 1, nfr - 1):
+        pa, pb = pyr[slot % 2]
+        ref = orc.flow(p, pa[0], pa[1], pa[2], pb[0])
+        assert_bits_equal(out[slot], ref, f"flow slot {slot}")
+        assert_bits_equal(full[slot], orc.upsample_crop(p, ref, w, h), f"full-resolution flow slot {slot}")
+
+
 @pytest.mark.parametrize("env", ["OFDIS_NO_GRAY8", "OFDIS_NO_FUSED"])
 def test_fallback_kernels_at_the_benchmark_geometry(gpu, orc, monkeypatch, env):
     """The generic patch kernel (8 lanes per patch) and the unfused TV path (tiled system kernel + wavefront SOR) must
