@@ -624,13 +624,19 @@ def main():
         # gfx950 SIMD for two clocks, MI355X_MICROARCH.md); the clock is the sustained one observed under this load
         roofline_valu = None
         if dom in valu:
-            simds, clk_ghz = 256 * 4, tj.get("sustained_clock_ghz", 1.81)
-            peak = simds * clk_ghz / 2.0  # G wave-instructions / s
-            ach = valu[dom] / (kernels[dom]["ms_per_step"] * 1e-3) / 1e9
-            roofline_valu = {"kernel": dom, "bound": "valu_issue", "achieved": round(ach, 1), "peak": round(peak, 1),
-                             "unit": "G wave64-VALU-instructions/s", "frac": round(ach / peak, 4),
-                             "valu_insts_per_step": valu[dom], "sustained_clock_ghz": clk_ghz,
-                             "note": "instruction count from rocprofv3 --pmc SQ_INSTS_VALU (profiles/), time from this run"}
+            simds = 256 * 4
+            clk = tj.get("sustained_clock_ghz")
+            ach = valu[dom] / (kernels[dom]["ms_per_step"] * 1e-3) / 1e9  # G issue slots / s
+            peak_nominal = simds * 2.4 / 2.0
+            roofline_valu = {"kernel": dom, "bound": "valu_issue", "achieved": round(ach, 1), "peak": round(peak_nominal, 1),
+                             "unit": "G wave64 VALU issue slots/s", "frac": round(ach / peak_nominal, 4),
+                             "valu_slots_per_step": valu[dom],
+                             "note": "slots = rocprofv3 --pmc SQ_INSTS_VALU of this kernel class per step (profiles/traffic.json; "
+                                     "8-byte encodings -- VOP3, DPP -- count twice, as they issue), time from this run; peak = "
+                                     "1024 SIMDs x 2.4 GHz / 2 clocks per wave64 instruction (MI355X_MICROARCH.md)"}
+            if clk:
+                roofline_valu["sustained_clock_ghz"] = clk
+                roofline_valu["frac_at_sustained_clock"] = round(ach / (simds * clk / 2.0), 4)
         result = {
             "metric": "frames/sec at 1024×436 op-point-2 (INT)", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -672,7 +678,7 @@ def main():
             except Exception as e:  # the checker is optional for the measurement
                 result["parity_check"] = f"not run ({type(e).__name__}: {e})"
         extras = world == 1 and tv and not e2e and not args.no_extras
-        if world == 1 and tv and not e2e:
+        if extras:
             # BASELINE.json also lists the same operating point with the refinement switched off (configs[1]); report it
             # next to the headline (configs[2], TV on -- what operating point 2 is in the reference, run_dense.cpp:259-265)
             try:

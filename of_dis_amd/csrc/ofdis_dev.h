@@ -100,6 +100,20 @@ __device__ __forceinline__ float div_by(float a, float b, float r) {
   return __builtin_amdgcn_div_fixupf(q, b, a);
 }
 __device__ __forceinline__ float div_rn(float a, float b) { return div_by(a, b, rcp_refined(b)); }
+// div_by without v_div_fixup_f32 (which only acts on zero / infinite / NaN operands): for a FINITE numerator and a normal,
+// finite denominator the refined quotient already is the result -- a == 0 gives 0 (possibly with the other sign of
+// zero, which no consumer in the fused TV kernel can observe: every quotient there is multiplied into sums that are
+// compared by value).  Saves one 8-byte-encoded VALU instruction per quotient.
+// nb = -b is passed in (computed once per denominator): with the negation a plain operand the residuals can be
+// v_fmac_f32 (4-byte encoding, destination = addend) where the numerator dies, instead of v_fma_f32 with a source
+// modifier (8-byte encoding = two issue slots on gfx950, profiles/README.md).
+__device__ __forceinline__ float div_by_finite(float a, float nb, float r) {
+  float q = a * r;
+  float e = __builtin_fmaf(nb, q, a);
+  q = __builtin_fmaf(e, r, q);
+  e = __builtin_fmaf(nb, q, a);
+  return __builtin_fmaf(e, r, q);
+}
 __device__ __forceinline__ float sqrt_rn(float x) {
   const float s = __builtin_amdgcn_sqrtf(x);
   const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);

@@ -49,6 +49,25 @@
 
 namespace ofdis {
 
+// Quotients of this kernel: denominators are normal and positive by construction (n >= 0.01, sqrt(.. + 1e-6) >= 1e-3,
+// det >= (sum of edge weights)^2 > 0) and numerators are finite for finite images, so v_div_fixup_f32 has nothing to
+// fix (ofdis_dev.h: div_by_finite).  OFDIS_FUSED_FIXUP=1 at build time keeps it (A/B builds, tools/ab_build.py).
+#ifndef OFDIS_FUSED_FIXUP
+#define OFDIS_FUSED_FIXUP 0
+#endif
+struct FDen {  // a denominator prepared once for all its quotients
+  float b, nb, r;
+};
+__device__ __forceinline__ FDen fden(float b) {
+  // 0 - b, not -b: a subtraction from +0 is not a negation for the compiler (signed zeros), so it stays one plain
+  // instruction and is not folded back into a source modifier (VOP3) of every fma that uses it
+  return FDen{b, 0.0f - b, rcp_refined(b)};
+}
+__device__ __forceinline__ float fdiv_by(float a, const FDen& d) {
+  return OFDIS_FUSED_FIXUP ? div_by(a, d.b, d.r) : div_by_finite(a, d.nb, d.r);
+}
+__device__ __forceinline__ float fdiv_rn(float a, float b) { return fdiv_by(a, fden(b)); }
+
 struct FSlot {
   float a11, a12, a22, b1, b2, sh, sv;  // system of pixel (j, tau - j); a** become the block inverse at step tau
   float dur, dvr;                       // old du,dv of the right neighbour (row tau+1)
@@ -75,9 +94,9 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
   if (BRIGHT) {  // hd3 != 0 (opticalflow_aux.c:352)
     tmp = iz + ix * u + iy * v;
     n1 = ix * ix + iy * iy + DATANORM;
-    const float r1 = rcp_refined(n1);
-    tmp = div_rn(m * hd3, sqrt_rn(div_by(3 * tmp * tmp, n1, r1) + EPS_COLOR));
-    tmp = div_by(tmp, n1, r1);
+    const FDen d1 = fden(n1);
+    tmp = fdiv_rn(m * hd3, sqrt_rn(fdiv_by(3 * tmp * tmp, d1) + EPS_COLOR));
+    tmp = fdiv_by(tmp, d1);
     a11 += tmp * ix * ix;
     a12 += tmp * ix * iy;
     a22 += tmp * iy * iy;
@@ -86,12 +105,12 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
   }
   n1 = ixx * ixx + ixy * ixy + DATANORM;
   n2 = iyy * iyy + ixy * ixy + DATANORM;
-  const float r1 = rcp_refined(n1), r2 = rcp_refined(n2);
+  const FDen d1 = fden(n1), d2 = fden(n2);
   tmp = ixz + ixx * u + ixy * v;
   tmp2 = iyz + ixy * u + iyy * v;
-  tmp = div_rn(m * hg3, sqrt_rn(div_by(3 * tmp * tmp, n1, r1) + div_by(3 * tmp2 * tmp2, n2, r2) + EPS_GRAD));
-  tmp2 = div_by(tmp, n2, r2);
-  tmp = div_by(tmp, n1, r1);
+  tmp = fdiv_rn(m * hg3, sqrt_rn(fdiv_by(3 * tmp * tmp, d1) + fdiv_by(3 * tmp2 * tmp2, d2) + EPS_GRAD));
+  tmp2 = fdiv_by(tmp, d2);
+  tmp = fdiv_by(tmp, d1);
   a11 += tmp * ixx * ixx + tmp2 * ixy * ixy;
   a12 += tmp * ixx * ixy + tmp2 * ixy * iyy;
   a22 += tmp2 * iyy * iyy + tmp * ixy * ixy;
@@ -114,7 +133,9 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
 // only the LDS counter is drained: __syncthreads() also waits for vmcnt(0), i.e. for the global row loads that are
 // deliberately kept 3-5 steps in flight, and would expose one memory latency per step.
 __device__ __forceinline__ void mw_step_barrier() {
+#ifndef OFDIS_MW_NOBARRIER  // (timing experiment only: without the barrier the results are wrong)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 constexpr int MW_LAG = 10;      // steps between consecutive iterations' wavefronts: PDW + 2*(NS-1) + 1 for NS = 3
@@ -283,7 +304,7 @@ __global__ __launch_bounds__(MW ? 64 * MW_MAX_ITERS : 256) void tv_fused_kernel(
         const float vx = D3_C0 * vl + D3_C2 * vr;
         const float uy = D3_C0 * ut + D3_C2 * ub;
         const float vy = D3_C0 * vt + D3_C2 * vb;
-        sm[(u + 2) % 3] = div_rn(qa, sqrt_rn(ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH));
+        sm[(u + 2) % 3] = fdiv_rn(qa, sqrt_rn(ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH));
       }
       // ---- (4) system of pixel row tau = t+1 (opticalflow_aux.c:150-163, 172-199, 342-427)
       //      x of row tau is x2 of the previous step: "last column" was x2_last then
@@ -321,10 +342,10 @@ __global__ __launch_bounds__(MW ? 64 * MW_MAX_ITERS : 256) void tv_fused_kernel(
         const float d = c.hl + c.sh + c.vt + c.sv;
         const float A11 = c.a22 + d, A22 = c.a11 + d;
         const float det = A11 * A22 - c.a12 * c.a12;
-        const float rdet = rcp_refined(det);
-        c.a11 = div_by(A11, det, rdet);
-        c.a22 = div_by(A22, det, rdet);
-        c.a12 = -div_by(c.a12, det, rdet);
+        const FDen dd = fden(det);
+        c.a11 = fdiv_by(A11, dd);
+        c.a22 = fdiv_by(A22, dd);
+        c.a12 = -fdiv_by(c.a12, dd);
       }
       float nu[NS], nv[NS];
 #pragma unroll

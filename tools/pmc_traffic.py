@@ -2,6 +2,12 @@
 profiles/traffic.json: HBM bytes per step per kernel class.
 
     python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <batch> <tv> <nrun_steps>
+                                [<sq_counter_collection.csv>]
+
+The optional third file is a pass with SQ_INSTS_VALU (+ GRBM_GUI_ACTIVE): wave64 VALU instructions issued per step per
+kernel class (8-byte encodings -- VOP3, DPP -- count twice: they take two issue slots on gfx950) and the shader clock
+sustained under the dominant kernel (GRBM_GUI_ACTIVE cycles / its kernel-trace duration), both read by bench.py for
+`roofline_valu`.
 
 Corrections (MI355X_MICROARCH.md "HBM", re-measured in profiles/r01_pmc_calibration.txt on known byte counts):
 FETCH_SIZE is in KiB and reports exactly half of the bytes read (4 B/lane and 16 B/lane alike); WRITE_SIZE is in
@@ -33,9 +39,30 @@ def collect(path, counter, scale):
 fetch = collect(sys.argv[1], "FETCH_SIZE", 2 * 1024.0)
 write = collect(sys.argv[2], "WRITE_SIZE", 1024.0)
 batch, tv, nsteps = int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
+sq_file = sys.argv[6] if len(sys.argv) > 6 else None
 out = {"batch": batch, "tv": tv, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 (calibrated)",
        "bytes_per_step": {k: (fetch[k] + write[k]) / nsteps for k in sorted(set(fetch) | set(write))},
        "read_bytes_per_step": {k: fetch[k] / nsteps for k in sorted(fetch)},
        "write_bytes_per_step": {k: write[k] / nsteps for k in sorted(write)}}
+if sq_file:
+    valu = collect(sq_file, "SQ_INSTS_VALU", 1.0)
+    out["valu_insts_per_step"] = {k: valu[k] / nsteps for k in sorted(valu)}
+    # sustained shader clock under the dominant kernel: busy cycles / duration of the same dispatches
+    cyc, dur = defaultdict(float), defaultdict(float)
+    for r in csv.DictReader(open(sq_file)):
+        if r["Counter_Name"] != "GRBM_GUI_ACTIVE":
+            continue
+        for key, cls in CLASS.items():
+            if "ofdis::" + key in r.get("Kernel_Name", ""):
+                cyc[cls] += float(r["Counter_Value"])
+                if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                    dur[cls] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    dom = max(valu, key=valu.get) if valu else None
+    if dom and dur.get(dom):
+        ghz = cyc[dom] / dur[dom] / 8.0  # the counter is reported summed over the 8 XCDs; timestamps are ns
+        if 0.8 < ghz < 2.6:
+            out["sustained_clock_ghz"] = round(ghz, 3)
+            out["sustained_clock_kernel"] = dom
+            out["sustained_clock_source"] = "GRBM_GUI_ACTIVE (sum over 8 XCDs) / 8 / dispatch duration, serialised PMC pass"
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out["bytes_per_step"], indent=1))
