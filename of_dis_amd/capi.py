@@ -94,6 +94,8 @@ def lib():
         L.ofdis_batch_upload_initflow.argtypes = [VP, C.c_int, FP, VP]
         L.ofdis_test_set_fused_mw_max.argtypes = [C.c_int]
         L.ofdis_test_set_fused_mw_max.restype = None
+        L.ofdis_test_set_fused_split.argtypes = [C.c_int]
+        L.ofdis_test_set_fused_split.restype = None
         L.ofdis_test_wave_sum.argtypes = [VP, VP, C.c_int, VP]
         L.ofdis_test_div_sqrt.argtypes = [VP, VP, VP, C.c_int, VP]
         _lib = L

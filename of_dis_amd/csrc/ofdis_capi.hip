@@ -1180,6 +1180,7 @@ float ofdis_test_outlier_sq(float t) { return outlier_sq_threshold(t); }
 // test hook (not declared in ofdis.h): wavefront budget of the multi-wave fused TV kernel (0 = single-wave kernel only,
 // large = multi-wave whenever the iteration count allows, < 0 = default)
 void ofdis_test_set_fused_mw_max(int waves) { set_tv_fused_mw_max(waves); }
+void ofdis_test_set_fused_split(int on) { set_tv_fused_split(on); }
 
 // test hook (not declared in ofdis.h): trimmed divide / sqrt next to the compiler's IEEE expansion
 int ofdis_test_div_sqrt(const float* a, const float* b, float* out, int n, void* stream) {

@@ -138,15 +138,32 @@ __device__ __forceinline__ void mw_step_barrier() {
 #endif
 }
 
-constexpr int MW_LAG = 10;      // steps between consecutive iterations' wavefronts: PDW + 2*(NS-1) + 1 for NS = 3
-constexpr int MW_MAX_ITERS = 8;  // wavefronts per workgroup (= fixed-point iterations handled by the multi-wave variant)
-constexpr int MW_RING = 8;       // LDS rows per producer wavefront
+constexpr int MW_LAG = 10;       // MODE 1: steps between consecutive iterations' wavefronts: PDW + 2*(NS-1) + 1 for NS = 3
+constexpr int MW_MAX_ITERS = 8;  // MODE 1: wavefronts per workgroup (= fixed-point iterations it handles)
+constexpr int MW_RING = 8;       // LDS rows of du/dv per iteration (a power of two)
+constexpr int SP_LAG = 9;        // MODE 2: du/dv are read 4 rows ahead instead of PDW = 5: 4 + 2*(NS-1) + 1
+constexpr int SP_MAX_ITERS = 6;  // MODE 2: 2 wavefronts per iteration, 12 per workgroup (3 per SIMD: 168 VGPRs each)
+constexpr int SLOT_FLOATS = 11;  // FSlot
 
-template <int NS, bool BRIGHT, bool MW>
-__global__ __launch_bounds__(MW ? 64 * MW_MAX_ITERS : 256) void tv_fused_kernel(const FusedArgs a, const int R) {
+// MODE 0: one wavefront walks all fixed-point iterations of its frame group (the throughput kernel).
+// MODE 1: "multi-wave" -- one workgroup per frame group, wavefront k runs iteration k (header comment).
+// MODE 2: "split" -- as MODE 1 with every iteration's work divided between TWO wavefronts: a producer (row loads, flow
+//         gradients, smoothness, data term, Laplacian: parts 1-4 of a step, ~2/3 of its instructions) and a solver (block
+//         inverse and the NS pipelined sweeps, part 5).  The producer hands each pixel's FSlot to its solver through a
+//         double-buffered LDS array one step later -- exactly the distance the single-wave kernel has between producing
+//         the slot of row t+1 and consuming the slot of row t -- and the solver hands the finished du/dv row to the next
+//         iteration's producer through the same LDS ring MODE 1 uses.  A lone wavefront issues one instruction per ~6
+//         clocks (dependent-issue latency), so halving the instructions per wavefront and step nearly halves the step.
+template <int NS, bool BRIGHT, int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * MW_MAX_ITERS : 256)) void tv_fused_kernel(
+    const FusedArgs a, const int R) {
   constexpr int U = 6;
-  // du/dv rows handed from the wavefront of iteration k to the wavefront of iteration k+1: [k][step & 7][lane]
-  __shared__ float2 xring[MW ? (MW_MAX_ITERS - 1) * MW_RING * 64 : 1];
+  constexpr bool MW = MODE != 0;
+  constexpr int MAXIT = MODE == 2 ? SP_MAX_ITERS : MW_MAX_ITERS;
+  // du/dv rows handed from iteration k to iteration k+1: [k][step & 7][lane]
+  __shared__ float2 xring[MW ? (MAXIT - 1) * MW_RING * 64 : 1];
+  // MODE 2: FSlot of the pixel row handed from an iteration's producer to its solver: [iteration][step & 1][field][lane]
+  __shared__ float sring[MODE == 2 ? SP_MAX_ITERS * 2 * SLOT_FLOATS * 64 : 1];
   // prefetch distances: the W row (wx,wy,du,dv) of diag row t+PDW and the D row (8 derivatives + mask) of row t+PDD are
   // requested at step t; first uses are rows t+3 (uu, vv) and t+1 (data term).  (5, 3) = two steps of slack, 141 VGPRs,
   // 3 wavefronts per SIMD; (4, 2) = one step of slack, 128 VGPRs, 4 wavefronts per SIMD measured the same kernel time
@@ -156,18 +173,25 @@ __global__ __launch_bounds__(MW ? 64 * MW_MAX_ITERS : 256) void tv_fused_kernel(
 #define OFDIS_FUSED_PDD 3
 #endif
   constexpr int PDW = OFDIS_FUSED_PDW, PDD = OFDIS_FUSED_PDD;
+  constexpr int PDU = MODE == 2 ? 4 : PDW;  // read-ahead of du/dv (MODE 2: from LDS, one step before their first use)
+  constexpr int LAG = MODE == 2 ? SP_LAG : MW_LAG;
   static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
-  static_assert(!MW || MW_LAG >= PDW + 2 * (NS - 1) + 1, "a row must be published before the next iteration prefetches it");
+  static_assert(!MW || LAG >= PDU + 2 * (NS - 1) + 1, "a row must be published before the next iteration reads it");
   const int w = a.t.w, h = a.t.h;
   const int npx = w * h;
   const int lane = threadIdx.x & 63;
-  // MW: one frame group per workgroup, wavefront `it` runs fixed-point iteration `it` of n_iters
-  const int it = MW ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-  const int n_iters = MW ? (int)(blockDim.x >> 6) : 1;
+  // MW: one frame group per workgroup; MODE 1: wavefront `it` runs iteration `it`; MODE 2: wavefronts 0..n-1 are the
+  // producers of iterations 0..n-1, wavefronts n..2n-1 their solvers (a producer and its solver share a SIMD when n = 4)
+  const int wv = MW ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  const int n_iters = MODE == 2 ? (int)(blockDim.x >> 7) : (MW ? (int)(blockDim.x >> 6) : 1);
+  const bool is_solver = MODE == 2 && wv >= n_iters;
+  const int it = MODE == 2 ? (is_solver ? wv - n_iters : wv) : wv;
+  const bool do_p = MODE != 2 || !is_solver;  // parts 1-4 of a step
+  const bool do_s = MODE != 2 || is_solver;   // part 5
   const int wid = MW ? (int)blockIdx.x : __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int G = 64 / R;  // frames per wavefront
   const int f0 = wid * G;
-  if (f0 >= a.t.nframes) return;  // whole wave idle (uniform)
+  if (f0 >= a.t.nframes) return;  // whole wave idle (uniform; MW: the whole workgroup)
   int fl = lane / R;              // frame of this lane within the wavefront
   const int jr = lane % R;
   const bool row_ok = (f0 + fl < a.t.nframes) && (jr < h);
@@ -216,20 +240,25 @@ __global__ __launch_bounds__(MW ? 64 * MW_MAX_ITERS : 256) void tv_fused_kernel(
   auto wrap = [&](int r) { r %= w; return r < 0 ? r + w : r; };
   auto next_row = [&](int r) { return (r + 1 == w) ? 0 : r + 1; };
   const int row_bytes = h * 4;
+  // du/dv of the previous iteration for the row with unwrapped step number tau (MW): from the LDS ring; zero in the
+  // first fixed-point iteration (image_erase, refine_variational.cpp:186-187)
+  auto ring_uv = [&](FRow& r, int tau) {
+    if (it == 0) {
+      r.du = 0.0f; r.dv = 0.0f;
+    } else {
+      const float2 v = xring[((it - 1) * MW_RING + (tau & (MW_RING - 1))) * 64 + lane];
+      r.du = v.x; r.dv = v.y;
+    }
+  };
   // tau = unwrapped step number of the row (MW only): the LDS ring slot
   auto load_w = [&](FRow& r, int drow, int tau) {
     const int o = drow * row_bytes;
     r.wx = ldf(rsWx, vo1, o); r.wy = ldf(rsWy, vo1, o);
-    if constexpr (MW) {
-      if (it == 0) {  // first fixed-point iteration: du = dv = 0 (image_erase, refine_variational.cpp:186-187)
-        r.du = 0.0f; r.dv = 0.0f;
-      } else {
-        const float2 v = xring[((it - 1) * MW_RING + (tau & (MW_RING - 1))) * 64 + lane];
-        r.du = v.x; r.dv = v.y;
-      }
-    } else {
+    if constexpr (MODE == 1) {
+      ring_uv(r, tau);
+    } else if constexpr (MODE == 0) {
       r.du = ldf(rsU, vo1, o); r.dv = ldf(rsV, vo1, o);
-    }
+    }  // MODE 2: du/dv follow one step later (PDU = 4)
   };
   auto load_d = [&](FDer& r, int drow) {
     const int o = drow * row_bytes;
@@ -240,17 +269,24 @@ __global__ __launch_bounds__(MW ? 64 * MW_MAX_ITERS : 256) void tv_fused_kernel(
 
   // ring index of diag row rho is (rho + 3) mod ring size; the loop variable is k = t + 3, u = k % 6,
   // so row t + c sits at index (u + c) % size.
-  // prologue: W rows -1, 0, 1 (indices 2, 3, 4)
-  if constexpr (MW) {  // the ring of this wavefront's successor starts with zeros (finite: see "Border handling")
+  if constexpr (MW) {  // the ring of this iteration's successor starts with zeros (finite: see "Border handling")
+    if (do_s && it < MAXIT - 1) {
 #pragma unroll
-    for (int q = 0; q < MW_RING; ++q)
-      if (it < MW_MAX_ITERS - 1) xring[(it * MW_RING + q) * 64 + lane] = make_float2(0.0f, 0.0f);
+      for (int q = 0; q < MW_RING; ++q) xring[(it * MW_RING + q) * 64 + lane] = make_float2(0.0f, 0.0f);
+    }
     __syncthreads();
-    for (int n = 0; n < it * MW_LAG; ++n) __syncthreads();  // trail the previous iteration by MW_LAG steps
+    for (int n = 0; n < it * LAG; ++n) __syncthreads();  // trail the previous iteration by LAG steps
   }
-  load_w(W[2], wrap(-1), -1);
-  load_w(W[3], wrap(0), 0);
-  if (PDW == 5) load_w(W[4], wrap(1), 1);
+  // prologue: W rows -1, 0, 1 (indices 2, 3, 4)
+  if (do_p) {
+    load_w(W[2], wrap(-1), -1);
+    load_w(W[3], wrap(0), 0);
+    if (PDW == 5) load_w(W[4], wrap(1), 1);
+    if constexpr (MODE == 2) {  // du/dv rows -1, 0: the loop starts with row t + PDU = 1
+      ring_uv(W[2], -1);
+      ring_uv(W[3], 0);
+    }
+  }
   // du, dv are zero before the first fixed-point iteration (refine_variational.cpp:186-187): the kernel never reads
   // them during its first pass over the columns, so the caller does not have to clear them
   if (!MW) W[2].du = W[2].dv = W[3].du = W[3].dv = W[4].du = W[4].dv = 0.0f;
@@ -266,137 +302,156 @@ __global__ __launch_bounds__(MW ? 64 * MW_MAX_ITERS : 256) void tv_fused_kernel(
   int ig = -3 - j - 2 * (NS - 1);  // global column (over all iterations) the last sweep finishes at step t
   bool first_w = !MW;              // row t+5 at t = -3 is column 2 - j: first iteration (w >= 16)
   int taus = -3 - 2 * (NS - 1);    // unwrapped step number of the row the last sweep finishes (MW)
+  int taut = -3;                   // unwrapped step number t (MODE 2: the slot hand-over buffer)
   for (int k0 = 0; k0 <= tend + 3; k0 += U) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // step t = k0 + u - 3; up to U-1 steps past tend are executed: every pixel is then out of range
-      // ---- (1) loads: W row t+5, D row t+3
-      load_w(W[(u + PDW) % 6], rowW, tauW);
-      rowW = next_row(rowW);
-      ++tauW;
-      if (!MW && first_w) {  // this lane's column on row t+5 still belongs to the first iteration: du = dv = 0 (image_erase)
-        W[(u + PDW) % 6].du = 0.0f;
-        W[(u + PDW) % 6].dv = 0.0f;
-      }
-      load_d(D[(u + PDD) % 3], rowD);
-      rowD = next_row(rowD);
-      // ---- (2) uu, vv of row t+3 (refine_variational.cpp:210-216: uu = wx + du of before this call)
-      {
-        const FRow& r = W[(u + 3) % 6];
-        uu[u % 3] = r.wx + r.du;
-        vv[u % 3] = r.wy + r.dv;
-      }
-      // ---- (3) smoothness of row t+2 (opticalflow_aux.c:128-140)
-      const bool x2_last = (x2 == w - 1);
-      {
-        const float uc = uu[(u + 2) % 3], vc = vv[(u + 2) % 3];
-        float ul = uu[(u + 1) % 3], vl = vv[(u + 1) % 3];                  // (x-1, y)
-        float ur = uu[u % 3], vr = vv[u % 3];                              // (x+1, y): row t+3
-        float ut = wave_from_prev(uu[(u + 1) % 3]), vt = wave_from_prev(vv[(u + 1) % 3]);  // (x, y-1)
-        float ub = wave_from_next(uu[u % 3]), vb = wave_from_next(vv[u % 3]);              // (x, y+1)
-        if (x2 == 0) { ul = uc; vl = vc; }
-        if (x2_last) { ur = uc; vr = vc; }
-        if (!has_top) { ut = uc; vt = vc; }
-        if (!has_bot) { ub = uc; vb = vc; }
-        // the reference's middle tap is -0 * centre: adding a signed zero changes at most the sign of a zero
-        // result, and each derivative is only ever squared
-        const float ux = D3_C0 * ul + D3_C2 * ur;
-        const float vx = D3_C0 * vl + D3_C2 * vr;
-        const float uy = D3_C0 * ut + D3_C2 * ub;
-        const float vy = D3_C0 * vt + D3_C2 * vb;
-        sm[(u + 2) % 3] = fdiv_rn(qa, sqrt_rn(ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH));
-      }
-      // ---- (4) system of pixel row tau = t+1 (opticalflow_aux.c:150-163, 172-199, 342-427)
-      //      x of row tau is x2 of the previous step: "last column" was x2_last then
-      {
-        const float sc = sm[(u + 1) % 3];
-        const float s_r = sm[(u + 2) % 3];
-        const float s_d = wave_from_next(sm[(u + 2) % 3]);
-        const float sh_c = x1_last ? 0.0f : sc + s_r;
-        const float sv_c = has_bot ? sc + s_d : 0.0f;
-        const FRow& rc = W[(u + 1) % 6];
-        const FRow& rm = W[u % 6];        // row tau-1
-        const FRow& rp = W[(u + 2) % 6];  // row tau+1
-        float a11, a12, a22, b1, b2;
-        data_term_gray<BRIGHT>(D[(u + 1) % 3], rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
-        const float wx_u = wave_from_prev(rm.wx), wy_u = wave_from_prev(rm.wy);
-        const float wx_d = wave_from_next(rp.wx), wy_d = wave_from_next(rp.wy);
-        const float sh_l = slot[u % 6].sh;         // (s_l + sc), 0 on column 0
-        const float sv_t = wave_from_prev(slot[u % 6].sv);  // (s_u + sc), 0 on row 0
-        b1 -= sh_l * (rc.wx - rm.wx);
-        b2 -= sh_l * (rc.wy - rm.wy);
-        b1 += sh_c * (rp.wx - rc.wx);
-        b2 += sh_c * (rp.wy - rc.wy);
-        b1 -= sv_t * (rc.wx - wx_u);
-        b2 -= sv_t * (rc.wy - wy_u);
-        b1 += sv_c * (wx_d - rc.wx);
-        b2 += sv_c * (wy_d - rc.wy);
-        FSlot& o = slot[(u + 1) % 6];
-        o.a11 = a11; o.a12 = a12; o.a22 = a22; o.b1 = b1; o.b2 = b2; o.sh = sh_c; o.sv = sv_c;
-        o.dur = rp.du; o.dvr = rp.dv;
-        o.hl = sh_l; o.vt = sv_t;
-      }
-      // ---- (5) SOR step t (ofdis_sor.hip): sweep 0 reaches pixel (j, t - j); block inverse (solver.c:100-110)
-      {
-        FSlot& c = slot[u % 6];
-        const float d = c.hl + c.sh + c.vt + c.sv;
-        const float A11 = c.a22 + d, A22 = c.a11 + d;
-        const float det = A11 * A22 - c.a12 * c.a12;
-        const FDen dd = fden(det);
-        c.a11 = fdiv_by(A11, dd);
-        c.a22 = fdiv_by(A22, dd);
-        c.a12 = -fdiv_by(c.a12, dd);
-      }
-      float nu[NS], nv[NS];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const FSlot& c = slot[(u - 2 * s + 12) % 6];
-        float ou, ov, rgu, rgv, bu, bv;
-        if (s == 0) {
-          const FSlot& p = slot[(u + 5) % 6];
-          ou = p.dur; ov = p.dvr;
-          rgu = c.dur; rgv = c.dvr;
-          bu = wave_from_next(c.dur);
-          bv = wave_from_next(c.dvr);
-        } else {
-          ou = ru2[s - 1]; ov = rv2[s - 1];
-          rgu = ru[s - 1]; rgv = rv[s - 1];
-          bu = wave_from_next(ru[s - 1]);
-          bv = wave_from_next(rv[s - 1]);
+      if (do_p) {
+        // ---- (1) loads: W row t+5, D row t+3
+        load_w(W[(u + PDW) % 6], rowW, tauW);
+        if constexpr (MODE == 2) ring_uv(W[(u + PDU) % 6], tauW - (PDW - PDU));
+        rowW = next_row(rowW);
+        ++tauW;
+        if (!MW && first_w) {  // this lane's column on row t+5 still belongs to the first iteration: du = dv = 0 (image_erase)
+          W[(u + PDW) % 6].du = 0.0f;
+          W[(u + PDW) % 6].dv = 0.0f;
         }
-        const float tu = wave_from_prev(ru[s]), tv = wave_from_prev(rv[s]);
-        const float lu = ru[s], lv = rv[s];
-        const float s1 = c.sh * rgu + c.vt * tu + c.sv * bu + c.b1;
-        const float s2 = c.sh * rgv + c.vt * tv + c.sv * bv + c.b2;
-        const float B1 = c.hl * lu + s1, B2 = c.hl * lv + s2;
-        nu[s] = ou + omega * (c.a11 * B1 + c.a12 * B2 - ou);
-        nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
-      }
-      {
-        if (!MW) first_w = ig + (PDW + 1 + 2 * (NS - 1)) < w;  // for the next step's row
-        if (MW && it < n_iters - 1) {  // hand the row to the next iteration's wavefront (lanes outside their columns
-          // publish finite values nobody reads as a pixel: the reader's lane is outside its columns at the same step number)
-          xring[(it * MW_RING + (taus & (MW_RING - 1))) * 64 + lane] = make_float2(nu[NS - 1], nv[NS - 1]);
-        } else if (row_ok && ig >= 0 && ig < wtot) {
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nu[NS - 1]), rsU, vo1, srow * row_bytes, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nv[NS - 1]), rsV, vo1, srow * row_bytes, 0);
+        load_d(D[(u + PDD) % 3], rowD);
+        rowD = next_row(rowD);
+        // ---- (2) uu, vv of row t+3 (refine_variational.cpp:210-216: uu = wx + du of before this call)
+        {
+          const FRow& r = W[(u + 3) % 6];
+          uu[u % 3] = r.wx + r.du;
+          vv[u % 3] = r.wy + r.dv;
         }
-        srow = next_row(srow);
-        ++ig;
-        ++taus;
+        // ---- (3) smoothness of row t+2 (opticalflow_aux.c:128-140)
+        const bool x2_last = (x2 == w - 1);
+        {
+          const float uc = uu[(u + 2) % 3], vc = vv[(u + 2) % 3];
+          float ul = uu[(u + 1) % 3], vl = vv[(u + 1) % 3];                  // (x-1, y)
+          float ur = uu[u % 3], vr = vv[u % 3];                              // (x+1, y): row t+3
+          float ut = wave_from_prev(uu[(u + 1) % 3]), vt = wave_from_prev(vv[(u + 1) % 3]);  // (x, y-1)
+          float ub = wave_from_next(uu[u % 3]), vb = wave_from_next(vv[u % 3]);              // (x, y+1)
+          if (x2 == 0) { ul = uc; vl = vc; }
+          if (x2_last) { ur = uc; vr = vc; }
+          if (!has_top) { ut = uc; vt = vc; }
+          if (!has_bot) { ub = uc; vb = vc; }
+          // the reference's middle tap is -0 * centre: adding a signed zero changes at most the sign of a zero
+          // result, and each derivative is only ever squared
+          const float ux = D3_C0 * ul + D3_C2 * ur;
+          const float vx = D3_C0 * vl + D3_C2 * vr;
+          const float uy = D3_C0 * ut + D3_C2 * ub;
+          const float vy = D3_C0 * vt + D3_C2 * vb;
+          sm[(u + 2) % 3] = fdiv_rn(qa, sqrt_rn(ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH));
+        }
+        // ---- (4) system of pixel row tau = t+1 (opticalflow_aux.c:150-163, 172-199, 342-427)
+        //      x of row tau is x2 of the previous step: "last column" was x2_last then
+        {
+          const float sc = sm[(u + 1) % 3];
+          const float s_r = sm[(u + 2) % 3];
+          const float s_d = wave_from_next(sm[(u + 2) % 3]);
+          const float sh_c = x1_last ? 0.0f : sc + s_r;
+          const float sv_c = has_bot ? sc + s_d : 0.0f;
+          const FRow& rc = W[(u + 1) % 6];
+          const FRow& rm = W[u % 6];        // row tau-1
+          const FRow& rp = W[(u + 2) % 6];  // row tau+1
+          float a11, a12, a22, b1, b2;
+          data_term_gray<BRIGHT>(D[(u + 1) % 3], rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
+          const float wx_u = wave_from_prev(rm.wx), wy_u = wave_from_prev(rm.wy);
+          const float wx_d = wave_from_next(rp.wx), wy_d = wave_from_next(rp.wy);
+          const float sh_l = slot[u % 6].sh;         // (s_l + sc), 0 on column 0
+          const float sv_t = wave_from_prev(slot[u % 6].sv);  // (s_u + sc), 0 on row 0
+          b1 -= sh_l * (rc.wx - rm.wx);
+          b2 -= sh_l * (rc.wy - rm.wy);
+          b1 += sh_c * (rp.wx - rc.wx);
+          b2 += sh_c * (rp.wy - rc.wy);
+          b1 -= sv_t * (rc.wx - wx_u);
+          b2 -= sv_t * (rc.wy - wy_u);
+          b1 += sv_c * (wx_d - rc.wx);
+          b2 += sv_c * (wy_d - rc.wy);
+          FSlot& o = slot[(u + 1) % 6];
+          o.a11 = a11; o.a12 = a12; o.a22 = a22; o.b1 = b1; o.b2 = b2; o.sh = sh_c; o.sv = sv_c;
+          o.dur = rp.du; o.dvr = rp.dv;
+          o.hl = sh_l; o.vt = sv_t;
+          if constexpr (MODE == 2) {  // hand the slot of row t+1 to this iteration's solver (it reads it in the next step)
+            float* sr = sring + ((it * 2 + ((taut + 1) & 1)) * SLOT_FLOATS) * 64 + lane;
+            sr[0 * 64] = a11; sr[1 * 64] = a12; sr[2 * 64] = a22; sr[3 * 64] = b1; sr[4 * 64] = b2; sr[5 * 64] = sh_c;
+            sr[6 * 64] = sv_c; sr[7 * 64] = rp.du; sr[8 * 64] = rp.dv; sr[9 * 64] = sh_l; sr[10 * 64] = sv_t;
+          }
+        }
+        x1_last = x2_last;
+        x2 = x2_last ? 0 : x2 + 1;
       }
+      if (do_s) {
+        if (MODE == 2 && taut > -3) {  // the slot of row t, published by the producer one step ago (its first one is
+          // row -2; before that the fill-phase slot stays)
+          const float* sr = sring + ((it * 2 + (taut & 1)) * SLOT_FLOATS) * 64 + lane;
+          FSlot& c = slot[u % 6];
+          c.a11 = sr[0 * 64]; c.a12 = sr[1 * 64]; c.a22 = sr[2 * 64]; c.b1 = sr[3 * 64]; c.b2 = sr[4 * 64]; c.sh = sr[5 * 64];
+          c.sv = sr[6 * 64]; c.dur = sr[7 * 64]; c.dvr = sr[8 * 64]; c.hl = sr[9 * 64]; c.vt = sr[10 * 64];
+        }
+        // ---- (5) SOR step t (ofdis_sor.hip): sweep 0 reaches pixel (j, t - j); block inverse (solver.c:100-110)
+        {
+          FSlot& c = slot[u % 6];
+          const float d = c.hl + c.sh + c.vt + c.sv;
+          const float A11 = c.a22 + d, A22 = c.a11 + d;
+          const float det = A11 * A22 - c.a12 * c.a12;
+          const FDen dd = fden(det);
+          c.a11 = fdiv_by(A11, dd);
+          c.a22 = fdiv_by(A22, dd);
+          c.a12 = -fdiv_by(c.a12, dd);
+        }
+        float nu[NS], nv[NS];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        ru2[s] = ru[s]; rv2[s] = rv[s];
-        ru[s] = nu[s]; rv[s] = nv[s];
+        for (int s = 0; s < NS; ++s) {
+          const FSlot& c = slot[(u - 2 * s + 12) % 6];
+          float ou, ov, rgu, rgv, bu, bv;
+          if (s == 0) {
+            const FSlot& p = slot[(u + 5) % 6];
+            ou = p.dur; ov = p.dvr;
+            rgu = c.dur; rgv = c.dvr;
+            bu = wave_from_next(c.dur);
+            bv = wave_from_next(c.dvr);
+          } else {
+            ou = ru2[s - 1]; ov = rv2[s - 1];
+            rgu = ru[s - 1]; rgv = rv[s - 1];
+            bu = wave_from_next(ru[s - 1]);
+            bv = wave_from_next(rv[s - 1]);
+          }
+          const float tu = wave_from_prev(ru[s]), tv = wave_from_prev(rv[s]);
+          const float lu = ru[s], lv = rv[s];
+          const float s1 = c.sh * rgu + c.vt * tu + c.sv * bu + c.b1;
+          const float s2 = c.sh * rgv + c.vt * tv + c.sv * bv + c.b2;
+          const float B1 = c.hl * lu + s1, B2 = c.hl * lv + s2;
+          nu[s] = ou + omega * (c.a11 * B1 + c.a12 * B2 - ou);
+          nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
+        }
+        {
+          if (!MW) first_w = ig + (PDW + 1 + 2 * (NS - 1)) < w;  // for the next step's row
+          if (MW && it < n_iters - 1) {  // hand the row to the next iteration (lanes outside their columns publish finite
+            // values nobody reads as a pixel: the reader's lane is outside its columns at the same step number)
+            xring[(it * MW_RING + (taus & (MW_RING - 1))) * 64 + lane] = make_float2(nu[NS - 1], nv[NS - 1]);
+          } else if (row_ok && ig >= 0 && ig < wtot) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nu[NS - 1]), rsU, vo1, srow * row_bytes, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nv[NS - 1]), rsV, vo1, srow * row_bytes, 0);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          ru2[s] = ru[s]; rv2[s] = rv[s];
+          ru[s] = nu[s]; rv[s] = nv[s];
+        }
       }
-      x1_last = x2_last;
-      x2 = x2_last ? 0 : x2 + 1;
-      if constexpr (MW) mw_step_barrier();  // the row published in this step is read by the next wavefront >= 1 step later
+      srow = next_row(srow);
+      ++ig;
+      ++taus;
+      ++taut;
+      if constexpr (MW) mw_step_barrier();  // what was published in this step is read >= 1 step later
     }
   }
   if constexpr (MW) {  // keep the barrier count equal for all wavefronts of the workgroup
-    for (int n = 0; n < (n_iters - 1 - it) * MW_LAG; ++n) __syncthreads();
+    for (int n = 0; n < (n_iters - 1 - it) * LAG; ++n) __syncthreads();
   }
 }
 
@@ -416,12 +471,19 @@ static int g_mw_max = -1;  // -1: not initialised
 static int mw_max_waves() {
   if (g_mw_max < 0) {
     const char* e = getenv("OFDIS_FUSED_MW_MAX");
-    g_mw_max = e ? atoi(e) : 2048;
+    g_mw_max = e ? atoi(e) : 4096;
     if (g_mw_max < 0) g_mw_max = 0;
   }
   return g_mw_max;
 }
 void set_tv_fused_mw_max(int waves) { g_mw_max = waves; }  // test hook / tuning: < 0 = back to the default
+
+static int g_split = -1;  // test hook / tuning: 0 = never use the split (producer / solver) variant; OFDIS_FUSED_NO_SPLIT
+void set_tv_fused_split(int on) { g_split = on; }
+static bool split_enabled() {
+  if (g_split < 0) g_split = getenv("OFDIS_FUSED_NO_SPLIT") ? 0 : 1;
+  return g_split != 0;
+}
 
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s) {
   if (!tv_fused_supported(a.t, a.iterations) || a.n_inner < 1 ||
@@ -433,13 +495,19 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s) {
   const int waves = (a.t.nframes + G - 1) / G;
   const int blocks = (waves + 3) / 4;
   const bool bright = a.half_delta_over3 != 0.0f;
+  // small batches: one workgroup per frame group, one (MODE 1) or two (MODE 2) wavefronts per fixed-point iteration,
+  // while the launch stays below the wavefront budget (i.e. while the throughput mapping would leave SIMDs idle)
   const bool mw = a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS && (long long)waves * a.n_inner <= mw_max_waves();
-#define OFDIS_FUSED_LAUNCH(NS)                                                                                        \
-  if (mw) {                                                                                                           \
-    if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, true>), dim3(waves), dim3(64 * a.n_inner), 0, s, a, R); \
-    else hipLaunchKernelGGL((tv_fused_kernel<NS, false, true>), dim3(waves), dim3(64 * a.n_inner), 0, s, a, R);       \
-  } else if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, false>), dim3(blocks), dim3(256), 0, s, a, R);     \
-  else hipLaunchKernelGGL((tv_fused_kernel<NS, false, false>), dim3(blocks), dim3(256), 0, s, a, R)
+  const bool split = mw && split_enabled() && a.n_inner <= SP_MAX_ITERS && (long long)waves * a.n_inner * 2 <= mw_max_waves();
+#define OFDIS_FUSED_LAUNCH(NS)                                                                                         \
+  if (split) {                                                                                                         \
+    if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 2>), dim3(waves), dim3(128 * a.n_inner), 0, s, a, R);    \
+    else hipLaunchKernelGGL((tv_fused_kernel<NS, false, 2>), dim3(waves), dim3(128 * a.n_inner), 0, s, a, R);          \
+  } else if (mw) {                                                                                                     \
+    if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 1>), dim3(waves), dim3(64 * a.n_inner), 0, s, a, R);     \
+    else hipLaunchKernelGGL((tv_fused_kernel<NS, false, 1>), dim3(waves), dim3(64 * a.n_inner), 0, s, a, R);           \
+  } else if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 0>), dim3(blocks), dim3(256), 0, s, a, R);          \
+  else hipLaunchKernelGGL((tv_fused_kernel<NS, false, 0>), dim3(blocks), dim3(256), 0, s, a, R)
   switch (a.iterations) {
     case 1: OFDIS_FUSED_LAUNCH(1); break;
     case 2: OFDIS_FUSED_LAUNCH(2); break;

@@ -128,6 +128,8 @@ bool tv_fused_params_ok(float quarter_alpha, float half_delta_over3, float half_
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s);
 // wavefront budget below which the multi-wave (iteration-pipelined) variant is launched; < 0 restores the default
 void set_tv_fused_mw_max(int waves);
+// 0 = never launch the split (producer / solver wavefronts) variant of the multi-wave kernel
+void set_tv_fused_split(int on);
 
 // layout conversion of `nplanes` planes of w x h (row-major <-> diag); used by the per-function entry
 // points, whose public interface is row-major

@@ -41,11 +41,15 @@ def orc():
     return o
 
 
-@pytest.fixture(params=["single-wave", "multi-wave"])
+@pytest.fixture(params=["single-wave", "multi-wave", "multi-wave-split"])
 def tv_variant(gpu, request):
-    """Both mappings of the fused TV kernel (ofdis_fused.hip): one wavefront walking all fixed-point iterations of a
-    frame group, or a workgroup with one wavefront per iteration (the small-batch variant the launcher would pick by
-    itself for these test sizes).  Bit-identical results are required of both."""
-    gpu.lib().ofdis_test_set_fused_mw_max(0 if request.param == "single-wave" else 1 << 30)
+    """The three mappings of the fused TV kernel (ofdis_fused.hip): one wavefront walking all fixed-point iterations of a
+    frame group; a workgroup with one wavefront per iteration; the same with each iteration divided between a producer and
+    a solver wavefront (the small-batch variants the launcher would pick by itself for these test sizes, the split one
+    up to 6 iterations).  Bit-identical results are required of all."""
+    L = gpu.lib()
+    L.ofdis_test_set_fused_mw_max(0 if request.param == "single-wave" else 1 << 30)
+    L.ofdis_test_set_fused_split(1 if request.param == "multi-wave-split" else 0)
     yield request.param
-    gpu.lib().ofdis_test_set_fused_mw_max(-1)
+    L.ofdis_test_set_fused_mw_max(-1)
+    L.ofdis_test_set_fused_split(1)
