@@ -122,8 +122,12 @@ def algorithmic_bytes(p, nframes, fused_tv=True):
         launches["densify"] += 1
         if p.usetvref:
             n_inner = p.tv_innerit * (l + 1)
-            out["warp"] += (8 + 4 * noc + 4 * noc + 4) * npx          # wx,wy + src once + dst + mask
-            out["derivatives"] += 40 * noc * npx                      # I0,I1w in, 8 planes out
+            if fused and not os.environ.get("OFDIS_NO_WARP_FUSION") and (nframes <= 256 or os.environ.get("OFDIS_FORCE_WARP_FUSION")):
+                # image_warp inside the derivatives kernel: wx,wy + both images in, mask + 8 planes out
+                out["derivatives"] += (8 + 4 + 4 + 4 + 32) * npx
+            else:
+                out["warp"] += (8 + 4 * noc + 4 * noc + 4) * npx      # wx,wy + src once + dst + mask
+                out["derivatives"] += 40 * noc * npx                  # I0,I1w in, 8 planes out
             if fused:   # system + SOR in one kernel: derivs, mask, wx, wy, du, dv in; du, dv out
                 out["tv_fused"] += n_inner * (32 * noc + 20 + 8) * npx
                 launches["tv_fused"] += 1

@@ -240,7 +240,15 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
   const int n_inner = p.tv_innerit * (g.level + 1);  // :36
   const TvConsts c = tv_consts(p.tv_alpha, p.tv_gamma, p.tv_delta);
   const bool fused = use_fused(b, g);
-  {
+  // fused path: image_warp runs inside the derivatives kernel (no warped image in memory, one launch less);
+  // OFDIS_NO_WARP_FUSION keeps the two kernels apart (A/B and the test of the stand-alone diag warp kernel)
+  // Only for small batches: a launch and a round trip less where launches dominate (64 pairs: -2 % per pass); on large
+  // batches warping the halo in every tile costs more than the round trip (4096 pairs: derivatives 0.53 + warp 0.26 ms
+  // apart, 1.00 ms fused).
+  const bool no_warp_fusion = getenv("OFDIS_NO_WARP_FUSION") != nullptr;       // (read per call: the tests toggle them)
+  const bool force_warp_fusion = getenv("OFDIS_FORCE_WARP_FUSION") != nullptr;
+  const bool warp_in_deriv = fused && !no_warp_fusion && (b->nframes <= 256 || force_warp_fusion);
+  if (!warp_in_deriv) {
     KTimer kt(b, OFDIS_K_WARP, s);
     if (fused) {  // wx_d, wy_d in, mask_d out (diag); the warped image stays row-major
       WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx_d, b->wy_d, b->w_im2, b->mask_d};
@@ -252,7 +260,14 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
   }
   {
     KTimer kt(b, OFDIS_K_DERIV, s);
-    DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs, fused ? 1 : 0, nullptr, nullptr};
+    DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs, fused ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (warp_in_deriv) {
+      da.im2w = nullptr;
+      da.warp_src = im_b;
+      da.wx_diag = b->wx_d;
+      da.wy_diag = b->wy_d;
+      da.mask_diag = b->mask_d;
+    }
     HIPCHK(launch_derivatives(da, s));
   }
   if (!fused || n_inner <= 0) {  // image_erase :186-187 (the fused kernel treats its first pass as du = dv = 0 itself)
@@ -304,7 +319,7 @@ int run_varref_de(ofdis_batch* b, const LevelGeom& g, const float* im_a, const f
   }
   {
     KTimer kt(b, OFDIS_K_DERIV, s);
-    DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs, 0, nullptr, nullptr};
+    DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     HIPCHK(launch_derivatives(da, s));
   }
   HIPCHK(hipMemsetAsync(b->du, 0, n * sizeof(float), s));                                    // image_erase(du)
@@ -1022,7 +1037,7 @@ int ofdis_image_warp(float* dst, float* mask, const float* src, const float* wx,
 int ofdis_get_derivatives(float* out, const float* im1, const float* im2w, int w, int h, int noc, int nframes,
                           void* stream) {
   if (!out || !im1 || !im2w || w < 1 || h < 4 || nframes < 1) return fail(OFDIS_ERR_INVALID, "bad arguments (need h >= 4)");
-  DerivArgs a{TvGeom{w, h, noc, nframes}, im1, 0, 0, 0, 0, im2w, out, 0, nullptr, nullptr};
+  DerivArgs a{TvGeom{w, h, noc, nframes}, im1, 0, 0, 0, 0, im2w, out, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
   HIPCHK(launch_derivatives(a, (hipStream_t)stream));
   return OFDIS_OK;
 }
@@ -1177,7 +1192,7 @@ int ofdis_test_wave_sum(const float* in, float* out, int n, void* stream) {
 // test hook (not declared in ofdis.h; host only, needs no GPU): the squared outlier threshold of the patch kernels
 float ofdis_test_outlier_sq(float t) { return outlier_sq_threshold(t); }
 
-// test hook (not declared in ofdis.h): wavefront budget of the multi-wave fused TV kernel (0 = single-wave kernel only,
+// test hook (not declared in ofdis.h): frame-group limit of the multi-wave fused TV kernels (0 = single-wave kernel only,
 // large = multi-wave whenever the iteration count allows, < 0 = default)
 void ofdis_test_set_fused_mw_max(int waves) { set_tv_fused_mw_max(waves); }
 void ofdis_test_set_fused_split(int on) { set_tv_fused_split(on); }

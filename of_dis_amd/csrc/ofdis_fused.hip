@@ -464,14 +464,15 @@ bool tv_fused_params_ok(float qa, float hd3, float hg3) {
   return qa > 0.0f && ok(qa) && ok(hd3) && ok(hg3);  // qa == 0: no smoothness at all, singular systems possible
 }
 
-// Wavefront budget of the multi-wave variant: it is chosen while (frame groups x iterations) stays below this many
-// wavefronts, i.e. while the single-wave mapping would leave most SIMDs (1024 on MI355X) without work.
-// OFDIS_FUSED_MW_MAX overrides it (0 = never use the multi-wave variant); read once.
+// The multi-wave variants are launched while the batch has at most this many frame groups (= workgroups; 256 CUs): up
+// to two rounds of workgroups they beat the throughput mapping, which would leave SIMDs idle (measured at operating
+// point 2: 512 pairs 1.07 -> 0.92 ms per step, 1024 pairs 1.72 -> 1.64 ms; beyond that the single-wave kernel wins).
+// OFDIS_FUSED_MW_MAX overrides it (0 = never use the multi-wave variants); read once.
 static int g_mw_max = -1;  // -1: not initialised
-static int mw_max_waves() {
+static int mw_max_groups() {
   if (g_mw_max < 0) {
     const char* e = getenv("OFDIS_FUSED_MW_MAX");
-    g_mw_max = e ? atoi(e) : 4096;
+    g_mw_max = e ? atoi(e) : 512;
     if (g_mw_max < 0) g_mw_max = 0;
   }
   return g_mw_max;
@@ -495,10 +496,9 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s) {
   const int waves = (a.t.nframes + G - 1) / G;
   const int blocks = (waves + 3) / 4;
   const bool bright = a.half_delta_over3 != 0.0f;
-  // small batches: one workgroup per frame group, one (MODE 1) or two (MODE 2) wavefronts per fixed-point iteration,
-  // while the launch stays below the wavefront budget (i.e. while the throughput mapping would leave SIMDs idle)
-  const bool mw = a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS && (long long)waves * a.n_inner <= mw_max_waves();
-  const bool split = mw && split_enabled() && a.n_inner <= SP_MAX_ITERS && (long long)waves * a.n_inner * 2 <= mw_max_waves();
+  // small batches: one workgroup per frame group, one (MODE 1) or two (MODE 2) wavefronts per fixed-point iteration
+  const bool mw = a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS && waves <= mw_max_groups();
+  const bool split = mw && split_enabled() && a.n_inner <= SP_MAX_ITERS;
 #define OFDIS_FUSED_LAUNCH(NS)                                                                                         \
   if (split) {                                                                                                         \
     if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 2>), dim3(waves), dim3(128 * a.n_inner), 0, s, a, R);    \

@@ -78,6 +78,12 @@ struct DerivArgs {
   int out_diag;
   const float* mask_rm;  // with out_diag: row-major mask to be copied ...
   float* mask_diag;      // ... into diag layout (may be null)
+  // fused image_warp (gray, out_diag, im1_padded): when warp_src is set, im2w is not read -- the second image is warped
+  // inside the kernel (opticalflow_aux.c:18-60, same arithmetic as warp_kernel) from the padded plane warp_src with the
+  // flow planes wx_diag / wy_diag (diag layout), and the warp's mask goes to mask_diag
+  const float* warp_src;
+  const float* wx_diag;
+  const float* wy_diag;
 };
 hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s);
 
@@ -126,7 +132,8 @@ bool tv_fused_supported(const TvGeom& t, int iterations);
 // the fused kernel's trimmed divisions (ofdis_dev.h) need the three weights to be 0 or of ordinary magnitude
 bool tv_fused_params_ok(float quarter_alpha, float half_delta_over3, float half_gamma_over3);
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s);
-// wavefront budget below which the multi-wave (iteration-pipelined) variant is launched; < 0 restores the default
+// number of frame groups (workgroups) up to which the multi-wave (iteration-pipelined) variants are launched; < 0 restores
+// the default
 void set_tv_fused_mw_max(int waves);
 // 0 = never launch the split (producer / solver wavefronts) variant of the multi-wave kernel
 void set_tv_fused_split(int on);

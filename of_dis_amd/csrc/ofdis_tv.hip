@@ -238,15 +238,20 @@ __device__ __forceinline__ float v5(const float* t, int pitch, int qy, int qx, i
   return D5_C0 * m2 + D5_C1 * m1 + D5_C2 * s0 + D5_C3 * p1 + D5_C4 * p2;
 }
 
-template <bool PADDED, bool DIAG>
+// WARP (fused TV path, gray): the warped second image is not read from memory but computed here, on the tile and its
+// halo, from the padded plane and the diag-layout flow planes -- image_warp folded into get_derivatives' first stage.
+// Removes the warped image's round trip through HBM and one launch per level; the halo pixels are warped by up to four
+// neighbouring tiles (x1.9 of the warp's arithmetic, about 45 instructions per pixel against this kernel's ~350).
+template <bool PADDED, bool DIAG, bool WARP>
 __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
-  constexpr int IN_FLOATS = 2 * DA_H * DA_W + 2 * DX_H * DX_W;
+  constexpr int IN_FLOATS = 2 * DA_H * DA_W + 2 * DX_H * DX_W + (WARP ? DT_H * DT_W : 0);
   constexpr int OUT_FLOATS = DIAG ? 9 * DT_H * DT_W : 0;  // staging for the diag transposition (8 planes + mask)
   __shared__ float lds[IN_FLOATS > OUT_FLOATS ? IN_FLOATS : OUT_FLOATS];
   float* avg_t = lds;
   float* iz_t = avg_t + DA_H * DA_W;
   float* ix_t = iz_t + DA_H * DA_W;
   float* iy_t = ix_t + DX_H * DX_W;
+  float* mask_t = iy_t + DX_H * DX_W;  // WARP: the warp's mask on the output tile
   const int w = a.t.w, h = a.t.h, noc = a.t.noc;
   const int npx = w * h;
   const int tiles_x = (w + DT_W - 1) / DT_W;
@@ -259,17 +264,38 @@ __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
 
   for (int c = 0; c < noc; ++c) {
     // stage 0: avg = 0.5*(im2w + im1), Iz = im2w - im1 on tile + halo 4, at border-clamped coordinates
-    for (int n = tid; n < DA_H * DA_W; n += 256) {
-      const int qy = n / DA_W, qx = n - qy * DA_W;
-      const int y = clampi(y0 + qy - 4, 0, h - 1), x = clampi(x0 + qx - 4, 0, w - 1);
-      float i1;
-      if (PADDED)
-        i1 = a.im1[(size_t)frame * a.tmp_w * a.tmp_h * noc + ((size_t)(y + a.pad) * a.tmp_w + x + a.pad) * noc + c];
-      else
-        i1 = a.im1[((size_t)frame * noc + c) * npx + y * w + x];
-      const float i2 = a.im2w[((size_t)frame * noc + c) * npx + y * w + x];
-      avg_t[n] = 0.5f * (i2 + i1);
-      iz_t[n] = i2 - i1;
+    if constexpr (WARP) {
+      // rotated enumeration (consecutive lanes walk an anti-diagonal of the halo tile: contiguous runs of the diag-layout
+      // flow planes); one channel
+      WarpArgs wa;
+      wa.t = a.t; wa.src = a.warp_src; wa.src_padded = 1; wa.pad = a.pad; wa.tmp_w = a.tmp_w; wa.tmp_h = a.tmp_h;
+      for (int n = tid; n < DA_H * DA_W; n += 256) {
+        const int qy = n % DA_H;
+        int qx = n / DA_H - qy;
+        if (qx < 0) qx += DA_W;
+        const int yy = y0 + qy - 4, xx = x0 + qx - 4;
+        const int y = clampi(yy, 0, h - 1), x = clampi(xx, 0, w - 1);
+        const size_t dg = (size_t)frame * npx + diag_index(x, y, w, h);
+        const float i1 = a.im1[(size_t)frame * a.tmp_w * a.tmp_h + (size_t)(y + a.pad) * a.tmp_w + x + a.pad];
+        float m, i2[3];
+        warp_pixel<true, 1>(wa, frame, x, y, a.wx_diag[dg], a.wy_diag[dg], m, i2);
+        avg_t[qy * DA_W + qx] = 0.5f * (i2[0] + i1);
+        iz_t[qy * DA_W + qx] = i2[0] - i1;
+        if (qy >= 4 && qy < 4 + DT_H && qx >= 4 && qx < 4 + DT_W) mask_t[(qy - 4) * DT_W + qx - 4] = m;
+      }
+    } else {
+      for (int n = tid; n < DA_H * DA_W; n += 256) {
+        const int qy = n / DA_W, qx = n - qy * DA_W;
+        const int y = clampi(y0 + qy - 4, 0, h - 1), x = clampi(x0 + qx - 4, 0, w - 1);
+        float i1;
+        if (PADDED)
+          i1 = a.im1[(size_t)frame * a.tmp_w * a.tmp_h * noc + ((size_t)(y + a.pad) * a.tmp_w + x + a.pad) * noc + c];
+        else
+          i1 = a.im1[((size_t)frame * noc + c) * npx + y * w + x];
+        const float i2 = a.im2w[((size_t)frame * noc + c) * npx + y * w + x];
+        avg_t[n] = 0.5f * (i2 + i1);
+        iz_t[n] = i2 - i1;
+      }
     }
     __syncthreads();
     // stage 1: Ix = d/dx avg, Iy = d/dy avg on tile + halo 2.  An entry outside the image holds the
@@ -301,6 +327,9 @@ __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
       res[k][6] = h5(iz_t, DA_W, ay, ax);
       res[k][7] = v5(iz_t, DA_W, ay, ax, y, h);
     }
+    float mk[NPIX];  // WARP: this thread's mask values, read before the staging area overwrites the input tiles
+#pragma unroll
+    for (int k = 0; k < NPIX; ++k) mk[k] = WARP ? mask_t[(tid / DT_W + k * (256 / DT_W)) * DT_W + qx] : 0.0f;
     if (!DIAG) {
 #pragma unroll
       for (int k = 0; k < NPIX; ++k) {
@@ -323,7 +352,8 @@ __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
         for (int q = 0; q < 8; ++q) lds[(q * DT_H + ry) * DT_W + qx] = res[k][q];
         if (c == 0 && a.mask_diag) {
           const int y = y0 + ry, x = x0 + qx;
-          lds[(8 * DT_H + ry) * DT_W + qx] = (y < h && x < w) ? a.mask_rm[(size_t)frame * npx + y * w + x] : 0.0f;
+          if (WARP) lds[(8 * DT_H + ry) * DT_W + qx] = mk[k];
+          else lds[(8 * DT_H + ry) * DT_W + qx] = (y < h && x < w) ? a.mask_rm[(size_t)frame * npx + y * w + x] : 0.0f;
         }
       }
       __syncthreads();
@@ -350,12 +380,15 @@ hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s) {
   if (a.t.h < 4) return hipErrorInvalidValue;  // the reference's vertical filter reads rows 0..3
   const int tiles = ((a.t.w + DT_W - 1) / DT_W) * ((a.t.h + DT_H - 1) / DT_H);
   const dim3 g(((a.t.nframes + 7) / 8) * 8 * tiles), b(256);
-  if (a.out_diag) {
-    if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((derivatives_kernel<false, true>), g, b, 0, s, a);
+  if (a.warp_src) {
+    if (!a.out_diag || !a.im1_padded || a.t.noc != 1 || !a.wx_diag || !a.wy_diag || !a.mask_diag) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((derivatives_kernel<true, true, true>), g, b, 0, s, a);
+  } else if (a.out_diag) {
+    if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true, true, false>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((derivatives_kernel<false, true, false>), g, b, 0, s, a);
   } else {
-    if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true, false>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((derivatives_kernel<false, false>), g, b, 0, s, a);
+    if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true, false, false>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((derivatives_kernel<false, false, false>), g, b, 0, s, a);
   }
   return hipGetLastError();
 }

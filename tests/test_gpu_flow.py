@@ -464,11 +464,17 @@ def test_streaming_pyramid_and_upsample_paths(gpu, orc, w, h, opp, lvl):
         assert_bits_equal(full[slot], orc.upsample_crop(p, ref, w, h), f"full-resolution flow slot {slot}")
 
 
-@pytest.mark.parametrize("env", ["OFDIS_NO_GRAY8", "OFDIS_NO_FUSED"])
+@pytest.mark.parametrize("env", ["OFDIS_NO_GRAY8", "OFDIS_NO_FUSED", "OFDIS_NO_WARP_FUSION"])
 def test_fallback_kernels_at_the_benchmark_geometry(gpu, orc, monkeypatch, env):
-    """The generic patch kernel (8 lanes per patch) and the unfused TV path (tiled system kernel + wavefront SOR) must
-    give the same bits as the specialised kernels they stand in for; the switches exist for this test."""
+    """The generic patch kernel (8 lanes per patch), the unfused TV path (tiled system kernel + wavefront SOR) and the
+    stand-alone diag-layout warp kernel (large batches; small ones warp inside the derivatives kernel) must give the same
+    bits as the kernels they stand in for; the switches exist for this test."""
     monkeypatch.setenv(env, "1")
+    gpu.lib().ofdis_flow_cache_clear()   # a cached drop-in context would replay the schedule it captured without the switch
     p, pa, pb, _, _ = synth_case(1024, 436, 1600, 1, 2, 1)
-    got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
-    assert_bits_equal(got, orc.flow(p, pa[0], pa[1], pa[2], pb[0]), f"{env}=1")
+    try:
+        for rep in range(3):                 # direct launches, then the captured graph of the fallback schedule
+            got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
+            assert_bits_equal(got, orc.flow(p, pa[0], pa[1], pa[2], pb[0]), f"{env}=1, call {rep}")
+    finally:
+        gpu.lib().ofdis_flow_cache_clear()
