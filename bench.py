@@ -381,13 +381,13 @@ def block_config4(capi, torch, p, batch, ia, ib, stream, dev, args):
     """BASELINE configs[3]: run_OF_RGB operating-point-4 geometry on 1920x1080, L1 cost, 50 iterations, TV on
     (CLI: run_OF_RGB a b out 6 1 50 50 0.05 0.95 0 12 0.75 0 1 1 1 10 10 5 1 3 1.6 2)."""
     from of_dis_amd.params import oppoint
-    W4, H4, n = 1920, 1080, 8
+    W4, H4, n = 1920, 1080, 32
     p4 = oppoint(4, W4, H4, noc=3, verbosity=0).copy(costfct=1, max_iter=50, min_iter=50)
     xa, xb = synth_frames_range(0, n, W4, H4, 4242, dev, channels=3)
     b4 = capi.Batch(p4, n)
     torch.cuda.synchronize()
     b4.build_pyramids_u8(xa.data_ptr(), xb.data_ptr(), W4, H4, stream)
-    dt = timed_steps(torch, lambda: b4.run(stream), 3, 1)
+    dt = timed_steps(torch, lambda: b4.run(stream), 2, 1)
     kernels = kernel_table(capi, torch, b4, p4, n, stream, nrep=1)
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     out = {"workload": f"run_OF_RGB 1920x1080 (padded 1920x1088, levels 6-1), patch 12 overlap 0.75, L1 cost, 50 GN "

@@ -128,48 +128,40 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const float* __restrict__
   }
 }
 
-__device__ __forceinline__ int reflect101(int i, int n) {
-  if (n == 1) return 0;
-  while (i < 0 || i >= n) {
-    if (i < 0) i = -i;
-    if (i >= n) i = 2 * (n - 1) - i;
-  }
-  return i;
-}
-
 // padded planes of one level: image (replicate border) and, if dx != nullptr, Sobel/8 gradients
-// (zero border)
+// (zero border).  grid = (chunks of 256 plane elements, frame): all index arithmetic is 32-bit.
 __global__ __launch_bounds__(256) void pyr_planes_kernel(const float* __restrict__ src, float* __restrict__ img,
                                                          float* __restrict__ dx, float* __restrict__ dy, int nframes,
                                                          int w, int h, int noc, int pad) {
   const int tw = w + 2 * pad, th = h + 2 * pad;
-  const long long total = (long long)nframes * th * tw * noc;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % noc);
-    long long r = idx / noc;
-    const int X = (int)(r % tw);
-    r /= tw;
-    const int Y = (int)(r % th);
-    const int f = (int)(r / th);
-    const float* s = src + (size_t)f * w * h * noc;
-    const int x = X - pad, y = Y - pad;
-    img[idx] = s[((size_t)clampi(y, 0, h - 1) * w + clampi(x, 0, w - 1)) * noc + c];
-    if (dx) {
-      float gx = 0.0f, gy = 0.0f;
-      if (x >= 0 && x < w && y >= 0 && y < h) {
-        float v[3][3];
+  const unsigned per_frame = (unsigned)(th * tw * noc);
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;
+  const int f = blockIdx.y;
+  if (e >= per_frame) return;
+  const unsigned pe = e / (unsigned)noc;  // noc is 1 or 3
+  const int c = (int)(e - pe * (unsigned)noc);
+  const int Y = (int)(pe / (unsigned)tw), X = (int)(pe - (unsigned)Y * (unsigned)tw);
+  const size_t idx = (size_t)f * per_frame + e;
+  const float* s = src + (size_t)f * w * h * noc;
+  const int x = X - pad, y = Y - pad;
+  img[idx] = s[(clampi(y, 0, h - 1) * w + clampi(x, 0, w - 1)) * noc + c];
+  if (dx) {
+    float gx = 0.0f, gy = 0.0f;
+    if (x >= 0 && x < w && y >= 0 && y < h) {
+      float v[3][3];
+      // BORDER_REFLECT_101 of a 3-tap window: one reflection suffices (h, w >= 2; a one-pixel image repeats its pixel)
+      const int ym = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yp = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+      const int xm = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xp = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
+      const int ys[3] = {ym, y, yp}, xs[3] = {xm, x, xp};
 #pragma unroll
-        for (int j = -1; j <= 1; ++j)
+      for (int j = 0; j < 3; ++j)
 #pragma unroll
-          for (int i = -1; i <= 1; ++i)
-            v[j + 1][i + 1] = s[((size_t)reflect101(y + j, h) * w + reflect101(x + i, w)) * noc + c];
-        gx = ((v[0][2] - v[0][0]) + 2.0f * (v[1][2] - v[1][0]) + (v[2][2] - v[2][0])) * 0.125f;
-        gy = ((v[2][0] - v[0][0]) + 2.0f * (v[2][1] - v[0][1]) + (v[2][2] - v[0][2])) * 0.125f;
-      }
-      dx[idx] = gx;
-      dy[idx] = gy;
+        for (int i = 0; i < 3; ++i) v[j][i] = s[(ys[j] * w + xs[i]) * noc + c];
+      gx = ((v[0][2] - v[0][0]) + 2.0f * (v[1][2] - v[1][0]) + (v[2][2] - v[2][0])) * 0.125f;
+      gy = ((v[2][0] - v[0][0]) + 2.0f * (v[2][1] - v[0][1]) + (v[2][2] - v[0][2])) * 0.125f;
     }
+    dx[idx] = gx;
+    dy[idx] = gy;
   }
 }
 
@@ -203,8 +195,10 @@ hipError_t launch_pyr_down(const float* src, float* dst, int nframes, int w, int
 }
 hipError_t launch_pyr_planes(const float* src, float* img, float* dx, float* dy, int nframes, int w, int h, int noc,
                              int pad, hipStream_t s) {
-  const long long total = (long long)nframes * (h + 2 * pad) * (w + 2 * pad) * noc;
-  hipLaunchKernelGGL(pyr_planes_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, img, dx, dy, nframes, w, h, noc, pad);
+  const long long per_frame = (long long)(h + 2 * pad) * (w + 2 * pad) * noc;
+  if (nframes > 65535 || per_frame >= (1ll << 31)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pyr_planes_kernel, dim3((unsigned)((per_frame + 255) / 256), (unsigned)nframes), dim3(256), 0, s, src, img,
+                     dx, dy, nframes, w, h, noc, pad);
   return hipGetLastError();
 }
 
