@@ -492,9 +492,12 @@ def main():
     torch.cuda.set_device(local_rank)
     capi.check(L.ofdis_set_device(local_rank))
     dist = None
-    if world > 1:
+    # (OFDIS_BENCH_FORCE_DIST: initialise the process group even for one rank -- a one-GPU box then still exercises every
+    # RCCL call of the multi-rank path: communicator creation, barrier, MAX all-reduce, object gather)
+    if world > 1 or os.environ.get("OFDIS_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         if backend == "nccl":  # RCCL
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:

@@ -186,3 +186,19 @@ def test_bench_strong_scaling_partition(gpu):
     assert d["config"]["global_frames_per_step"] == 75 and d["config"]["frames_per_gpu_per_step"] == [38, 37]
     assert d["multi_gpu_check"] == {**d["multi_gpu_check"], "frames_compared": 37, "mismatches": 0, "bit_identical_to_1gpu": True}
     assert d["parity_check"].startswith("bit-exact")
+
+
+@pytest.mark.gpu
+def test_bench_rccl_calls_with_one_rank(gpu):
+    """Every RCCL call of the multi-rank path (communicator creation with a device id, barriers, the MAX all-reduce on a
+    device tensor, the object gathers) on a one-rank communicator: what a one-GPU box can check of the RCCL side."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OFDIS_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "OFDIS_BENCH_BACKEND", "OFDIS_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    d = _run_bench([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                    "--batch", "64", "--cpu-seconds", "0", "--no-extras"], env)
+    assert d["n_gpus"] == 1 and d["config"]["ranks"]["world_size"] == 1
+    assert d["config"]["ranks"]["backend"] == "rccl (torch.distributed nccl)"
+    assert d["parity_check"].startswith("bit-exact")

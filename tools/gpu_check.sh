@@ -1,7 +1,8 @@
 #!/bin/bash
-# GPU session r2c: full GPU test-suite after the RGB12 / XCD map / streaming kernels / C program, default bench
+# One GPU session: the whole GPU test-suite, then the default bench with a summary of its blocks.
+#   gpurun --timeout 2700 -- "bash tools/gpu_check.sh [TAG]"   ->  gpurun_out/TAG/{pytest.log, bench.json}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r2c
+OUT=$R/gpurun_out/${1:-check}
 mkdir -p $OUT
 cd $R
 timeout 1800 python -m pytest tests -m gpu -x -q --durations=8 > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -14 $OUT/pytest.log
