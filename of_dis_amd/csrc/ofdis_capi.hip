@@ -99,6 +99,7 @@ struct EventPair {
 struct ofdis_batch {
   ofdis_params p;
   int nframes = 0;
+  int total_frames = 0;              // nframes of the owning context (a frame_view keeps it)
   int nlevels = 0;
   std::vector<LevelGeom> geom;       // index = level - sc_l
   std::vector<float*> in[6];         // A, A_dx, A_dy, B per level (+ B_dx, B_dy when usefbcon)
@@ -277,7 +278,7 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
   if (fused && n_inner > 0) {  // every fixed-point iteration of this level in one launch
     KTimer kt(b, OFDIS_K_FUSED, s);
     FusedArgs fa{t, b->derivs, b->mask_d, b->wx_d, b->wy_d, b->du, b->dv, c.quarter_alpha, c.half_delta_over3,
-                 c.half_gamma_over3, p.tv_solverit, p.tv_sor, n_inner};
+                 c.half_gamma_over3, p.tv_solverit, p.tv_sor, n_inner, b->total_frames};
     HIPCHK(launch_tv_fused(fa, s));
   }
   for (int it = 0; it < n_inner && !fused; ++it) {
@@ -415,6 +416,7 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
   ofdis_batch* b = new ofdis_batch();
   b->p = *p;
   b->nframes = nframes;
+  b->total_frames = nframes;
   b->nlevels = p->sc_f - p->sc_l + 1;
   b->nop = p->selectmode == 2 ? 1 : 2;
   for (int l = p->sc_l; l <= p->sc_f; ++l) b->geom.push_back(make_geom(*p, l));

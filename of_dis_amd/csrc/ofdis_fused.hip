@@ -464,10 +464,15 @@ bool tv_fused_params_ok(float qa, float hd3, float hg3) {
   return qa > 0.0f && ok(qa) && ok(hd3) && ok(hg3);  // qa == 0: no smoothness at all, singular systems possible
 }
 
-// The multi-wave variants are launched while the batch has at most this many frame groups (= workgroups; 256 CUs): up
-// to two rounds of workgroups they beat the throughput mapping, which would leave SIMDs idle (measured at operating
-// point 2: 512 pairs 1.07 -> 0.92 ms per step, 1024 pairs 1.72 -> 1.64 ms; beyond that the single-wave kernel wins).
-// OFDIS_FUSED_MW_MAX overrides it (0 = never use the multi-wave variants); read once.
+// When the multi-wave variants are launched (measured at operating point 2, ms per step, T = this limit on the frame
+// groups = workgroups of a launch; batches >= 1024 run as two pipelined sub-batches):
+//      512 pairs: T >= 512: 0.92, T = 256: 1.02            1024 (2 x 512): T = 512: 1.65, 256: 1.75, 0: 1.89
+//     2048 (2 x 1024): T = 0: 2.93, 256 / 512: 3.00         4096 (2 x 2048): T = 0 / 256: 5.06-5.16, 512: 5.39-5.44
+// i.e. up to two rounds of workgroups (256 CUs) they beat the throughput mapping as long as the WHOLE batch is small;
+// once the other sub-batch has enough work to fill the SIMDs a workgroup that owns a CU for a whole level only gets
+// in the way.  Rule: at most 512 frame groups in the launch AND at most 1024 frames in the whole batch.
+// OFDIS_FUSED_MW_MAX overrides the group limit (0 = never use the multi-wave variants); read once.
+constexpr int MW_MAX_BATCH_FRAMES = 1024;
 static int g_mw_max = -1;  // -1: not initialised
 static int mw_max_groups() {
   if (g_mw_max < 0) {
@@ -497,7 +502,9 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s) {
   const int blocks = (waves + 3) / 4;
   const bool bright = a.half_delta_over3 != 0.0f;
   // small batches: one workgroup per frame group, one (MODE 1) or two (MODE 2) wavefronts per fixed-point iteration
-  const bool mw = a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS && waves <= mw_max_groups();
+  const int total = a.total_frames > 0 ? a.total_frames : a.t.nframes;
+  const bool mw = a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS && waves <= mw_max_groups() &&
+                  (total <= MW_MAX_BATCH_FRAMES || mw_max_groups() >= (1 << 30));
   const bool split = mw && split_enabled() && a.n_inner <= SP_MAX_ITERS;
 #define OFDIS_FUSED_LAUNCH(NS)                                                                                         \
   if (split) {                                                                                                         \

@@ -127,6 +127,7 @@ struct FusedArgs {
   int iterations;  // SOR sweeps per fixed-point iteration (tv_solverit)
   float omega;
   int n_inner;     // fixed-point iterations run back to back inside one launch
+  int total_frames;  // frames of the whole batch this launch is a part of (pipelined sub-batches); 0 = t.nframes
 };
 bool tv_fused_supported(const TvGeom& t, int iterations);
 // the fused kernel's trimmed divisions (ofdis_dev.h) need the three weights to be 0 or of ordinary magnitude
