@@ -464,6 +464,30 @@ def test_streaming_pyramid_and_upsample_paths(gpu, orc, w, h, opp, lvl):
         assert_bits_equal(full[slot], orc.upsample_crop(p, ref, w, h), f"full-resolution flow slot {slot}")
 
 
+@pytest.mark.parametrize("nfr", [7, 8, 255, 257, 512, 513, 1024, 1025, 2049])
+def test_kernel_selection_does_not_change_results(gpu, orc, nfr):
+    """Which kernels run depends on the batch size: image_warp inside the derivatives kernel up to 256 pairs, the
+    multi-wave TV kernels up to 512 frame groups per launch and 1024 frames per batch (split variant up to 6 fixed-point
+    iterations), the per-XCD frame map from 8 frames on, pipelined sub-batches.  A frame's bits must not."""
+    w, h = 256, 128                                   # levels 3..1: 32x16, 64x32, 128x64 -- all on the fused TV path
+    cases = [synth_case(w, h, 2200 + k, 1, 2, 1) for k in range(3)]
+    p = cases[0][0]
+    refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
+    b = gpu.Batch(p, nfr)
+    for l in range(p.sc_l, p.sc_f + 1):               # slot s holds frame s % 3
+        for kind in range(4):
+            planes = [c[1][kind][l] if kind < 3 else c[2][0][l] for c in cases]
+            b.set_input(l, kind, np.stack([planes[s % 3] for s in range(nfr)]))
+    if nfr >= 1024:
+        b.set_pipeline(2)
+    for rep in range(2):                              # direct launches, then (un-pipelined) the captured graph
+        b.run()
+        out = b.download_all()
+        for s in list(range(min(nfr, 12))) + [nfr // 2, nfr - 2, nfr - 1]:
+            assert_bits_equal(out[s], refs[s % 3], f"{nfr} frames, pass {rep}, slot {s}")
+    b.close()
+
+
 @pytest.mark.parametrize("env", ["OFDIS_NO_GRAY8", "OFDIS_NO_FUSED", "OFDIS_NO_WARP_FUSION"])
 def test_fallback_kernels_at_the_benchmark_geometry(gpu, orc, monkeypatch, env):
     """The generic patch kernel (8 lanes per patch), the unfused TV path (tiled system kernel + wavefront SOR) and the
