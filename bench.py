@@ -269,7 +269,7 @@ def block_small_batch(capi, torch, p, batch, ia, ib, stream, dev, args):
     dt = timed_steps(torch, lambda: b.run(stream), 100, 10)
     same = frame_checksums(capi, torch, b, p, n, dev) == frame_checksums(capi, torch, batch, p, n, dev)
     b.close()
-    return {"workload": "64 pairs per step, one GPU, launch-graph replay, multi-wave fused TV (producer + solver wavefront per fixed-point iteration)", "value": round(n / dt, 1),
+    return {"workload": "64 pairs per step, one GPU, multi-wave fused TV (producer + solver wavefront per fixed-point iteration)", "value": round(n / dt, 1),
             "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "bit_identical_to_large_batch": bool(same)}
 
 
@@ -299,7 +299,7 @@ def block_dropin_latency(capi, torch, p, batch, ia, ib, stream, dev, args):
     same = np.array_equal(out, batch.download(0))
     L.ofdis_flow_cache_clear()
     return {"workload": "ofdis_flow(): one 1024x436 op-2 pair per call, 245 KB host pyramid in, 57 KB host flow out, "
-                        "synchronous (cached context, pinned staging, launch-graph replay)",
+                        "synchronous (cached context, pinned staging pulled by copy kernels level by level)",
             "value": round(1.0 / dt, 1), "unit": "pairs/s", "ms_per_call": round(dt * 1e3, 4),
             "bit_identical_to_batched": bool(same)}
 
@@ -524,7 +524,7 @@ def main():
     tstream = torch.cuda.Stream(device=dev)
     stream = tstream.cuda_stream
     batch = capi.Batch(p, B)
-    pipeline = args.pipeline if B >= 1024 else 1  # small shares: one stream, launch-graph replay instead
+    pipeline = args.pipeline if B >= 1024 else 1  # small shares: one stream
     batch.set_pipeline(pipeline)
     torch.cuda.synchronize()  # frames were generated on torch's default stream
     batch.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
@@ -662,7 +662,7 @@ def main():
                                  "launch": "self-spawned by bench.py --gpus" if os.environ.get("OFDIS_BENCH_SPAWNED") else
                                            ("torch.distributed.run" if world > 1 else "single process")},
                        "pipeline": f"{pipeline} sub-batches per GPU on internal HIP streams, consecutive steps "
-                                   f"overlap inside the timed region" if pipeline > 1 else "off (launch-graph replay)"},
+                                   f"overlap inside the timed region" if pipeline > 1 else "off"},
             "roofline": roofline, "kernels": kernels,
         }
         if roofline_valu:

@@ -89,8 +89,7 @@ int ofdis_flow(const ofdis_params* p,
                const float* const* im_a, const float* const* im_a_dx, const float* const* im_a_dy,
                const float* const* im_b, const float* const* im_b_dx, const float* const* im_b_dy,
                float* outflow, const float* initflow);
-/* ofdis_flow keeps the device contexts of the last few parameter sets (buffers, a stream, pinned staging, the captured
- * launch graph) so that a loop over frame pairs -- the reference's usage, one constructor per pair -- pays for them
+/* ofdis_flow keeps the device contexts of the last few parameter sets (buffers, a stream, pinned staging) so that a loop over frame pairs -- the reference's usage, one constructor per pair -- pays for them
  * once; calls are serialised internally.  ofdis_flow_cache_clear() releases them (e.g. before hipDeviceReset or at
  * shutdown); the next ofdis_flow() builds a fresh one. */
 void ofdis_flow_cache_clear(void);
@@ -149,9 +148,10 @@ int ofdis_batch_run(ofdis_batch* b, void* stream);
 int ofdis_batch_set_pipeline(ofdis_batch* b, int sub_batches);
 int ofdis_batch_join(ofdis_batch* b, void* stream);
 /* Launch-graph replay: the schedule of a context never changes, so an un-pipelined ofdis_batch_run can replay it as one
- * hipGraph launch instead of ~18 kernel launches (matters for small batches and the single-pair drop-in).
- * mode -1 = automatic (the default: captured at the second pass of a context), 0 = never, 1 = from the first pass.
- * Results are identical; timing mode, verbosity > 0 and pipelined mode always launch directly. */
+ * hipGraph launch instead of ~15 kernel launches.  mode 0 = direct launches (the default: measured, the asynchronous
+ * launches already overlap the execution and the replay is not faster), 1 = captured at the next pass, -1 = captured at
+ * the second pass of the context.  Results are identical; timing mode, verbosity > 0 and pipelined mode always launch
+ * directly. */
 int ofdis_batch_set_graph(ofdis_batch* b, int mode);
 /* device pointer to the result, [nframes][h>>sc_l][w>>sc_l][2] ([..][1] in stereo-depth mode); in pipelined mode valid on
  * a stream after ofdis_batch_join(b, stream) */

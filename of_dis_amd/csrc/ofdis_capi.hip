@@ -94,6 +94,21 @@ struct EventPair {
   hipEvent_t a, b;
 };
 
+// Plain copy kernel for the drop-in's staging traffic: the pinned host buffer is device-accessible, so the pyramid is
+// pulled (and the flow pushed) over PCIe by a kernel on the same queue as the computation instead of a DMA command with
+// its cross-engine synchronisation -- worth ~8 % of a 0.5 ms call (OFDIS_FLOW_DMA=1 goes back to hipMemcpyAsync).
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+hipError_t launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t s) {  // bytes: multiple of 16
+  const size_t n16 = bytes / 16;
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 struct ofdis_batch {
@@ -126,7 +141,7 @@ struct ofdis_batch {
   char* in_base = nullptr;
   size_t in_bytes = 0;
   // hipGraph replay of the launch schedule (ofdis_batch_set_graph)
-  int graph_mode = -1;                   // -1 auto, 0 off, 1 on
+  int graph_mode = 0;                    // 0 off (default), 1 on, -1 captured at the second pass
   long runs = 0;                         // un-pipelined passes so far
   hipGraphExec_t graph_exec = nullptr;
   const float* graph_initflow = nullptr; // the warm-start pointer the captured graph was built with
@@ -607,6 +622,7 @@ ofdis_batch frame_view(const ofdis_batch& b, int f0, int n) {
 }
 
 int run_levels(ofdis_batch* b, hipStream_t s);
+int run_one_level(ofdis_batch* b, int sl, hipStream_t s);
 int run_graph_or_levels(ofdis_batch* b, hipStream_t s);
 
 }  // namespace
@@ -684,6 +700,8 @@ int ofdis_batch_run(ofdis_batch* b, void* stream) {
 
 namespace {
 
+int run_one_level(ofdis_batch* b, int sl, hipStream_t s);
+
 int run_levels(ofdis_batch* b, hipStream_t s) {
   const ofdis_params& p = b->p;
   const int verbose = p.verbosity;
@@ -693,7 +711,21 @@ int run_levels(ofdis_batch* b, hipStream_t s) {
     t_all0 = now_ms();
   }
   if (verbose > 1) printf("TIME (Grid Memo. Alloc. ) (ms): %3g\n", 0.0);  // buffers live in the batch context
-  for (int sl = p.sc_f; sl >= p.sc_l; --sl) {
+  for (int sl = p.sc_f; sl >= p.sc_l; --sl)
+    if (int rc = run_one_level(b, sl, s)) return rc;
+  if (verbose > 0) {
+    (void)hipStreamSynchronize(s);
+    printf("TIME (O.Flow Run-Time   ) (ms): %3g\n", now_ms() - t_all0);
+    fflush(stdout);
+  }
+  return OFDIS_OK;
+}
+
+// one pyramid level of the loop (the body of oflow.cpp:184-337)
+int run_one_level(ofdis_batch* b, int sl, hipStream_t s) {
+  const ofdis_params& p = b->p;
+  const int verbose = p.verbosity;
+  {
     const int ii = sl - p.sc_l;
     const LevelGeom& g = b->geom[ii];
     double tt[5] = {0, 0, 0, 0, 0};
@@ -781,19 +813,15 @@ int run_levels(ofdis_batch* b, hipStream_t s) {
              sl, g.nop, tt[0], tt[1], tt[2], tt[3], tt[4], tt[0] + tt[1] + tt[2] + tt[3] + tt[4]);
     }
   }
-  if (verbose > 0) {
-    (void)hipStreamSynchronize(s);
-    printf("TIME (O.Flow Run-Time   ) (ms): %3g\n", now_ms() - t_all0);
-    fflush(stdout);
-  }
   return OFDIS_OK;
 }
 
-// The launch schedule of a context is fixed (same kernels, same pointers every pass), so from its second un-pipelined
-// pass on it is replayed as ONE hipGraph launch instead of ~18 kernel launches and a few memsets: for small batches
-// (and the single-pair drop-in) the host-side launch cost is a visible share of a pass.  Off when timing or TIME lines
-// are requested (they synchronise between stages), in pipelined mode (the sub-batches are deliberately not joined),
-// with OFDIS_NO_GRAPH, or after a capture failure -- the direct launches are always the fallback.
+// The launch schedule of a context is fixed (same kernels, same pointers every pass), so it can be replayed as ONE
+// hipGraph launch instead of ~15 kernel launches (ofdis_batch_set_graph).  Measured on this stack it buys nothing: the
+// direct launches are asynchronous and overlap the execution of the first kernels (64 pairs per pass: 0.491 ms replayed,
+// 0.486 ms direct; one pair: 0.459 both), so the default is off.  Never used when timing or TIME lines are requested
+// (they synchronise between stages), in pipelined mode (the sub-batches are deliberately not joined), with
+// OFDIS_NO_GRAPH, or after a capture failure -- the direct launches are always the fallback.
 int run_graph_or_levels(ofdis_batch* b, hipStream_t s) {
   static const bool env_off = getenv("OFDIS_NO_GRAPH") != nullptr;
   const bool want = b->graph_mode != 0 && !env_off && !b->timing && b->p.verbosity == 0 && (b->graph_mode == 1 || b->runs >= 1);
@@ -1003,25 +1031,51 @@ int ofdis_flow(const ofdis_params* p, const float* const* im_a, const float* con
   rc = flow_ctx_get(p, &c);
   if (rc) return rc;
   ofdis_batch* b = c->b;
-  // the whole pyramid through pinned staging in one copy (the planes mirror the device layout)
+  // The pyramid goes through pinned staging (the planes mirror the device layout), coarsest level first: a level is
+  // copied into the staging buffer, pulled to the device by a copy kernel and its kernels are launched; while the GPU
+  // works on it the host stages the next finer -- larger -- level (measured per 1024x436 pair: whole pyramid staged up
+  // front + DMA + graph replay 0.507 ms, with kernel copies 0.495, with direct launches 0.488-0.500, level by level
+  // 0.484-0.494).  The launches are direct: replaying a graph per call is not faster than 15 asynchronous launches that
+  // overlap the execution.
+  // With verbosity > 0 the whole pyramid is uploaded first so that the TIME lines measure computation only.
   const float* const* src[6] = {im_a, im_a_dx, im_a_dy, im_b, im_b_dx, im_b_dy};
   const int nin = p->usefbcon ? 6 : 4;
   for (int l = p->sc_l; l <= p->sc_f; ++l)
-    for (int k = 0; k < nin; ++k) {
+    for (int k = 0; k < nin; ++k)
       if (!src[k][l]) return fail(OFDIS_ERR_INVALID, "pyramid level pointer is NULL");
-      memcpy(c->stage + ((char*)b->in[k][l - p->sc_l] - b->in_base), src[k][l], b->g(l).plane_elems * sizeof(float));
-    }
-  HIPCHK(hipMemcpyAsync(b->in_base, c->stage, b->in_bytes, hipMemcpyHostToDevice, c->s));
   if (initflow) {
     rc = ofdis_batch_upload_initflow(b, 0, initflow, c->s);
     if (!rc) HIPCHK(hipStreamSynchronize(c->s));  // the caller's array is pageable and may go away after the call
+    if (rc) return rc;
   } else {
     b->initflow = nullptr;  // a previous call on this context may have warm-started
   }
-  if (!rc) rc = ofdis_batch_run(b, c->s);
+  static const bool use_dma = getenv("OFDIS_FLOW_DMA") != nullptr;
+  auto stage_level = [&](int l) -> int {
+    const int i = l - p->sc_l;
+    for (int k = 0; k < nin; ++k)
+      memcpy(c->stage + ((char*)b->in[k][i] - b->in_base), src[k][l], b->g(l).plane_elems * sizeof(float));
+    // the planes of one level are consecutive allocations: [in[0][i], in[nin-1][i] + its padded size)
+    char* lo = (char*)b->in[0][i];
+    const size_t last = (b->g(l).plane_elems * sizeof(float) + 255) & ~(size_t)255;
+    const size_t bytes = (size_t)((char*)b->in[nin - 1][i] - lo) + last;
+    if (use_dma) HIPCHK(hipMemcpyAsync(lo, c->stage + (lo - b->in_base), bytes, hipMemcpyHostToDevice, c->s));
+    else HIPCHK(launch_copy16(lo, c->stage + (lo - b->in_base), bytes, c->s));
+    return OFDIS_OK;
+  };
+  if (p->verbosity == 0 && !getenv("OFDIS_FLOW_WHOLE")) {
+    for (int l = p->sc_f; l >= p->sc_l && !rc; --l) {
+      rc = stage_level(l);
+      if (!rc) rc = run_one_level(b, l, c->s);
+    }
+  } else {
+    for (int l = p->sc_f; l >= p->sc_l && !rc; --l) rc = stage_level(l);
+    if (!rc) rc = ofdis_batch_run(b, c->s);
+  }
   if (rc) return rc;
   char* out_stage = c->stage + b->in_bytes;
-  HIPCHK(hipMemcpyAsync(out_stage, b->flow[0], c->flow_bytes, hipMemcpyDeviceToHost, c->s));
+  if (use_dma || (c->flow_bytes & 15)) HIPCHK(hipMemcpyAsync(out_stage, b->flow[0], c->flow_bytes, hipMemcpyDeviceToHost, c->s));
+  else HIPCHK(launch_copy16(out_stage, b->flow[0], c->flow_bytes, c->s));
   HIPCHK(hipStreamSynchronize(c->s));
   memcpy(outflow, out_stage, c->flow_bytes);
   return OFDIS_OK;

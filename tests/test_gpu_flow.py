@@ -79,7 +79,7 @@ def test_upsample_crop_on_device(gpu, orc, size, opp):
 
 @pytest.mark.parametrize("mode", [-1, 0, 1])
 def test_launch_graph_replay(gpu, orc, mode):
-    """ofdis_batch_set_graph: the schedule replayed as one hipGraph launch (automatic mode captures at the second pass)
+    """ofdis_batch_set_graph: the schedule replayed as one hipGraph launch (0 = the default, direct; -1 captures at the second pass)
     must give the bits of the direct launches, also after the inputs or the warm start of the context changed."""
     cases = [synth_case(1024, 436, 1700 + k, 1, 2, 1) for k in range(3)]
     p = cases[0][0]
@@ -121,7 +121,7 @@ def test_dropin_context_cache(gpu, orc):
         for i, (p, pa, pb, _, _) in enumerate(cases):   # six parameter sets > four cache entries: evictions
             assert_bits_equal(gpu.flow(p, pa[0], pa[1], pa[2], pb[0]), refs[i], f"round {rnd}, set {i}")
     p, pa, pb, _, _ = cases[0]
-    for rep in range(5):                                 # the same context again and again (graph replay from call 2)
+    for rep in range(5):                                 # the same context again and again
         assert_bits_equal(gpu.flow(p, pa[0], pa[1], pa[2], pb[0]), refs[0], f"repeat {rep}")
     p2, qa, qb, _, _ = synth_case(1024, 436, 1900, 1, 2, 1)   # same parameters, other images: same context
     assert_bits_equal(gpu.flow(p2, qa[0], qa[1], qa[2], qb[0]), orc.flow(p2, qa[0], qa[1], qa[2], qb[0]), "other pair")
@@ -480,7 +480,7 @@ def test_kernel_selection_does_not_change_results(gpu, orc, nfr):
             b.set_input(l, kind, np.stack([planes[s % 3] for s in range(nfr)]))
     if nfr >= 1024:
         b.set_pipeline(2)
-    for rep in range(2):                              # direct launches, then (un-pipelined) the captured graph
+    for rep in range(2):
         b.run()
         out = b.download_all()
         for s in list(range(min(nfr, 12))) + [nfr // 2, nfr - 2, nfr - 1]:
@@ -494,10 +494,10 @@ def test_fallback_kernels_at_the_benchmark_geometry(gpu, orc, monkeypatch, env):
     stand-alone diag-layout warp kernel (large batches; small ones warp inside the derivatives kernel) must give the same
     bits as the kernels they stand in for; the switches exist for this test."""
     monkeypatch.setenv(env, "1")
-    gpu.lib().ofdis_flow_cache_clear()   # a cached drop-in context would replay the schedule it captured without the switch
+    gpu.lib().ofdis_flow_cache_clear()   # a cached drop-in context was created (and sized) without the switch
     p, pa, pb, _, _ = synth_case(1024, 436, 1600, 1, 2, 1)
     try:
-        for rep in range(3):                 # direct launches, then the captured graph of the fallback schedule
+        for rep in range(3):
             got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
             assert_bits_equal(got, orc.flow(p, pa[0], pa[1], pa[2], pb[0]), f"{env}=1, call {rep}")
     finally:
