@@ -290,11 +290,13 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
     HIPCHK(hipMemsetAsync(b->du, 0, npx * b->nframes * sizeof(float), s));
     HIPCHK(hipMemsetAsync(b->dv, 0, npx * b->nframes * sizeof(float), s));
   }
+  bool flow_written = false;  // the multi-wave variants of the fused kernel write the refined AoS flow themselves
   if (fused && n_inner > 0) {  // every fixed-point iteration of this level in one launch
     KTimer kt(b, OFDIS_K_FUSED, s);
     FusedArgs fa{t, b->derivs, b->mask_d, b->wx_d, b->wy_d, b->du, b->dv, c.quarter_alpha, c.half_delta_over3,
-                 c.half_gamma_over3, p.tv_solverit, p.tv_sor, n_inner, b->total_frames};
-    HIPCHK(launch_tv_fused(fa, s));
+                 c.half_gamma_over3, p.tv_solverit, p.tv_sor, n_inner, b->total_frames,
+                 getenv("OFDIS_NO_FINISH_FUSION") ? nullptr : flow_out};
+    HIPCHK(launch_tv_fused(fa, s, &flow_written));
   }
   for (int it = 0; it < n_inner && !fused; ++it) {
     {
@@ -309,7 +311,7 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
       HIPCHK(launch_sor(so, s));
     }
   }
-  {
+  if (!flow_written) {
     KTimer kt(b, OFDIS_K_UPDATE, s);
     if (fused)
       HIPCHK(launch_tv_finish(t, b->wx_d, b->wy_d, b->du, b->dv, flow_out, 1, s));

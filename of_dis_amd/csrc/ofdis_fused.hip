@@ -216,6 +216,11 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
   };
 
+  // this lane's row of the AoS output (multi-wave variants with flow_out)
+  float2* const flow_row = MW && a.flow_out
+                               ? reinterpret_cast<float2*>(a.flow_out) + ((size_t)(f0 + fl) * npx + (size_t)j * w)
+                               : nullptr;
+
   FRow W[6];
   FDer D[3];
   float uu[3], vv[3], sm[3];
@@ -432,6 +437,11 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           if (MW && it < n_iters - 1) {  // hand the row to the next iteration (lanes outside their columns publish finite
             // values nobody reads as a pixel: the reader's lane is outside its columns at the same step number)
             xring[(it * MW_RING + (taus & (MW_RING - 1))) * 64 + lane] = make_float2(nu[NS - 1], nv[NS - 1]);
+          } else if (MW && a.flow_out) {  // last iteration: the refined flow itself, AoS (one 8-byte store per lane;
+            // a lane's consecutive columns fill its cache lines over the next steps)
+            const float fwx = ldf(rsWx, vo1, srow * row_bytes), fwy = ldf(rsWy, vo1, srow * row_bytes);
+            if (row_ok && ig >= 0 && ig < wtot)
+              flow_row[ig] = make_float2(fwx + nu[NS - 1], fwy + nv[NS - 1]);
           } else if (row_ok && ig >= 0 && ig < wtot) {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nu[NS - 1]), rsU, vo1, srow * row_bytes, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nv[NS - 1]), rsV, vo1, srow * row_bytes, 0);
@@ -491,7 +501,8 @@ static bool split_enabled() {
   return g_split != 0;
 }
 
-hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s) {
+hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow) {
+  if (wrote_flow) *wrote_flow = false;
   if (!tv_fused_supported(a.t, a.iterations) || a.n_inner < 1 ||
       !tv_fused_params_ok(a.quarter_alpha, a.half_delta_over3, a.half_gamma_over3))
     return hipErrorInvalidValue;
@@ -506,6 +517,7 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s) {
   const bool mw = a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS && waves <= mw_max_groups() &&
                   (total <= MW_MAX_BATCH_FRAMES || mw_max_groups() >= (1 << 30));
   const bool split = mw && split_enabled() && a.n_inner <= SP_MAX_ITERS;
+  if (wrote_flow) *wrote_flow = mw && a.flow_out != nullptr;
 #define OFDIS_FUSED_LAUNCH(NS)                                                                                         \
   if (split) {                                                                                                         \
     if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 2>), dim3(waves), dim3(128 * a.n_inner), 0, s, a, R);    \

@@ -128,11 +128,15 @@ struct FusedArgs {
   float omega;
   int n_inner;     // fixed-point iterations run back to back inside one launch
   int total_frames;  // frames of the whole batch this launch is a part of (pipelined sub-batches); 0 = t.nframes
+  // optional: AoS flow [B][h][w][2].  When the launcher picks a multi-wave variant it writes uu = wx + du, vv = wy + dv
+  // of the last fixed-point iteration there itself (refine_variational.cpp:209-221, 92-99) instead of storing du, dv --
+  // tv_finish_kernel and its launch are then not needed; launch_tv_fused reports that through *wrote_flow.
+  float* flow_out;
 };
 bool tv_fused_supported(const TvGeom& t, int iterations);
 // the fused kernel's trimmed divisions (ofdis_dev.h) need the three weights to be 0 or of ordinary magnitude
 bool tv_fused_params_ok(float quarter_alpha, float half_delta_over3, float half_gamma_over3);
-hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s);
+hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow = nullptr);
 // number of frame groups (workgroups) up to which the multi-wave (iteration-pipelined) variants are launched; < 0 restores
 // the default
 void set_tv_fused_mw_max(int waves);
