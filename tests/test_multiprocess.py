@@ -172,6 +172,23 @@ def test_bench_spawns_its_own_ranks(gpu):
 
 
 @pytest.mark.gpu
+def test_bench_batch512_block_with_two_ranks(gpu):
+    """The secondary block `batch512` (BASELINE configs[4]: 512 pairs per step in total) in a two-rank run: 256 pairs per
+    rank, collectives in step on both ranks, one JSON line."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env, _ = _bench_env(gpu)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    d = _run_bench([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                    "--batch", "256", "--cpu-seconds", "0", "--no-parity"], env)
+    assert d["n_gpus"] == 2 and d["multi_gpu_check"]["bit_identical_to_1gpu"]
+    b5 = d["batch512"]
+    assert b5["scaling"] == "strong" and b5["value"] > 0 and "256 pairs on rank 0" in b5["workload"]
+    assert "small_batch" not in d and "cpu_baseline" not in d      # one-GPU blocks only
+
+
+@pytest.mark.gpu
 def test_bench_strong_scaling_partition(gpu):
     """BASELINE configs[4] in small: a FIXED batch (--total-frames) cut into contiguous per-rank shares; every frame of
     the other rank is re-computed on rank 0's GPU and must have the same bits."""
