@@ -162,6 +162,11 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   constexpr int MAXIT = MODE == 2 ? SP_MAX_ITERS : MW_MAX_ITERS;
   // du/dv rows handed from iteration k to iteration k+1: [k][step & 7][lane]
   __shared__ float2 xring[MW ? (MAXIT - 1) * MW_RING * 64 : 1];
+#ifdef OFDIS_FUSED_LDS_DUMMY  // occupancy experiment (tools/ab_build.py ... -DOFDIS_FUSED_LDS_DUMMY=15500: 62 KB per block
+  // = 2 wavefronts per SIMD instead of the 3 that 144 VGPRs allow): SAME kernel time, 2.64 ms per 4096-pair step
+  __shared__ float lds_dummy[MODE == 0 ? OFDIS_FUSED_LDS_DUMMY : 1];
+  if (a.n_inner < 0) lds_dummy[threadIdx.x] = a.omega;  // never true; keeps the array
+#endif
   // MODE 2: FSlot of the pixel row handed from an iteration's producer to its solver: [iteration][step & 1][field][lane]
   __shared__ float sring[MODE == 2 ? SP_MAX_ITERS * 2 * SLOT_FLOATS * 64 : 1];
   // prefetch distances: the W row (wx,wy,du,dv) of diag row t+PDW and the D row (8 derivatives + mask) of row t+PDD are

@@ -1,0 +1,75 @@
+// probe: cost per wave64 VALU instruction on gfx950 in SHADER CLOCKS (s_memtime), per SIMD, for 1..4 resident wavefronts
+// per SIMD and 1..8 independent dependency chains per wavefront -- the table behind DESIGN.md's VALU account.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/probes/issue_probe.hip -o tools/probes/issue_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+template <int CH, int MODE>
+__global__ __launch_bounds__(256) void k(float* out, unsigned long long* clk, int iters, float seed) {
+  float x[CH], y[CH];
+  unsigned long long m64 = __builtin_amdgcn_read_exec() ^ (unsigned long long)iters;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) { x[c] = seed + c + threadIdx.x; y[c] = seed * 0.5f + c; }
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if (MODE == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[c]) : "v"(seed));              // VOP2, 2 VGPR sources
+        if (MODE == 1) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[c]) : "v"(y[c]));               // VOP2, 2 distinct VGPRs
+        if (MODE == 2) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x[c]) : "s"(seed));               // VOP2, SGPR source
+        if (MODE == 3) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(y[c]), "v"(seed)); // VOP3, 3 VGPR sources
+        if (MODE == 4) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[c]) : "v"(y[c]), "v"(seed));   // VOP2 fmac
+        if (MODE == 5) asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x[c]));
+        if (MODE == 6) asm volatile("v_mul_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x[c]) : "v"(y[c]));
+        if (MODE == 7) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x[c]) : "v"(y[c]), "s"(m64));
+        if (MODE == 8) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[c]));
+        if (MODE == 9) asm volatile("v_sqrt_f32 %0, %0" : "+v"(x[c]));
+        if (MODE == 10) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x[c]) : "v"(y[c]));
+        if (MODE == 11) asm volatile("v_fma_f32 %0, -%0, %1, %2" : "+v"(x[c]) : "v"(y[c]), "v"(seed)); // VOP3 with modifier
+        if (MODE == 12) asm volatile("v_add_f32 %0, %0, %1\n\tv_mul_f32 %2, %2, %1" : "+v"(x[c]), "+v"(y[c]) : "v"(seed)); // 2 instrs
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) s += x[c] + y[c];
+  if (s == 12345.678f) out[0] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
+}
+
+template <int CH, int MODE>
+void run(const char* name, float* out, unsigned long long* clk, int per_iter = 1) {
+  const int iters = 1000;
+  printf("%-26s chains=%d :", name, CH);
+  for (int wps : {1, 2, 3, 4, 8}) {               // waves per SIMD
+    const int threads = 256, blocks = 256 * wps;  // 4 waves per block -> one per SIMD; wps blocks per CU
+    k<CH, MODE><<<blocks, threads>>>(out, clk, 10, 1.0f);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    k<CH, MODE><<<blocks, threads>>>(out, clk, iters, 1.0f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+    const double instr_per_wave = (double)iters * 16 * CH * per_iter;
+    // clocks one wave spent per instruction x waves sharing the SIMD = SIMD clocks per instruction... (block 0's view)
+    printf("  w%d: %.2f clk/instr/SIMD (s_memtime %.0f MHz)", wps, (double)c / instr_per_wave / wps,
+           (double)c / (ms * 1e-3) / 1e6);
+  }
+  printf("\n");
+}
+
+int main() {
+  float* out; hipMalloc(&out, 4);
+  unsigned long long* clk; hipMalloc(&clk, 8);
+  run<1, 0>("v_add (dependent)", out, clk); run<2, 0>("v_add", out, clk); run<4, 0>("v_add", out, clk); run<8, 0>("v_add", out, clk);
+  run<4, 1>("v_mul 2 VGPR", out, clk); run<4, 2>("v_mul SGPR src", out, clk); run<4, 10>("v_sub 2 VGPR", out, clk);
+  run<4, 3>("v_fma VOP3", out, clk); run<4, 11>("v_fma VOP3 neg", out, clk); run<4, 4>("v_fmac VOP2", out, clk);
+  run<4, 5>("v_mov_dpp", out, clk); run<4, 6>("v_mul_dpp", out, clk); run<4, 7>("v_cndmask_e64", out, clk);
+  run<4, 8>("v_rcp", out, clk); run<4, 9>("v_sqrt", out, clk);
+  run<4, 12>("v_add + v_mul pair", out, clk, 2);
+  return 0;
+}
