@@ -64,9 +64,18 @@ __device__ __forceinline__ FDen fden(float b) {
   return FDen{b, 0.0f - b, rcp_refined(b)};
 }
 __device__ __forceinline__ float fdiv_by(float a, const FDen& d) {
+#ifdef OFDIS_FUSED_NODIV  // timing experiment only (results wrong): quotient = one multiplication, root = v_sqrt_f32 alone
+  return a * d.r;
+#endif
   return OFDIS_FUSED_FIXUP ? div_by(a, d.b, d.r) : div_by_finite(a, d.nb, d.r);
 }
 __device__ __forceinline__ float fdiv_rn(float a, float b) { return fdiv_by(a, fden(b)); }
+__device__ __forceinline__ float fsqrt_rn(float x) {
+#ifdef OFDIS_FUSED_NODIV
+  return __builtin_amdgcn_sqrtf(x);
+#endif
+  return sqrt_rn(x);
+}
 
 struct FSlot {
   float a11, a12, a22, b1, b2, sh, sv;  // system of pixel (j, tau - j); a** become the block inverse at step tau
@@ -95,7 +104,7 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
     tmp = iz + ix * u + iy * v;
     n1 = ix * ix + iy * iy + DATANORM;
     const FDen d1 = fden(n1);
-    tmp = fdiv_rn(m * hd3, sqrt_rn(fdiv_by(3 * tmp * tmp, d1) + EPS_COLOR));
+    tmp = fdiv_rn(m * hd3, fsqrt_rn(fdiv_by(3 * tmp * tmp, d1) + EPS_COLOR));
     tmp = fdiv_by(tmp, d1);
     a11 += tmp * ix * ix;
     a12 += tmp * ix * iy;
@@ -108,7 +117,7 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
   const FDen d1 = fden(n1), d2 = fden(n2);
   tmp = ixz + ixx * u + ixy * v;
   tmp2 = iyz + ixy * u + iyy * v;
-  tmp = fdiv_rn(m * hg3, sqrt_rn(fdiv_by(3 * tmp * tmp, d1) + fdiv_by(3 * tmp2 * tmp2, d2) + EPS_GRAD));
+  tmp = fdiv_rn(m * hg3, fsqrt_rn(fdiv_by(3 * tmp * tmp, d1) + fdiv_by(3 * tmp2 * tmp2, d2) + EPS_GRAD));
   tmp2 = fdiv_by(tmp, d2);
   tmp = fdiv_by(tmp, d1);
   a11 += tmp * ixx * ixx + tmp2 * ixy * ixy;
@@ -209,17 +218,33 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   // constant, the moving part (plane, diag row) is a scalar offset
   const int nfr = min(G, a.t.nframes - f0);
   const int plane_bytes = npx * 4;
+#ifdef OFDIS_FUSED_ALIAS  // timing experiment only (results wrong): every wavefront works on one of the first few frame
+  // groups' memory, so that the operands stay in L2 -- separates the kernel's HBM time from its issue time
+  const int fmem = (wid % OFDIS_FUSED_ALIAS) * G;
+#else
+  const int fmem = f0;
+#endif
   auto rsrc = [&](const float* base, int planes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)f0 * planes * npx), 0, nfr * planes * plane_bytes,
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)fmem * planes * npx), 0, nfr * planes * plane_bytes,
                                              0x00020000);
   };
   const __amdgpu_buffer_rsrc_t rsD = rsrc(a.derivs, 8), rsM = rsrc(a.mask, 1), rsWx = rsrc(a.wx, 1),
                                rsWy = rsrc(a.wy, 1), rsU = rsrc(a.du, 1), rsV = rsrc(a.dv, 1);
   const int vo1 = (fl * npx + j) * 4;      // single-plane operands
   const int vo8 = (fl * 8 * npx + j) * 4;  // the 8 derivative planes of a frame
+#ifdef OFDIS_FUSED_NOLOAD  // timing experiment only (results wrong): one load per operand before the loop, then the value
+  // is only made opaque again at every use site -- the step loop issues no VMEM loads at all
+  const float ld_once = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsWx, vo1, 0, 0));
+  auto ldf = [&](const __amdgpu_buffer_rsrc_t&, int, int) {
+    float v = ld_once;
+    asm volatile("" : "+v"(v));
+    return v;
+  };
+#else
   auto ldf = [&](const __amdgpu_buffer_rsrc_t& rs, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
   };
+#endif
 
   // this lane's row of the AoS output (multi-wave variants with flow_out)
   float2* const flow_row = MW && a.flow_out
@@ -353,7 +378,7 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           const float vx = D3_C0 * vl + D3_C2 * vr;
           const float uy = D3_C0 * ut + D3_C2 * ub;
           const float vy = D3_C0 * vt + D3_C2 * vb;
-          sm[(u + 2) % 3] = fdiv_rn(qa, sqrt_rn(ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH));
+          sm[(u + 2) % 3] = fdiv_rn(qa, fsqrt_rn(ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH));
         }
         // ---- (4) system of pixel row tau = t+1 (opticalflow_aux.c:150-163, 172-199, 342-427)
         //      x of row tau is x2 of the previous step: "last column" was x2_last then

@@ -29,6 +29,16 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* clk, in
         if (MODE == 10) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x[c]) : "v"(y[c]));
         if (MODE == 11) asm volatile("v_fma_f32 %0, -%0, %1, %2" : "+v"(x[c]) : "v"(y[c]), "v"(seed)); // VOP3 with modifier
         if (MODE == 12) asm volatile("v_add_f32 %0, %0, %1\n\tv_mul_f32 %2, %2, %1" : "+v"(x[c]), "+v"(y[c]) : "v"(seed)); // 2 instrs
+        if (MODE == 13) asm volatile("v_add_f32 %0, 0x3c23d70b, %0" : "+v"(x[c]));                   // VOP2 + 32-bit literal
+        if (MODE == 14) asm volatile("v_mul_f32 %0, 0.5, %0" : "+v"(x[c]));                          // VOP2, inline constant
+        if (MODE == 15) asm volatile("v_cmp_ge_f32_e64 s[40:41], 0, %0" : : "v"(x[c]) : "s40", "s41");  // compare -> SGPR pair
+        if (MODE == 16) asm volatile("v_cmp_ge_f32_e32 vcc, 0, %0" : : "v"(x[c]) : "vcc");           // compare -> VCC
+        if (MODE == 17) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x[c]) : "v"(y[c]));   // select on VCC (4-byte)
+        if (MODE == 18) asm volatile("v_add_u32_e32 %0, 1, %0" : "+v"(x[c]));                        // integer add, inline constant
+        if (MODE == 19) asm volatile("v_mul_f32 %0, %0, %1\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x[c]), "+v"(y[c]) : "v"(seed)); // plain + DPP alternating
+        if (MODE == 20) asm volatile("v_mul_f32 %0, %0, %1\n\tv_mul_f32 %2, %3, %2" : "+v"(x[c]), "+v"(y[c]) : "v"(seed), "s"(seed)); // plain + SGPR-source alternating
+        if (MODE == 21) asm volatile("v_mul_f32 %0, %0, %1\n\tv_rcp_f32 %2, %2" : "+v"(x[c]), "+v"(y[c]) : "v"(seed)); // plain + transcendental alternating
+        if (MODE == 22) asm volatile("v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_rcp_f32 %2, %2" : "+v"(x[c]), "+v"(y[c]) : "v"(seed)); // 3 plain + 1 transcendental
       }
     }
   }
@@ -37,7 +47,9 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* clk, in
 #pragma unroll
   for (int c = 0; c < CH; ++c) s += x[c] + y[c];
   if (s == 12345.678f) out[0] = s;
-  if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
+  // the longest-resident wavefront = the launch in shader clocks (block 0 alone would report the OLDEST wavefront, which the
+  // issue arbiter prefers: it runs at lone-wavefront speed whatever else is resident)
+  if ((threadIdx.x & 63) == 0) atomicMax(clk, t1 - t0);
 }
 
 template <int CH, int MODE>
@@ -48,6 +60,7 @@ void run(const char* name, float* out, unsigned long long* clk, int per_iter = 1
     const int threads = 256, blocks = 256 * wps;  // 4 waves per block -> one per SIMD; wps blocks per CU
     k<CH, MODE><<<blocks, threads>>>(out, clk, 10, 1.0f);
     hipDeviceSynchronize();
+    hipMemset(clk, 0, 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
     k<CH, MODE><<<blocks, threads>>>(out, clk, iters, 1.0f);
@@ -71,5 +84,9 @@ int main() {
   run<4, 5>("v_mov_dpp", out, clk); run<4, 6>("v_mul_dpp", out, clk); run<4, 7>("v_cndmask_e64", out, clk);
   run<4, 8>("v_rcp", out, clk); run<4, 9>("v_sqrt", out, clk);
   run<4, 12>("v_add + v_mul pair", out, clk, 2);
+  run<4, 13>("v_add literal", out, clk); run<4, 14>("v_mul inline const", out, clk); run<4, 15>("v_cmp_e64 -> sgpr", out, clk);
+  run<4, 16>("v_cmp_e32 -> vcc", out, clk); run<4, 17>("v_cndmask_e32 vcc", out, clk); run<4, 18>("v_add_u32 inline", out, clk);
+  run<4, 19>("plain + dpp", out, clk, 2); run<4, 20>("plain + sgpr src", out, clk, 2); run<4, 21>("plain + rcp", out, clk, 2);
+  run<4, 22>("3 plain + rcp", out, clk, 4);
   return 0;
 }
