@@ -245,12 +245,13 @@ def wave_sum_test(x):
 
 
 def div_sqrt_test(a, b):
-    """Rows: div_rn(a,b), a/b, sqrt_rn(|a|), sqrtf(|a|) computed on the device (ofdis_dev.h)."""
+    """Rows: div_rn(a,b), a/b, sqrt_rn(|a|), sqrtf(|a|), the quotient through rcp_newton, rcp_newton(b), sqrt_newton(|a|),
+    b / sqrt(|a|) through rcp_from, computed on the device (ofdis_dev.h)."""
     a, b = _f(a), _f(b)
-    da, db, o = Dev(a), Dev(b), Dev(nbytes=4 * a.nbytes)
+    da, db, o = Dev(a), Dev(b), Dev(nbytes=8 * a.nbytes)
     check(lib().ofdis_test_div_sqrt(da.ptr, db.ptr, o.ptr, a.size, None))
     check(lib().ofdis_sync(None))
-    return o.get((4, a.size))
+    return o.get((8, a.size))
 
 
 class Batch:

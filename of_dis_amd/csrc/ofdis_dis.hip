@@ -809,6 +809,13 @@ __global__ void div_sqrt_test_kernel(const float* a, const float* b, float* out,
   out[n + i] = x / y;
   out[2 * n + i] = sqrt_rn(fabsf(x));
   out[3 * n + i] = sqrtf(fabsf(x));
+  // the fused TV kernel's quotient: reciprocal without v_rcp_f32 (rcp_newton), no v_div_fixup (finite operands only)
+  out[4 * n + i] = div_by_finite(x, 0.0f - y, rcp_newton(y, 0.0f - y));
+  out[5 * n + i] = rcp_newton(y, 0.0f - y);
+  float rs;
+  const float sq = sqrt_newton(fabsf(x), rs);
+  out[6 * n + i] = sq;
+  out[7 * n + i] = div_by_finite(y, 0.0f - sq, rcp_from(sq, 0.0f - sq, rs));  // y / sqrt(|x|) as the fused TV kernel forms it
 }
 hipError_t launch_div_sqrt_test(const float* a, const float* b, float* out, int n, hipStream_t s) {
   hipLaunchKernelGGL(div_sqrt_test_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);

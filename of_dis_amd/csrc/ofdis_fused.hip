@@ -58,10 +58,26 @@ namespace ofdis {
 struct FDen {  // a denominator prepared once for all its quotients
   float b, nb, r;
 };
+#ifndef OFDIS_FUSED_RCPNR
+#define OFDIS_FUSED_RCPNR 0  // 1: reciprocals by rcp_newton (no transcendental instruction) instead of v_rcp_f32 + one step
+#endif
+#ifndef OFDIS_FUSED_BPERM
+#define OFDIS_FUSED_BPERM 0  // 1: lane shifts by ds_bpermute_b32 instead of DPP moves
+#endif
+#ifndef OFDIS_FUSED_SQRTNR
+#define OFDIS_FUSED_SQRTNR 0  // 1: square roots by sqrt_newton (no transcendental instruction) instead of v_sqrt_f32 + selection
+#endif
 __device__ __forceinline__ FDen fden(float b) {
   // 0 - b, not -b: a subtraction from +0 is not a negation for the compiler (signed zeros), so it stays one plain
   // instruction and is not folded back into a source modifier (VOP3) of every fma that uses it
-  return FDen{b, 0.0f - b, rcp_refined(b)};
+  const float nb = 0.0f - b;
+#if OFDIS_FUSED_RCPNR == 2  // experiment: v_rcp_f32 followed by a scalar instruction
+  float r0;
+  asm("v_rcp_f32 %0, %1\n\ts_nop 0" : "=v"(r0) : "v"(b));
+  const float e0 = __builtin_fmaf(nb, r0, 1.0f);
+  return FDen{b, nb, __builtin_fmaf(e0, r0, r0)};
+#endif
+  return FDen{b, nb, OFDIS_FUSED_RCPNR ? rcp_newton(b, nb) : rcp_refined(b)};
 }
 __device__ __forceinline__ float fdiv_by(float a, const FDen& d) {
 #ifdef OFDIS_FUSED_NODIV  // timing experiment only (results wrong): quotient = one multiplication, root = v_sqrt_f32 alone
@@ -70,11 +86,31 @@ __device__ __forceinline__ float fdiv_by(float a, const FDen& d) {
   return OFDIS_FUSED_FIXUP ? div_by(a, d.b, d.r) : div_by_finite(a, d.nb, d.r);
 }
 __device__ __forceinline__ float fdiv_rn(float a, float b) { return fdiv_by(a, fden(b)); }
-__device__ __forceinline__ float fsqrt_rn(float x) {
+// num / sqrt(x): the root and, from its by-product 1/sqrt(x), the reciprocal of the root
+__device__ __forceinline__ float fdiv_by_sqrt(float num, float x) {
 #ifdef OFDIS_FUSED_NODIV
-  return __builtin_amdgcn_sqrtf(x);
+  return num * __builtin_amdgcn_rsqf(x);
 #endif
-  return sqrt_rn(x);
+  if (OFDIS_FUSED_SQRTNR == 1) {
+    float y;
+    const float s = sqrt_newton(x, y);
+    const float ns = 0.0f - s;
+    return fdiv_by(num, FDen{s, ns, rcp_from(s, ns, y)});
+  }
+#if OFDIS_FUSED_SQRTNR == 2  // experiment: v_sqrt_f32 followed by a scalar instruction
+  {
+    float s;
+    asm("v_sqrt_f32 %0, %1\n\ts_nop 0" : "=v"(s) : "v"(x));
+    const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    const float su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    const float ed = __builtin_fmaf(-sd, s, x);
+    const float eu = __builtin_fmaf(-su, s, x);
+    float r = (ed <= 0.0f) ? sd : s;
+    r = (eu > 0.0f) ? su : r;
+    return fdiv_by(num, fden(r));
+  }
+#endif
+  return fdiv_rn(num, sqrt_rn(x));
 }
 
 struct FSlot {
@@ -104,7 +140,7 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
     tmp = iz + ix * u + iy * v;
     n1 = ix * ix + iy * iy + DATANORM;
     const FDen d1 = fden(n1);
-    tmp = fdiv_rn(m * hd3, fsqrt_rn(fdiv_by(3 * tmp * tmp, d1) + EPS_COLOR));
+    tmp = fdiv_by_sqrt(m * hd3, fdiv_by(3 * tmp * tmp, d1) + EPS_COLOR);
     tmp = fdiv_by(tmp, d1);
     a11 += tmp * ix * ix;
     a12 += tmp * ix * iy;
@@ -117,7 +153,7 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
   const FDen d1 = fden(n1), d2 = fden(n2);
   tmp = ixz + ixx * u + ixy * v;
   tmp2 = iyz + ixy * u + iyy * v;
-  tmp = fdiv_rn(m * hg3, fsqrt_rn(fdiv_by(3 * tmp * tmp, d1) + fdiv_by(3 * tmp2 * tmp2, d2) + EPS_GRAD));
+  tmp = fdiv_by_sqrt(m * hg3, fdiv_by(3 * tmp * tmp, d1) + fdiv_by(3 * tmp2 * tmp2, d2) + EPS_GRAD);
   tmp2 = fdiv_by(tmp, d2);
   tmp = fdiv_by(tmp, d1);
   a11 += tmp * ixx * ixx + tmp2 * ixy * ixy;
@@ -164,7 +200,11 @@ constexpr int SLOT_FLOATS = 11;  // FSlot
 //         iteration's producer through the same LDS ring MODE 1 uses.  A lone wavefront issues one instruction per ~6
 //         clocks (dependent-issue latency), so halving the instructions per wavefront and step nearly halves the step.
 template <int NS, bool BRIGHT, int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * MW_MAX_ITERS : 256)) void tv_fused_kernel(
+#ifndef OFDIS_FUSED_MINWAVES
+#define OFDIS_FUSED_MINWAVES 1
+#endif
+__global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * MW_MAX_ITERS : 256),
+                             MODE == 0 ? OFDIS_FUSED_MINWAVES : 1) void tv_fused_kernel(
     const FusedArgs a, const int R) {
   constexpr int U = 6;
   constexpr bool MW = MODE != 0;
@@ -213,6 +253,26 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   const int j = jr < h ? jr : h - 1;
   const bool has_top = j > 0, has_bot = j < h - 1;
   const float omega = a.omega, qa = a.quarter_alpha, hd3 = a.half_delta_over3, hg3 = a.half_gamma_over3;
+  // (x, y-1) / (x, y+1) live in the neighbouring lanes.  Through the LDS crossbar the shift wraps around instead of
+  // filling with zero; every consumer either selects the value away on its border row or multiplies it by an edge weight
+  // that is zero there (and the weight itself is zero in the source lane: last / idle rows have sv = 0), see "Border
+  // handling" below.
+  const int a_prev = ((lane + 63) & 63) * 4, a_next = ((lane + 1) & 63) * 4;
+#if OFDIS_FUSED_BPERM == 2  // experiment: DPP moves, each followed by a scalar instruction (ends the slow issue mode it starts)
+  auto from_prev = [&](float x) {
+    float r;
+    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 0" : "=v"(r) : "v"(x));
+    return r;
+  };
+  auto from_next = [&](float x) {
+    float r;
+    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 0" : "=v"(r) : "v"(x));
+    return r;
+  };
+#else
+  auto from_prev = [&](float x) { return OFDIS_FUSED_BPERM ? lane_read(x, a_prev) : wave_from_prev(x); };
+  auto from_next = [&](float x) { return OFDIS_FUSED_BPERM ? lane_read(x, a_next) : wave_from_next(x); };
+#endif
 
   // one buffer resource per operand, based at the wavefront's first frame: a lane's byte offset within it is
   // constant, the moving part (plane, diag row) is a scalar offset
@@ -366,8 +426,8 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           const float uc = uu[(u + 2) % 3], vc = vv[(u + 2) % 3];
           float ul = uu[(u + 1) % 3], vl = vv[(u + 1) % 3];                  // (x-1, y)
           float ur = uu[u % 3], vr = vv[u % 3];                              // (x+1, y): row t+3
-          float ut = wave_from_prev(uu[(u + 1) % 3]), vt = wave_from_prev(vv[(u + 1) % 3]);  // (x, y-1)
-          float ub = wave_from_next(uu[u % 3]), vb = wave_from_next(vv[u % 3]);              // (x, y+1)
+          float ut = from_prev(uu[(u + 1) % 3]), vt = from_prev(vv[(u + 1) % 3]);  // (x, y-1)
+          float ub = from_next(uu[u % 3]), vb = from_next(vv[u % 3]);              // (x, y+1)
           if (x2 == 0) { ul = uc; vl = vc; }
           if (x2_last) { ur = uc; vr = vc; }
           if (!has_top) { ut = uc; vt = vc; }
@@ -378,14 +438,14 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           const float vx = D3_C0 * vl + D3_C2 * vr;
           const float uy = D3_C0 * ut + D3_C2 * ub;
           const float vy = D3_C0 * vt + D3_C2 * vb;
-          sm[(u + 2) % 3] = fdiv_rn(qa, fsqrt_rn(ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH));
+          sm[(u + 2) % 3] = fdiv_by_sqrt(qa, ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH);
         }
         // ---- (4) system of pixel row tau = t+1 (opticalflow_aux.c:150-163, 172-199, 342-427)
         //      x of row tau is x2 of the previous step: "last column" was x2_last then
         {
           const float sc = sm[(u + 1) % 3];
           const float s_r = sm[(u + 2) % 3];
-          const float s_d = wave_from_next(sm[(u + 2) % 3]);
+          const float s_d = from_next(sm[(u + 2) % 3]);
           const float sh_c = x1_last ? 0.0f : sc + s_r;
           const float sv_c = has_bot ? sc + s_d : 0.0f;
           const FRow& rc = W[(u + 1) % 6];
@@ -393,10 +453,10 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           const FRow& rp = W[(u + 2) % 6];  // row tau+1
           float a11, a12, a22, b1, b2;
           data_term_gray<BRIGHT>(D[(u + 1) % 3], rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
-          const float wx_u = wave_from_prev(rm.wx), wy_u = wave_from_prev(rm.wy);
-          const float wx_d = wave_from_next(rp.wx), wy_d = wave_from_next(rp.wy);
+          const float wx_u = from_prev(rm.wx), wy_u = from_prev(rm.wy);
+          const float wx_d = from_next(rp.wx), wy_d = from_next(rp.wy);
           const float sh_l = slot[u % 6].sh;         // (s_l + sc), 0 on column 0
-          const float sv_t = wave_from_prev(slot[u % 6].sv);  // (s_u + sc), 0 on row 0
+          const float sv_t = from_prev(slot[u % 6].sv);  // (s_u + sc), 0 on row 0
           b1 -= sh_l * (rc.wx - rm.wx);
           b2 -= sh_l * (rc.wy - rm.wy);
           b1 += sh_c * (rp.wx - rc.wx);
@@ -446,15 +506,15 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
             const FSlot& p = slot[(u + 5) % 6];
             ou = p.dur; ov = p.dvr;
             rgu = c.dur; rgv = c.dvr;
-            bu = wave_from_next(c.dur);
-            bv = wave_from_next(c.dvr);
+            bu = from_next(c.dur);
+            bv = from_next(c.dvr);
           } else {
             ou = ru2[s - 1]; ov = rv2[s - 1];
             rgu = ru[s - 1]; rgv = rv[s - 1];
-            bu = wave_from_next(ru[s - 1]);
-            bv = wave_from_next(rv[s - 1]);
+            bu = from_next(ru[s - 1]);
+            bv = from_next(rv[s - 1]);
           }
-          const float tu = wave_from_prev(ru[s]), tv = wave_from_prev(rv[s]);
+          const float tu = from_prev(ru[s]), tv = from_prev(rv[s]);
           const float lu = ru[s], lv = rv[s];
           const float s1 = c.sh * rgu + c.vt * tu + c.sv * bu + c.b1;
           const float s2 = c.sh * rgv + c.vt * tv + c.sv * bv + c.b2;

@@ -55,6 +55,22 @@ def test_trimmed_div_sqrt(gpu):
                        ("sqrt vs compiler", got[2], got[3]), ("sqrt vs numpy", got[2], r)]:
         same = (x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y))
         assert same.all(), (name, int((~same).sum()), a[~same][:4], b[~same][:4], x[~same][:4], y[~same][:4])
+    # the fused TV kernel's quotient (reciprocal by integer seed + Newton steps instead of v_rcp_f32, no v_div_fixup):
+    # finite numerators and normal finite denominators only; compared by value (a zero may carry the other sign)
+    fin = np.isfinite(a) & np.isfinite(b) & (b != 0)
+    assert np.array_equal(got[4][fin], q[fin]), int((got[4][fin] != q[fin]).sum())
+    with np.errstate(all="ignore"):
+        rr = (np.float32(1.0) / b).astype(_f32)
+    off = got[5][fin] != rr[fin]  # rcp_newton is the correctly rounded reciprocal up to rare 1-ulp cases
+    assert off.mean() < 1e-5, off.mean()
+    assert np.all(np.abs(got[5][fin].view(np.int32) - rr[fin].view(np.int32)) <= 1)
+    # square root without v_sqrt_f32, and the quotient by it (reciprocal seeded with the root's by-product)
+    pos = np.isfinite(a) & (np.abs(a) >= 2.0 ** -96)
+    assert np.array_equal(got[6][pos], r[pos]), int((got[6][pos] != r[pos]).sum())
+    both = pos & np.isfinite(b)
+    with np.errstate(all="ignore"):
+        qs = (b / r).astype(_f32)
+    assert np.array_equal(got[7][both], qs[both]), int((got[7][both] != qs[both]).sum())
 
 
 @pytest.mark.parametrize("w,h,noc", [(128, 56, 1), (64, 28, 1), (32, 14, 1), (30, 17, 3), (67, 33, 1), (5, 4, 1)])

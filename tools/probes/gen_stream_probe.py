@@ -51,6 +51,10 @@ def variant(stream, kind, seed=1):
             stream = variant(stream, kd, seed)
         return stream
     rnd = random.Random(seed)
+    if kind == "lds":
+        return list(stream)
+    if kind == "ldsnowait":
+        return [(op, a) for op, a in stream if op != "s_waitcnt"]
     out = []
     for op, args in stream:
         if kind == "vconst" and op.startswith("v_") and not op.startswith("v_cndmask") and not op.startswith("v_cmp") \
@@ -144,19 +148,27 @@ __global__ __launch_bounds__(512) void k_{tag}(unsigned long long* clk, int iter
 
 if __name__ == "__main__":
     name, loop = main_loop(sys.argv[1], sys.argv[2])
-    full = [(op, args) if (op.startswith("v_") or op.startswith("s_nop")) else ("s_nop", "0") for op, args, a, n in loop]
+    def keep(op, args):
+        if op.startswith("v_") or op.startswith("s_nop") or op.startswith("ds_bpermute"):
+            return (op, args)
+        if op == "s_waitcnt" and "lgkmcnt" in args:
+            return (op, re.search(r"lgkmcnt\(\d+\)", args).group(0))
+        return None
+    full = [keep(op, args) or ("s_nop", "0") for op, args, a, n in loop]
+    lds = [keep(op, args) for op, args, a, n in loop if keep(op, args)]
+    lds = [(op, args) for op, args in lds if not op.startswith("v_readfirstlane") and not op.startswith("v_cmpx")]
     full = [(op, args) for op, args in full if not op.startswith("v_readfirstlane") and not op.startswith("v_cmpx")]
     stream = [(op, args) for op, args, a, n in loop if op.startswith("v_") or op.startswith("s_nop")]
     # exec-mask writers / lane-crossing ops with SGPR results that the replay cannot keep meaningful are still plain VALU
     # issue; v_readfirstlane writes an SGPR the compiler may own: drop it
     stream = [(op, args) for op, args in stream if not op.startswith("v_readfirstlane") and not op.startswith("v_cmpx")]
-    kinds = ["nodpp__notrans", "plainonly", "asis", "nop_after"]
+    kinds = ["asis", "lds", "ldsnowait", "salu", "notrans"]
     print("// GENERATED by tools/probes/gen_stream_probe.py from", sys.argv[1], "--", name)
     print("// Build: hipcc --offload-arch=gfx950 -O3 tools/probes/stream_probe.hip -o tools/probes/stream_probe")
     print("#include <hip/hip_runtime.h>\n#include <stdio.h>")
     counts = {}
     for kd in kinds:
-        base = full if kd in ("salu", "salu_nop") else stream
+        base = full if kd in ("salu", "salu_nop") else (lds if kd.startswith("lds") else stream)
         nv, src = emit(name, kd, variant(base, kd))
         counts[kd] = nv
         print(src)
@@ -165,7 +177,7 @@ template <typename K>
 void run(const char* tag, K kern, int nvalu, unsigned long long* clk) {
   const int iters = 200;
   printf("%-8s (%d VALU/pass):", tag, nvalu);
-  for (int delay : {0, 1, 3, 17}) {  // the second wavefront of every SIMD enters the loop `delay` x s_sleep 1 later
+  for (int delay : {0, 1}) {  // the second wavefront of every SIMD enters the loop `delay` x s_sleep 1 later
     const int wps = 2;
     const int blocks = 256;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 0, 0, clk, 3, delay);
