@@ -114,6 +114,15 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     const int col = q % P, row = q / P;
     off[e] = ((row + lb) * tw + (col + lb)) * noc + c;
   }
+  int offb[E];  // ... in bytes, for the buffer loads of the second image
+#pragma unroll
+  for (int e = 0; e < E; ++e) offb[e] = off[e] * 4;
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc((void*)imB, 0, (int)(plane * sizeof(float)), 0x00020000);
+  const int nocb = noc * 4, upb = tw * noc * 4;
+  auto ldB = [&](int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voff, soff, 0));
+  };
   // x / novals: when novals is a power of two the product with its reciprocal is the same correctly
   // rounded value as the reference's division (both round the same real number), at 1/10 the cost
   const float fnv = (float)nv;
@@ -211,13 +220,15 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     const float we0 = r0 * r1, we1 = (1 - r0) * r1, we2 = r0 * (1 - r1), we3 = (1 - r0) * (1 - r1);
     pos0 += g.pad;
     pos1 += g.pad;
-    const int base = (pos1 * tw + pos0) * noc;
-    const unsigned up = (unsigned)(tw * noc);
+    // the four taps of an entry through ONE buffer resource: a 32-bit per-lane byte offset (the upper-left tap d; the
+    // position is >= one row + one pixel inside the plane for every in-bounds patch) and wave-uniform offsets to the
+    // other three -- one integer add per entry instead of a 64-bit address per tap
+    const int based = ((pos1 - 1) * tw + (pos0 - 1)) * noc * 4;
     float v[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const unsigned o = (unsigned)(base + off[e]);  // >= up + noc for every in-bounds position
-      const float ta = imB[o], tb = imB[o - noc], tc = imB[o - up], td = imB[o - up - noc];
+      const int vo = based + offb[e];
+      const float td = ldB(vo, 0), tc = ldB(vo, nocb), tb = ldB(vo, upb), ta = ldB(vo, upb + nocb);
       v[e] = valid[e] ? (we0 * ta + we1 * tb + we2 * tc + we3 * td) : 0.0f;
     }
     if (a.patnorm > 0) {
