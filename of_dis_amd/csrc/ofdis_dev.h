@@ -73,6 +73,14 @@ __device__ __forceinline__ float swap32_sum(float x) {
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
   return a + b;
 }
+// the first five steps: every 32-lane half reduced on its own (all its lanes end with the half's sum)
+__device__ __forceinline__ float half_wave_sum(float x) {
+  x = x + dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
+  x = x + dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+  x = x + dpp_mov<0x141>(x);  // row_half_mirror
+  x = x + dpp_mov<0x140>(x);  // row_mirror
+  return swap16_sum(x);
+}
 __device__ __forceinline__ float wave_sum(float x) {
   x = x + dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
   x = x + dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]

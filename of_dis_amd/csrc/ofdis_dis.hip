@@ -44,6 +44,19 @@ __device__ __forceinline__ float patch_sum(const float (&x)[M * (64 / LPP)], con
     for (int m = 1; m < M; ++m)
       if (valid[m]) c = c + x[m];
     return wave_sum(c);
+  } else if constexpr (LPP == 32) {
+    // novals > 64 with TWO patches per wavefront: lane pl of a patch's 32 lanes stands for the lanes pl and pl + 32 of the
+    // one-patch mapping and keeps their two accumulation chains apart (x[2m] = entry pl + 64 m, x[2m+1] = entry
+    // pl + 32 + 64 m); the butterfly steps at distance 1 ... 16 never leave a 32-lane half, so each chain is reduced over
+    // the patch's 32 lanes exactly as its half was, and the last step (distance 32: lower half + upper half, in that
+    // order in every lane) is one in-lane add.  Same additions, same order: same bits.
+    float ca = valid[0] ? x[0] : 0.0f, cb = valid[1] ? x[1] : 0.0f;
+#pragma unroll
+    for (int m = 1; m < M; ++m) {
+      if (valid[2 * m]) ca = ca + x[2 * m];
+      if (valid[2 * m + 1]) cb = cb + x[2 * m + 1];
+    }
+    return half_wave_sum(ca) + half_wave_sum(cb);
   } else {
     static_assert(LPP == 8 && M == 1, "novals <= 64 uses 8 lanes per patch");
     float c = valid[0] ? x[0] : 0.0f;
@@ -600,7 +613,15 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   const int M = (a.g.novals + 63) / 64;
   const bool full = a.g.novals == 64 * M;
   const bool gray8 = a.g.noc == 1 && a.g.P == 8 && !a.stereo && !getenv("OFDIS_NO_GRAY8");
-  const int lpp = (M <= 1) ? (gray8 ? 4 : 8) : 64;  // lanes per patch
+  // RGB 12x12 (operating points 3 and 4, BASELINE configs[3]): 432 entries, 6 full groups of 64 + 48.  OFDIS_RGB12_LPP=32:
+  // two patches per wavefront (the scalar solve, predicates and every reduction instruction shared by two patches:
+  // 929 -> 705 instructions per patch and iteration, 82 -> 127 VGPRs).  Measured on configs[3] the same 19.6 +- 0.4 ms per
+  // 16-pair level-1 launch either way -- patches that reset early leave their wavefront's other half running alone
+  // (PMC: 18 % fewer VALU instructions, same time) -- so one patch per wavefront stays the default.
+  const char* const lpp_env = getenv("OFDIS_RGB12_LPP");
+  const int rgb12_lpp = lpp_env ? atoi(lpp_env) : 64;
+  const bool rgb12 = a.g.novals == 432 && !a.stereo && (a.costfct == 0 || a.costfct == 1) && !getenv("OFDIS_NO_RGB12");
+  const int lpp = (M <= 1) ? (gray8 ? 4 : 8) : ((rgb12 && rgb12_lpp == 32) ? 32 : 64);  // lanes per patch
   const int ppw = 64 / lpp;                           // patches per wavefront
   const int wpf = (a.g.nop + ppw - 1) / ppw;          // wavefronts per frame
   const bool fast = gray8 && M <= 1;
@@ -620,10 +641,13 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((patch_optimize_kernel<1, 8, 0, -1>), gd, bd, 0, s, a);
   else if (M <= 3)
     hipLaunchKernelGGL((patch_optimize_kernel<3, 64, 0, -1>), gd, bd, 0, s, a);
-  // RGB 12x12 (operating points 3 and 4, BASELINE configs[3]): 432 entries, 6 full groups of 64 + 48
-  else if (a.g.novals == 432 && !a.stereo && a.costfct == 0 && !getenv("OFDIS_NO_RGB12"))
+  else if (rgb12 && lpp == 32 && a.costfct == 0)
+    hipLaunchKernelGGL((patch_optimize_kernel<7, 32, 432, 0>), gd, bd, 0, s, a);
+  else if (rgb12 && lpp == 32)
+    hipLaunchKernelGGL((patch_optimize_kernel<7, 32, 432, 1>), gd, bd, 0, s, a);
+  else if (rgb12 && a.costfct == 0)
     hipLaunchKernelGGL((patch_optimize_kernel<7, 64, 432, 0>), gd, bd, 0, s, a);
-  else if (a.g.novals == 432 && !a.stereo && a.costfct == 1 && !getenv("OFDIS_NO_RGB12"))
+  else if (rgb12)
     hipLaunchKernelGGL((patch_optimize_kernel<7, 64, 432, 1>), gd, bd, 0, s, a);
   else if (M <= 7)
     hipLaunchKernelGGL((patch_optimize_kernel<7, 64, 0, -1>), gd, bd, 0, s, a);

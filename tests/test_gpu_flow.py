@@ -269,6 +269,21 @@ def test_rgb_flow_bit_exact(gpu, orc):
         assert_bits_equal(got, oracle.ref("rgb", True).flow(p, pa[0], pa[1], pa[2], pb[0]), "rgb flow vs reference")
 
 
+@pytest.mark.parametrize("size,cost", [((320, 240), 1), ((320, 240), 0), ((203, 131), 1)])
+def test_rgb_two_patches_per_wavefront(gpu, orc, monkeypatch, size, cost):
+    """OFDIS_RGB12_LPP=32: the RGB 12x12 patch kernel with two patches per wavefront (32 lanes each, two accumulation
+    chains per lane standing for the lanes l and l + 32 of the one-patch mapping) gives the same bits -- also with an odd
+    patch count per frame (one half of the last wavefront idle)."""
+    monkeypatch.setenv("OFDIS_RGB12_LPP", "32")
+    gpu.lib().ofdis_flow_cache_clear()
+    p, pa, pb, _, _ = synth_case(size[0], size[1], 78, 3, 3, 1)
+    p = p.copy(costfct=cost, max_iter=8, min_iter=3)
+    try:
+        assert_bits_equal(gpu.flow(p, pa[0], pa[1], pa[2], pb[0]), orc.flow(p, pa[0], pa[1], pa[2], pb[0]), "rgb, 2 patches per wave")
+    finally:
+        gpu.lib().ofdis_flow_cache_clear()
+
+
 @pytest.mark.parametrize("cost", [1, 2])
 def test_cost_functions(gpu, orc, cost):
     p, pa, pb, _, _ = synth_case(320, 240, 55, 1, 2, 1)
