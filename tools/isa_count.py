@@ -70,8 +70,11 @@ def classify(op):
     return "vmem"
 
 
-COST = {"plain": 2.36, "inline": 2.36, "vop3": 2.46, "dpp": 4.1, "sgpr": 4.1, "literal": 4.1, "trans": 8.0,
-        "cmp": 4.1, "cndmask_sgpr": 4.1, "cndmask_vcc": 4.1}
+# back-to-back issue costs of tools/probes/issue_probe.hip (2+ wavefronts per SIMD); in a mixed stream compares, selects,
+# SGPR and literal operands pair like plain instructions (2.1) and every DPP / transcendental costs its wavefront the
+# pairing for ~100 instructions (profiles/README.md, snapshot r02_c) -- the estimate below is a lower bound
+COST = {"plain": 2.1, "inline": 2.1, "vop3": 2.2, "dpp": 4.1, "sgpr": 2.1, "literal": 2.1, "trans": 8.0,
+        "cmp": 2.1, "cndmask_sgpr": 2.1, "cndmask_vcc": 2.1}
 
 
 def valu_class(op, args, nbytes):
@@ -131,7 +134,7 @@ def summarize(name, body):
             if re.match(r"v_(rcp|sqrt|rsq|exp|log|sin|cos)", op):
                 trans += 1
     print(f"{name}\n  loop of {len(loop)} instructions: " + ", ".join(f"{k} {v}" for k, v in sorted(c.items())) +
-          f"; VALU 8-byte {v8}, DPP {dpp}, transcendental {trans}; issue slots (8-byte = 2) {c.get('valu', 0) + v8}")
+          f"; VALU 8-byte encoded {v8}, DPP {dpp}, transcendental {trans}")
     print("  " + ", ".join(f"{k} {v}" for k, v in sorted(ops.items(), key=lambda kv: -kv[1])[:14]))
     # operand classes with the issue costs measured by tools/probes/class_probe.hip (SIMD clocks per wave64 instruction)
     cl = {}
@@ -140,9 +143,9 @@ def summarize(name, body):
             continue
         k = valu_class(op, args, n)
         cl[k] = cl.get(k, 0) + 1
-    est = sum(COST.get(k, 4.1) * v for k, v in cl.items())
+    est = sum(COST.get(k, 2.1) * v for k, v in cl.items())
     print("  classes: " + ", ".join(f"{k} {v}" for k, v in sorted(cl.items(), key=lambda kv: -kv[1])) +
-          f"; issue-cost estimate {est:.0f} clocks per loop pass")
+          f"; paired-issue lower bound {est:.0f} clocks per loop pass")
 
 
 if __name__ == "__main__":

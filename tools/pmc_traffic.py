@@ -5,7 +5,7 @@ profiles/traffic.json: HBM bytes per step per kernel class.
                                 [<sq_counter_collection.csv>]
 
 The optional third file is a pass with SQ_INSTS_VALU (+ GRBM_GUI_ACTIVE): wave64 VALU instructions issued per step per
-kernel class (8-byte encodings -- VOP3, DPP -- count twice: they take two issue slots on gfx950) and the shader clock
+kernel class (every instruction counts once) and the shader clock
 sustained under the dominant kernel (GRBM_GUI_ACTIVE cycles / its kernel-trace duration), both read by bench.py for
 `roofline_valu`.
 
