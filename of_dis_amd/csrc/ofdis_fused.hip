@@ -216,6 +216,14 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   __shared__ float lds_dummy[MODE == 0 ? OFDIS_FUSED_LDS_DUMMY : 1];
   if (a.n_inner < 0) lds_dummy[threadIdx.x] = a.omega;  // never true; keeps the array
 #endif
+#ifndef OFDIS_FUSED_SLOTLDS
+#define OFDIS_FUSED_SLOTLDS 0
+#endif
+  // SL (MODE 0, -DOFDIS_FUSED_SLOTLDS=1): the systems waiting for sweeps 1 ... NS-1 live in LDS instead of a six-deep register
+  // ring (8 floats per pixel: block inverse, right-hand side, sh, sv, vt; hl is the previous row's sh): 8 KB per wavefront,
+  // ~40 VGPRs less -- the register budget of four wavefronts per SIMD.  [wavefront of the block][row & 3][half][lane]
+  constexpr bool SL = OFDIS_FUSED_SLOTLDS != 0 && MODE == 0;
+  __shared__ float4 slds[SL ? 4 * 4 * 2 * 64 : 1];
   // MODE 2: FSlot of the pixel row handed from an iteration's producer to its solver: [iteration][step & 1][field][lane]
   __shared__ float sring[MODE == 2 ? SP_MAX_ITERS * 2 * SLOT_FLOATS * 64 : 1];
   // prefetch distances: the W row (wx,wy,du,dv) of diag row t+PDW and the D row (8 derivatives + mask) of row t+PDD are
@@ -331,6 +339,17 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   float ru[NS], rv[NS], ru2[NS], rv2[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) { ru[s] = rv[s] = ru2[s] = rv2[s] = 0.0f; }
+  float4* const myring = slds + (SL ? (threadIdx.x >> 6) * (4 * 2 * 64) + lane : 0);
+  float hlc[NS], pdur = 0.0f, pdvr = 0.0f;  // SL: hl of the row each later sweep handles next; dur, dvr of the row before sweep 0's
+#pragma unroll
+  for (int s = 0; s < NS; ++s) hlc[s] = 1.0f;
+  if constexpr (SL) {  // fill-phase systems: unit diagonal and unit weights, as the register ring starts
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      myring[r * 128] = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
+      myring[r * 128 + 64] = make_float4(0.0f, 1.0f, 1.0f, 0.0f);
+    }
+  }
 
   auto wrap = [&](int r) { r %= w; return r < 0 ? r + w : r; };
   auto next_row = [&](int r) { return (r + 1 == w) ? 0 : r + 1; };
@@ -402,6 +421,15 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // step t = k0 + u - 3; up to U-1 steps past tend are executed: every pixel is then out of range
+      float4 qa_[NS], qb_[NS];
+      if constexpr (SL) {  // the systems of rows t-2, t-4, ... (issued first: consumed at the end of the step)
+#pragma unroll
+        for (int sw = 1; sw < NS; ++sw) {
+          const int row = (k0 + u - 3 - 2 * sw) & 3;
+          qa_[sw] = myring[row * 128];
+          qb_[sw] = myring[row * 128 + 64];
+        }
+      }
       if (do_p) {
         // ---- (1) loads: W row t+5, D row t+3
         load_w(W[(u + PDW) % 6], rowW, tauW);
@@ -496,15 +524,29 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           c.a11 = fdiv_by(A11, dd);
           c.a22 = fdiv_by(A22, dd);
           c.a12 = -fdiv_by(c.a12, dd);
+          if constexpr (SL && NS > 1) {  // (after this step's reads of the same ring row in program order)
+            const int row = (k0 + u - 3) & 3;
+            myring[row * 128] = make_float4(c.a11, c.a12, c.a22, c.b1);
+            myring[row * 128 + 64] = make_float4(c.b2, c.sh, c.sv, c.vt);
+          }
         }
         float nu[NS], nv[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          const FSlot& c = slot[(u - 2 * s + 12) % 6];
+          FSlot cl;
+          if constexpr (SL) {
+            if (s > 0) {
+              cl.a11 = qa_[s].x; cl.a12 = qa_[s].y; cl.a22 = qa_[s].z; cl.b1 = qa_[s].w;
+              cl.b2 = qb_[s].x; cl.sh = qb_[s].y; cl.sv = qb_[s].z; cl.vt = qb_[s].w;
+              cl.hl = hlc[s];
+              hlc[s] = qb_[s].y;  // the next row's left weight
+            }
+          }
+          const FSlot& c = (SL && s > 0) ? cl : slot[(u - 2 * s + 12) % 6];
           float ou, ov, rgu, rgv, bu, bv;
           if (s == 0) {
             const FSlot& p = slot[(u + 5) % 6];
-            ou = p.dur; ov = p.dvr;
+            ou = SL ? pdur : p.dur; ov = SL ? pdvr : p.dvr;
             rgu = c.dur; rgv = c.dvr;
             bu = from_next(c.dur);
             bv = from_next(c.dvr);
@@ -533,8 +575,12 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
             if (row_ok && ig >= 0 && ig < wtot)
               flow_row[ig] = make_float2(fwx + nu[NS - 1], fwy + nv[NS - 1]);
           } else if (row_ok && ig >= 0 && ig < wtot) {
+#ifdef OFDIS_FUSED_NOSTORE  // timing experiment only (results wrong): the results are only kept alive, never stored
+            asm volatile("" ::"v"(nu[NS - 1]), "v"(nv[NS - 1]));
+#else
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nu[NS - 1]), rsU, vo1, srow * row_bytes, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nv[NS - 1]), rsV, vo1, srow * row_bytes, 0);
+#endif
           }
         }
 #pragma unroll
@@ -542,6 +588,7 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           ru2[s] = ru[s]; rv2[s] = rv[s];
           ru[s] = nu[s]; rv[s] = nv[s];
         }
+        if constexpr (SL) { pdur = slot[u % 6].dur; pdvr = slot[u % 6].dvr; }
       }
       srow = next_row(srow);
       ++ig;
