@@ -1,6 +1,6 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-bash tools/gpu_check.sh r2final2
-OUT=$R/gpurun_out/r2final2
+bash tools/gpu_check.sh ${1:-r02c}
+OUT=$R/gpurun_out/${1:-r02c}
 export TMPDIR=/tmp; cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-parity --no-extras > $OUT/kt.log 2>&1
 f=$(find $OUT/kt -name "*kernel_stats.csv" | head -1)
