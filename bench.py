@@ -381,13 +381,27 @@ def block_config4(capi, torch, p, batch, ia, ib, stream, dev, args):
     """BASELINE configs[3]: run_OF_RGB operating-point-4 geometry on 1920x1080, L1 cost, 50 iterations, TV on
     (CLI: run_OF_RGB a b out 6 1 50 50 0.05 0.95 0 12 0.75 0 1 1 1 10 10 5 1 3 1.6 2)."""
     from of_dis_amd.params import oppoint
-    W4, H4, n = 1920, 1080, 32
+    # pairs per step: the block SOR of levels above 64 rows runs one workgroup per frame (7.5 ms per step whatever the
+    # batch up to 256 frames), so the resident batch is what amortises it: ~230 MB per pair, 96 pairs = 22 GB of the 288
+    W4, H4, n = 1920, 1080, int(os.environ.get("OFDIS_BENCH_CONFIG4_PAIRS", "96"))
     p4 = oppoint(4, W4, H4, noc=3, verbosity=0).copy(costfct=1, max_iter=50, min_iter=50)
     xa, xb = synth_frames_range(0, n, W4, H4, 4242, dev, channels=3)
     b4 = capi.Batch(p4, n)
     torch.cuda.synchronize()
     b4.build_pyramids_u8(xa.data_ptr(), xb.data_ptr(), W4, H4, stream)
     dt = timed_steps(torch, lambda: b4.run(stream), 2, 1)
+    # the last two frames again in a batch of their own: same bits (frame content depends on the global index only;
+    # a large batch must not change a frame's result -- 32-bit offsets, kernel selection)
+    tail_same = None
+    if n > 2:
+        sums = frame_checksums(capi, torch, b4, p4, n, dev)
+        ya, yb = synth_frames_range(n - 2, n, W4, H4, 4242, dev, channels=3)
+        b2 = capi.Batch(p4, 2)
+        torch.cuda.synchronize()
+        b2.build_pyramids_u8(ya.data_ptr(), yb.data_ptr(), W4, H4, stream)
+        b2.run(stream)
+        tail_same = frame_checksums(capi, torch, b2, p4, 2, dev) == sums[n - 2:]
+        b2.close()
     kernels = kernel_table(capi, torch, b4, p4, n, stream, nrep=1)
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     out = {"workload": f"run_OF_RGB 1920x1080 (padded 1920x1088, levels 6-1), patch 12 overlap 0.75, L1 cost, 50 GN "
@@ -396,6 +410,8 @@ def block_config4(capi, torch, p, batch, ia, ib, stream, dev, args):
            "roofline": {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"]},
            "kernels": kernels}
+    if tail_same is not None:
+        out["last_two_frames_bit_identical_to_a_batch_of_two"] = tail_same
     if args.cpu_seconds > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(p4, b4, 1, 1.0, mode="rgb", org=(W4, H4))
@@ -704,7 +720,10 @@ def main():
                 result["tv_off"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         if extras:
             args.batch_frames = B
+            only = os.environ.get("OFDIS_BENCH_BLOCKS")  # developer switch: comma-separated block names
             for name, fn in BLOCKS:
+                if only and name not in only.split(","):
+                    continue
                 try:
                     result[name] = fn(capi, torch, p, batch, ia, ib, stream, dev, args)
                 except Exception as e:
