@@ -663,6 +663,9 @@ def main():
             if clk:
                 roofline_valu["sustained_clock_ghz"] = clk
                 roofline_valu["frac_at_sustained_clock"] = round(ach / (simds * clk / 2.0), 4)
+                # the rate of a stream that cannot pair (this kernel's: DPP moves and transcendentals): one VALU
+                # instruction per ~4.2 clocks per SIMD (tools/probes/issue_probe.hip, profiles/README.md r02_c)
+                roofline_valu["frac_of_single_issue_rate"] = round(ach / (simds * clk / 4.2), 4)
         result = {
             "metric": "frames/sec at 1024×436 op-point-2 (INT)", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
