@@ -373,11 +373,24 @@ __device__ __forceinline__ f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y *
 __device__ __forceinline__ f2 operator-(f2 a, float b) { return f2{a.x - b, a.y - b}; }
 __device__ __forceinline__ f2 operator*(float a, f2 b) { return f2{a * b.x, a * b.y}; }
 
+#ifndef OFDIS_GRAY8_SWZ
+#define OFDIS_GRAY8_SWZ 0
+#endif
+// quad permutation through the LDS crossbar (ds_swizzle_b32, no LDS memory involved): unlike a DPP move it does not cost
+// the wavefront its paired VALU issue (profiles/README.md "VALU issue model")
+template <int QP>
+__device__ __forceinline__ float quad_swz(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x8000 | QP));
+}
+template <int QP>
+__device__ __forceinline__ float quad_perm(float x) {
+  return OFDIS_GRAY8_SWZ ? quad_swz<QP>(x) : dpp_mov<QP>(x);
+}
 __device__ __forceinline__ float gray8_combine(float c0, float c1) {  // column sums p_2pl, p_2pl+1 of this lane
-  c0 = c0 + dpp_mov<0x4E>(c0);  // lane distance 2 = column distance 4: q_(2pl mod 4)
-  c1 = c1 + dpp_mov<0x4E>(c1);  //                                       q_(2pl mod 4 + 1)
-  float q = c0 + c1;            // lanes 0,2: q0 + q1; lanes 1,3: q2 + q3
-  q = q + dpp_mov<0xB1>(q);     // lane distance 1
+  c0 = c0 + quad_perm<0x4E>(c0);  // lane distance 2 = column distance 4: q_(2pl mod 4)
+  c1 = c1 + quad_perm<0x4E>(c1);  //                                       q_(2pl mod 4 + 1)
+  float q = c0 + c1;              // lanes 0,2: q0 + q1; lanes 1,3: q2 + q3
+  q = q + quad_perm<0xB1>(q);     // lane distance 1
   return q;
 }
 __device__ __forceinline__ float gray8_sum(const f2 (&x)[8]) {

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from of_dis_amd import build as B  # noqa: E402
 
+CSRC = os.environ.get("OFDIS_CSRC", B.CSRC)  # a patched copy of the sources (timing-only experiments stay out of the tree)
 name = sys.argv[1]
 extra = {}
 for a in sys.argv[2:]:
@@ -25,7 +26,7 @@ for src in B.HIP_SOURCES:
     flags = [f for f in B.PER_FILE_FLAGS.get(src, [])] + extra.get(src, [])
     drop = [f[1:] for f in flags if f.startswith("!")]
     flags = [f for f in flags if not f.startswith("!") and f not in drop]
-    subprocess.check_call([B._hipcc()] + B.HIPFLAGS + flags + ["-c", os.path.join(B.CSRC, src), "-o", obj])
+    subprocess.check_call([B._hipcc()] + B.HIPFLAGS + flags + ["-c", os.path.join(CSRC, src), "-o", obj])
     objs.append(obj)
 so = os.path.join(out, "libofdis_hip.so")
 subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)
