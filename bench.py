@@ -117,27 +117,27 @@ def algorithmic_bytes(p, nframes, fused_tv=True):
         out["patch_optimize"] += nframes * (4 * th * tw * noc * 4 + (2 * (w // 2) * (h // 2) * 4 if l < p.sc_f else 0)
                                             + nop * 8 + nop * nv * 4)
         launches["patch_optimize"] += 1
-        fused = p.usetvref and fused_tv and noc == 1 and h <= 64 and w >= 16 and p.tv_solverit <= 3
+        fused = p.usetvref and fused_tv and noc == 1 and 4 <= h <= 64 and 16 <= w <= 128 and p.tv_solverit <= 3
         out["densify"] += nframes * (nop * 8 + nop * nv * 4) + 8 * npx       # p, pweight in; wx, wy out
         launches["densify"] += 1
         if p.usetvref:
             n_inner = p.tv_innerit * (l + 1)
-            if fused and not os.environ.get("OFDIS_NO_WARP_FUSION") and (nframes <= 256 or os.environ.get("OFDIS_FORCE_WARP_FUSION")):
-                # image_warp inside the derivatives kernel: wx,wy + both images in, mask + 8 planes out
-                out["derivatives"] += (8 + 4 + 4 + 4 + 32) * npx
-            else:
-                out["warp"] += (8 + 4 * noc + 4 * noc + 4) * npx      # wx,wy + src once + dst + mask
-                out["derivatives"] += 40 * noc * npx                  # I0,I1w in, 8 planes out
-            if fused:   # system + SOR in one kernel: derivs, mask, wx, wy, du, dv in; du, dv out
-                out["tv_fused"] += n_inner * (32 * noc + 20 + 8) * npx
+            if fused:
+                # image_warp + get_derivatives in one kernel (ofdis_prep.hip): flow + both images in; the derivative
+                # record (32 B, zero where the warp mask is zero) and the (wx, wy) record (8 B) out
+                out["derivatives"] += (8 + 4 + 4 + 32 + 8) * npx
+                # system + SOR, all iterations in one kernel: the three records in, (du, dv) out, per iteration
+                out["tv_fused"] += n_inner * (32 + 8 + 8 + 8) * npx
                 launches["tv_fused"] += 1
             else:
+                out["warp"] += (8 + 4 * noc + 4 * noc + 4) * npx      # wx,wy + src once + dst + mask
+                launches["warp"] += 1
+                out["derivatives"] += 40 * noc * npx                  # I0,I1w in, 8 planes out
                 out["tv_system"] += n_inner * (20 + 32 * noc + 28) * npx  # mask,wx,wy,du,dv + derivs in, 7 planes out
                 out["sor"] += n_inner * 44 * npx                          # 7 planes + du,dv in, du,dv out (3 sweeps fused)
                 launches["tv_system"] += n_inner
                 launches["sor"] += n_inner
             out["tv_finish"] += 24 * npx
-            launches["warp"] += 1
             launches["derivatives"] += 1
             launches["tv_finish"] += 1
     return out, launches
@@ -244,7 +244,7 @@ def kernel_table(capi, torch, batch, p, B, stream, nrep=3):
     for _ in range(nrep):
         batch.run(stream)
     torch.cuda.synchronize()
-    abytes, _ = algorithmic_bytes(p, B, fused_tv=not os.environ.get("OFDIS_NO_FUSED"))
+    abytes, _ = algorithmic_bytes(p, B, fused_tv=bool(capi.get_tuning().fused_tv))
     kernels = {}
     for k, name in enumerate(capi.K_NAMES):
         ms, n = batch.kernel_time(k)

@@ -173,6 +173,32 @@ int ofdis_batch_timing(ofdis_batch* b, int enable);
 int ofdis_batch_kernel_time(ofdis_batch* b, int kernel_class, double* ms_sum, long* launches);
 
 /* ---------------------------------------------------------------------------------------------
+ * Kernel-selection knobs.  Several stages exist in more than one mapping of the SAME arithmetic (every setting gives
+ * bit-identical results); the library picks by geometry and batch size.  The knobs are process-wide, are initialised
+ * ONCE from the environment variables named below at the first call into the library and can be changed at run time
+ * (the parity tests run every mapping; a maintainer can pin one).  A change takes effect at the next ofdis_batch_run /
+ * ofdis_flow; contexts created while fused_tv was 0 stay on the unfused path (they do not own the fused path's buffers),
+ * and a captured launch graph (ofdis_batch_set_graph) is re-captured after a change.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ofdis_tuning {
+  int gray8;          /* 1: gray 8x8 patches use the 4-lanes-per-patch kernel; 0: generic kernel     OFDIS_NO_GRAY8 -> 0 */
+  int rgb12;          /* 1: RGB 12x12 patches use the compile-time instantiations                  OFDIS_NO_RGB12 -> 0 */
+  int rgb12_lpp;      /* lanes per RGB 12x12 patch: 64 (default) or 32 (two patches per wavefront)    OFDIS_RGB12_LPP */
+  int fused_tv;       /* 1: gray levels of <= 64 rows take the fused TV path (prep + fused kernel)   OFDIS_NO_FUSED -> 0 */
+  int fused_mw_max;   /* frame groups up to which the multi-wave fused TV kernels are launched       OFDIS_FUSED_MW_MAX
+                       * (default 512 and at most 1024 frames per batch; 0 = never; >= 2^30 = always) */
+  int fused_split;    /* 1: multi-wave kernel with producer + solver wavefronts per iteration  OFDIS_FUSED_NO_SPLIT -> 0 */
+  int finish_fusion;  /* 1: the multi-wave kernels write the refined flow themselves        OFDIS_NO_FINISH_FUSION -> 0 */
+  int fused_strip;    /* frames per strip of the throughput fused TV kernel; 0 = chosen by the library  OFDIS_FUSED_STRIP */
+  int prep_band_rows; /* output rows per wavefront of the warp + derivatives kernel; 0 = by batch size  OFDIS_PREP_BAND_ROWS */
+  int graph;          /* 1: ofdis_batch_set_graph may replay a captured launch graph                 OFDIS_NO_GRAPH -> 0 */
+  int flow_dma;       /* 1: ofdis_flow stages through hipMemcpyAsync instead of copy kernels               OFDIS_FLOW_DMA */
+  int flow_whole;     /* 1: ofdis_flow uploads the whole pyramid before the first launch                OFDIS_FLOW_WHOLE */
+} ofdis_tuning;
+int ofdis_get_tuning(ofdis_tuning* out);
+int ofdis_set_tuning(const ofdis_tuning* in);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-function entry points (device pointers, batched over `nframes` frames, packed planes
  * [nframes][h][w]).  Each replaces one FDF1.0.1 / PatGrid function; used by the parity tests and
  * available to a maintainer who wants to swap a single stage.

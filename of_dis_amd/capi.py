@@ -31,8 +31,14 @@ ABI_SYMBOLS = [
     "ofdis_batch_level_flow", "ofdis_batch_download", "ofdis_batch_upsample", "ofdis_batch_timing", "ofdis_batch_kernel_time",
     "ofdis_image_warp", "ofdis_get_derivatives", "ofdis_tv_system", "ofdis_sor_coupled", "ofdis_patchgrid_level",
     "ofdis_varref_level", "ofdis_dev_alloc", "ofdis_dev_free", "ofdis_memcpy_h2d", "ofdis_memcpy_d2h", "ofdis_memcpy_d2d", "ofdis_sync",
-    "ofdis_batch_set_graph", "ofdis_flow_cache_clear",
+    "ofdis_batch_set_graph", "ofdis_flow_cache_clear", "ofdis_get_tuning", "ofdis_set_tuning",
 ]
+
+
+class OfdisTuning(C.Structure):
+    """include/ofdis.h: ofdis_tuning -- kernel-selection knobs, every setting bit-identical."""
+    _fields_ = [(n, C.c_int) for n in ("gray8", "rgb12", "rgb12_lpp", "fused_tv", "fused_mw_max", "fused_split",
+                                       "finish_fusion", "fused_strip", "prep_band_rows", "graph", "flow_dma", "flow_whole")]
 
 
 class OfdisError(RuntimeError):
@@ -92,12 +98,8 @@ def lib():
         L.ofdis_batch_initflow_elems.argtypes = [VP]
         L.ofdis_batch_set_initflow.argtypes = [VP, VP]
         L.ofdis_batch_upload_initflow.argtypes = [VP, C.c_int, FP, VP]
-        L.ofdis_test_set_fused_mw_max.argtypes = [C.c_int]
-        L.ofdis_test_set_fused_mw_max.restype = None
-        L.ofdis_test_set_fused_split.argtypes = [C.c_int]
-        L.ofdis_test_set_fused_split.restype = None
-        L.ofdis_test_wave_sum.argtypes = [VP, VP, C.c_int, VP]
-        L.ofdis_test_div_sqrt.argtypes = [VP, VP, VP, C.c_int, VP]
+        L.ofdis_get_tuning.argtypes = [C.POINTER(OfdisTuning)]
+        L.ofdis_set_tuning.argtypes = [C.POINTER(OfdisTuning)]
         _lib = L
     return _lib
 
@@ -105,6 +107,28 @@ def lib():
 def check(rc):
     if rc != 0:
         raise OfdisError(f"ofdis status {rc}: {lib().ofdis_last_error().decode()}")
+
+
+def get_tuning():
+    t = OfdisTuning()
+    check(lib().ofdis_get_tuning(C.byref(t)))
+    return t
+
+
+def set_tuning(**kw):
+    """Change kernel-selection knobs (ofdis_set_tuning); returns the previous settings (pass them to restore_tuning)."""
+    old = get_tuning()
+    new = get_tuning()
+    for k, v in kw.items():
+        setattr(new, k, v)
+    check(lib().ofdis_set_tuning(C.byref(new)))
+    lib().ofdis_flow_cache_clear()  # cached drop-in contexts were sized under the old settings
+    return old
+
+
+def restore_tuning(old):
+    check(lib().ofdis_set_tuning(C.byref(old)))
+    lib().ofdis_flow_cache_clear()
 
 
 class Dev:
@@ -234,24 +258,6 @@ def flow(p, pyr_a, pyr_a_dx, pyr_a_dy, pyr_b, initflow=None, pyr_b_dx=None, pyr_
                            _ptr_array(keep[3], n), bdx, bdy, out.ctypes.data_as(FP),
                            _f(initflow).ctypes.data_as(FP) if initflow is not None else None))
     return out
-
-
-def wave_sum_test(x):
-    x = _f(x)
-    d, o = Dev(x), Dev(nbytes=x.nbytes)
-    check(lib().ofdis_test_wave_sum(d.ptr, o.ptr, x.size, None))
-    check(lib().ofdis_sync(None))
-    return o.get(x.shape)
-
-
-def div_sqrt_test(a, b):
-    """Rows: div_rn(a,b), a/b, sqrt_rn(|a|), sqrtf(|a|), the quotient through rcp_newton, rcp_newton(b), sqrt_newton(|a|),
-    b / sqrt(|a|) through rcp_from, computed on the device (ofdis_dev.h)."""
-    a, b = _f(a), _f(b)
-    da, db, o = Dev(a), Dev(b), Dev(nbytes=8 * a.nbytes)
-    check(lib().ofdis_test_div_sqrt(da.ptr, db.ptr, o.ptr, a.size, None))
-    check(lib().ofdis_sync(None))
-    return o.get((8, a.size))
 
 
 class Batch:

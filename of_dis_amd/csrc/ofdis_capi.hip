@@ -12,9 +12,51 @@
 #include <string>
 #include <vector>
 
+// the library is compiled with -fvisibility=hidden: what include/ofdis.h declares is the whole export list
+#pragma GCC visibility push(default)
+#include "../../include/ofdis.h"
+#pragma GCC visibility pop
 #include "ofdis_kernels.h"
 
 using namespace ofdis;
+
+namespace ofdis {
+
+// Kernel-selection knobs (include/ofdis.h: ofdis_tuning): read ONCE from the environment, changed only through
+// ofdis_set_tuning; every launch path takes a snapshot (no getenv on the dispatch path).
+namespace {
+std::mutex g_tuning_mutex;
+ofdis_tuning g_tuning;
+bool g_tuning_init = false;
+unsigned g_tuning_epoch = 0;
+void tuning_init_locked() {
+  if (g_tuning_init) return;
+  auto on = [](const char* name) { return getenv(name) != nullptr; };
+  auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+  g_tuning.gray8 = !on("OFDIS_NO_GRAY8");
+  g_tuning.rgb12 = !on("OFDIS_NO_RGB12");
+  g_tuning.rgb12_lpp = num("OFDIS_RGB12_LPP", 64) == 32 ? 32 : 64;
+  g_tuning.fused_tv = !on("OFDIS_NO_FUSED");
+  g_tuning.fused_mw_max = std::max(0, num("OFDIS_FUSED_MW_MAX", 512));
+  g_tuning.fused_split = !on("OFDIS_FUSED_NO_SPLIT");
+  g_tuning.finish_fusion = !on("OFDIS_NO_FINISH_FUSION");
+  g_tuning.fused_strip = std::max(0, num("OFDIS_FUSED_STRIP", 0));
+  g_tuning.prep_band_rows = std::max(0, num("OFDIS_PREP_BAND_ROWS", 0));
+  g_tuning.graph = !on("OFDIS_NO_GRAPH");
+  g_tuning.flow_dma = on("OFDIS_FLOW_DMA");
+  g_tuning.flow_whole = on("OFDIS_FLOW_WHOLE");
+  g_tuning_init = true;
+}
+}  // namespace
+
+ofdis_tuning tuning(unsigned* epoch) {
+  std::lock_guard<std::mutex> lock(g_tuning_mutex);
+  tuning_init_locked();
+  if (epoch) *epoch = g_tuning_epoch;
+  return g_tuning;
+}
+
+}  // namespace ofdis
 
 namespace {
 
@@ -130,7 +172,8 @@ struct ofdis_batch {
   float *pvec = nullptr, *pweight = nullptr;
   float *wx = nullptr, *wy = nullptr, *du = nullptr, *dv = nullptr, *mask = nullptr;
   float *w_im2 = nullptr, *derivs = nullptr, *sys = nullptr;
-  float *wx_d = nullptr, *wy_d = nullptr, *mask_d = nullptr;  // diag-layout copies for the fused TV kernel
+  float *wrec = nullptr, *uv = nullptr;  // fused TV path: the (wx, wy) and (du, dv) records; `derivs` holds the
+                                         // derivative records there (ofdis_dev.h: sdiag_index)
   std::vector<float*> pyr_tmp;       // unpadded level images (ofdis_batch_build_pyramids_u8), lazily allocated
   // device memory: requests are collected (dalloc) and served from ONE hipMalloc per commit (dcommit) -- a context is
   // one allocation (two with the u8 pyramid scratch), and the input planes form one contiguous region [in_base,
@@ -145,6 +188,7 @@ struct ofdis_batch {
   long runs = 0;                         // un-pipelined passes so far
   hipGraphExec_t graph_exec = nullptr;
   const float* graph_initflow = nullptr; // the warm-start pointer the captured graph was built with
+  unsigned graph_epoch = 0;              // ... and the state of the kernel-selection knobs (ofdis_set_tuning)
   hipStream_t cap_stream = nullptr;      // capture stream
   // sub-batches on internal streams (ofdis_batch_run)
   std::vector<hipStream_t> sub_streams;  // streams of sub-batches 1..S-1 (sub-batch 0 runs on the caller's stream)
@@ -239,12 +283,24 @@ TvConsts tv_consts(float alpha, float gamma, float delta) {  // refine_variation
   return c;
 }
 
-// VarRefClass for one level, all frames (refine_variational.cpp:25-241).  wx/wy hold the dense flow
-// (planar, row-major; plus diag copies in wx_d/wy_d when the fused kernel is used) on entry; the refined
-// flow is written AoS to flow_out.
+// Frames per strip of the throughput fused TV kernel: the largest of 8, 4, 2 that divides the frame count and still
+// leaves two wavefronts per SIMD (2048 strips groups per launch), else 1; ofdis_tuning::fused_strip overrides.
+int strip_length(const ofdis_batch* b, const LevelGeom& g, const ofdis_tuning& tn) {
+  const int n = b->nframes;
+  if (tn.fused_strip > 0) return (n % tn.fused_strip == 0) ? tn.fused_strip : 1;
+  const int R = g.h <= 16 ? 16 : (g.h <= 32 ? 32 : 64);
+  for (int S = 8; S > 1; S >>= 1)
+    if (n % S == 0 && (n / S) / (64 / R) >= 2048) return S;
+  return 1;
+}
+
+// VarRefClass for one level, all frames (refine_variational.cpp:25-241).  Unfused path: wx/wy hold the dense flow (planar,
+// row-major) on entry.  Fused path (gray, <= 64 rows): flow_out itself holds the densified flow (AoS) on entry.  Either
+// way the refined flow is in flow_out (AoS) on return.
 bool use_fused(const ofdis_batch* b, const LevelGeom& g) {
   const TvConsts c = tv_consts(b->p.tv_alpha, b->p.tv_gamma, b->p.tv_delta);
-  return b->wx_d && tv_fused_supported(TvGeom{g.w, g.h, g.noc, b->nframes}, b->p.tv_solverit) &&
+  const TvGeom t{g.w, g.h, g.noc, b->nframes};
+  return b->wrec && tuning().fused_tv && tv_fused_supported(t, b->p.tv_solverit) && tv_prep_supported(t) &&
          tv_fused_params_ok(c.quarter_alpha, c.half_delta_over3, c.half_gamma_over3);
 }
 
@@ -255,50 +311,41 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
   const size_t npx = (size_t)g.w * g.h;
   const int n_inner = p.tv_innerit * (g.level + 1);  // :36
   const TvConsts c = tv_consts(p.tv_alpha, p.tv_gamma, p.tv_delta);
-  const bool fused = use_fused(b, g);
-  // fused path: image_warp runs inside the derivatives kernel (no warped image in memory, one launch less);
-  // OFDIS_NO_WARP_FUSION keeps the two kernels apart (A/B and the test of the stand-alone diag warp kernel)
-  // Only for small batches: a launch and a round trip less where launches dominate (64 pairs: -2 % per pass); on large
-  // batches warping the halo in every tile costs more than the round trip (4096 pairs: derivatives 0.53 + warp 0.26 ms
-  // apart, 1.00 ms fused).
-  const bool no_warp_fusion = getenv("OFDIS_NO_WARP_FUSION") != nullptr;       // (read per call: the tests toggle them)
-  const bool force_warp_fusion = getenv("OFDIS_FORCE_WARP_FUSION") != nullptr;
-  const bool warp_in_deriv = fused && !no_warp_fusion && (b->nframes <= 256 || force_warp_fusion);
-  if (!warp_in_deriv) {
-    KTimer kt(b, OFDIS_K_WARP, s);
-    if (fused) {  // wx_d, wy_d in, mask_d out (diag); the warped image stays row-major
-      WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx_d, b->wy_d, b->w_im2, b->mask_d};
-      HIPCHK(launch_warp_diag(wa, s));
-    } else {
-      WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx, b->wy, b->w_im2, b->mask};
-      HIPCHK(launch_warp(wa, s));
+  if (use_fused(b, g)) {
+    if (n_inner <= 0) return OFDIS_OK;  // du = dv = 0: the flow stays what it is
+    const ofdis_tuning tn = tuning();
+    FusedArgs fa{t, b->derivs, b->wrec, b->uv, 1, c.quarter_alpha, c.half_delta_over3, c.half_gamma_over3, p.tv_solverit,
+                 p.tv_sor, n_inner, b->total_frames, tn.finish_fusion ? flow_out : nullptr, tn.fused_mw_max, tn.fused_split};
+    if (tv_fused_mode(fa) == 0) fa.S = strip_length(b, g, tn);  // strips: throughput mapping only
+    {  // image_warp + get_derivatives (refine_variational.cpp:189-190): one kernel, records out
+      KTimer kt(b, OFDIS_K_DERIV, s);
+      PrepArgs pa{t, im_a, im_b, g.pad, g.tmp_w, g.tmp_h, flow_out, b->derivs, b->wrec, fa.S, tn.prep_band_rows};
+      HIPCHK(launch_tv_prep(pa, s));
     }
+    bool flow_written = false;  // the multi-wave variants of the fused kernel write the refined AoS flow themselves
+    {  // every fixed-point iteration of this level in one launch (du = dv = 0 on its first pass: no memset)
+      KTimer kt(b, OFDIS_K_FUSED, s);
+      HIPCHK(launch_tv_fused(fa, s, &flow_written));
+    }
+    if (!flow_written) {
+      KTimer kt(b, OFDIS_K_UPDATE, s);
+      HIPCHK(launch_tv_finish_records(t, flow_out, b->uv, fa.S, s));
+    }
+    return OFDIS_OK;
+  }
+  {
+    KTimer kt(b, OFDIS_K_WARP, s);
+    WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx, b->wy, b->w_im2, b->mask};
+    HIPCHK(launch_warp(wa, s));
   }
   {
     KTimer kt(b, OFDIS_K_DERIV, s);
-    DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs, fused ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (warp_in_deriv) {
-      da.im2w = nullptr;
-      da.warp_src = im_b;
-      da.wx_diag = b->wx_d;
-      da.wy_diag = b->wy_d;
-      da.mask_diag = b->mask_d;
-    }
+    DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs};
     HIPCHK(launch_derivatives(da, s));
   }
-  if (!fused || n_inner <= 0) {  // image_erase :186-187 (the fused kernel treats its first pass as du = dv = 0 itself)
-    HIPCHK(hipMemsetAsync(b->du, 0, npx * b->nframes * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(b->dv, 0, npx * b->nframes * sizeof(float), s));
-  }
-  bool flow_written = false;  // the multi-wave variants of the fused kernel write the refined AoS flow themselves
-  if (fused && n_inner > 0) {  // every fixed-point iteration of this level in one launch
-    KTimer kt(b, OFDIS_K_FUSED, s);
-    FusedArgs fa{t, b->derivs, b->mask_d, b->wx_d, b->wy_d, b->du, b->dv, c.quarter_alpha, c.half_delta_over3,
-                 c.half_gamma_over3, p.tv_solverit, p.tv_sor, n_inner, b->total_frames,
-                 getenv("OFDIS_NO_FINISH_FUSION") ? nullptr : flow_out};
-    HIPCHK(launch_tv_fused(fa, s, &flow_written));
-  }
-  for (int it = 0; it < n_inner && !fused; ++it) {
+  HIPCHK(hipMemsetAsync(b->du, 0, npx * b->nframes * sizeof(float), s));  // image_erase :186-187
+  HIPCHK(hipMemsetAsync(b->dv, 0, npx * b->nframes * sizeof(float), s));
+  for (int it = 0; it < n_inner; ++it) {
     {
       KTimer kt(b, OFDIS_K_SYSTEM, s);
       SystemArgs sa{t, b->mask, b->wx, b->wy, b->du, b->dv, b->derivs, c.quarter_alpha, c.half_delta_over3,
@@ -311,12 +358,9 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
       HIPCHK(launch_sor(so, s));
     }
   }
-  if (!flow_written) {
+  {
     KTimer kt(b, OFDIS_K_UPDATE, s);
-    if (fused)
-      HIPCHK(launch_tv_finish(t, b->wx_d, b->wy_d, b->du, b->dv, flow_out, 1, s));
-    else
-      HIPCHK(launch_tv_finish(t, b->wx, b->wy, b->du, b->dv, flow_out, 0, s));
+    HIPCHK(launch_tv_finish(t, b->wx, b->wy, b->du, b->dv, flow_out, s));
   }
   return OFDIS_OK;
 }
@@ -337,7 +381,7 @@ int run_varref_de(ofdis_batch* b, const LevelGeom& g, const float* im_a, const f
   }
   {
     KTimer kt(b, OFDIS_K_DERIV, s);
-    DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs};
     HIPCHK(launch_derivatives(da, s));
   }
   HIPCHK(hipMemsetAsync(b->du, 0, n * sizeof(float), s));                                    // image_erase(du)
@@ -367,11 +411,7 @@ int run_varref_de(ofdis_batch* b, const LevelGeom& g, const float* im_a, const f
 int run_varref_from_aos(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow,
                         hipStream_t s) {
   TvGeom t{g.w, g.h, g.noc, b->nframes};
-  HIPCHK(launch_flow_split(t, flow, b->wx, b->wy, s));
-  if (use_fused(b, g)) {
-    HIPCHK(launch_to_diag(b->wx, b->wx_d, g.w, g.h, b->nframes, s));
-    HIPCHK(launch_to_diag(b->wy, b->wy_d, g.w, g.h, b->nframes, s));
-  }
+  if (!use_fused(b, g)) HIPCHK(launch_flow_split(t, flow, b->wx, b->wy, s));  // (the fused path starts from the AoS flow)
   return run_varref(b, g, im_a, im_b, flow, s);
 }
 
@@ -470,10 +510,9 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
     if (!rc) rc = dalloc(b, &b->derivs, npx * 8 * p->noc);
     if (!rc) rc = dalloc(b, &b->sys, npx * 7);
     if (!rc && p->selectmode == 2) rc = dalloc(b, &b->uu, npx);
-    if (!rc && p->noc == 1 && p->selectmode != 2 && !getenv("OFDIS_NO_FUSED")) {
-      rc = dalloc(b, &b->wx_d, npx);
-      if (!rc) rc = dalloc(b, &b->wy_d, npx);
-      if (!rc) rc = dalloc(b, &b->mask_d, npx);
+    if (!rc && p->noc == 1 && p->selectmode != 2 && tuning().fused_tv) {
+      rc = dalloc(b, &b->wrec, npx * 2);
+      if (!rc) rc = dalloc(b, &b->uv, npx * 2);
     }
   }
   if (!rc) rc = dcommit(b);
@@ -619,7 +658,7 @@ ofdis_batch frame_view(const ofdis_batch& b, int f0, int n) {
   off(v.pvec_bw, nop_max * 2); off(v.pweight_bw, nop_max * g0.novals);
   off(v.wx, npx); off(v.wy, npx); off(v.du, npx); off(v.dv, npx); off(v.mask, npx); off(v.uu, npx);
   off(v.w_im2, npx * b.p.noc); off(v.derivs, npx * 8 * b.p.noc); off(v.sys, npx * 7);
-  off(v.wx_d, npx); off(v.wy_d, npx); off(v.mask_d, npx);
+  off(v.wrec, npx * 2); off(v.uv, npx * 2);
   return v;
 }
 
@@ -778,7 +817,7 @@ int run_one_level(ofdis_batch* b, int sl, hipStream_t s) {
         d.cg_pweight = dir ? b->pweight : b->pweight_bw;
       }
       if (p.usetvref && dir == 0) {
-        if (use_fused(b, g)) { d.wx_diag = b->wx_d; d.wy_diag = b->wy_d; }  // diag only
+        if (use_fused(b, g)) d.flow_aos = b->flow[ii];  // the fused TV path refines the AoS flow in place
         else { d.wx = b->wx; d.wy = b->wy; }
       } else if (p.usetvref) {  // backward flow: parked as AoS until the forward refinement has used the planes
         d.flow_aos = b->flow_bw[ii];
@@ -825,11 +864,12 @@ int run_one_level(ofdis_batch* b, int sl, hipStream_t s) {
 // (they synchronise between stages), in pipelined mode (the sub-batches are deliberately not joined), with
 // OFDIS_NO_GRAPH, or after a capture failure -- the direct launches are always the fallback.
 int run_graph_or_levels(ofdis_batch* b, hipStream_t s) {
-  static const bool env_off = getenv("OFDIS_NO_GRAPH") != nullptr;
+  unsigned epoch = 0;
+  const bool env_off = !tuning(&epoch).graph;
   const bool want = b->graph_mode != 0 && !env_off && !b->timing && b->p.verbosity == 0 && (b->graph_mode == 1 || b->runs >= 1);
   b->runs++;
   if (!want) return run_levels(b, s);
-  if (b->graph_exec && b->graph_initflow != b->initflow) {
+  if (b->graph_exec && (b->graph_initflow != b->initflow || b->graph_epoch != epoch)) {  // the knobs are baked into the capture
     (void)hipGraphExecDestroy(b->graph_exec);
     b->graph_exec = nullptr;
   }
@@ -854,6 +894,7 @@ int run_graph_or_levels(ofdis_batch* b, hipStream_t s) {
       return run_levels(b, s);
     }
     b->graph_initflow = b->initflow;
+    b->graph_epoch = epoch;
   }
   HIPCHK(hipGraphLaunch(b->graph_exec, s));
   return OFDIS_OK;
@@ -1052,7 +1093,8 @@ int ofdis_flow(const ofdis_params* p, const float* const* im_a, const float* con
   } else {
     b->initflow = nullptr;  // a previous call on this context may have warm-started
   }
-  static const bool use_dma = getenv("OFDIS_FLOW_DMA") != nullptr;
+  const ofdis_tuning tn = tuning();
+  const bool use_dma = tn.flow_dma != 0;
   auto stage_level = [&](int l) -> int {
     const int i = l - p->sc_l;
     for (int k = 0; k < nin; ++k)
@@ -1065,7 +1107,7 @@ int ofdis_flow(const ofdis_params* p, const float* const* im_a, const float* con
     else HIPCHK(launch_copy16(lo, c->stage + (lo - b->in_base), bytes, c->s));
     return OFDIS_OK;
   };
-  if (p->verbosity == 0 && !getenv("OFDIS_FLOW_WHOLE")) {
+  if (p->verbosity == 0 && !tn.flow_whole) {
     for (int l = p->sc_f; l >= p->sc_l && !rc; --l) {
       rc = stage_level(l);
       if (!rc) rc = run_one_level(b, l, c->s);
@@ -1095,7 +1137,7 @@ int ofdis_image_warp(float* dst, float* mask, const float* src, const float* wx,
 int ofdis_get_derivatives(float* out, const float* im1, const float* im2w, int w, int h, int noc, int nframes,
                           void* stream) {
   if (!out || !im1 || !im2w || w < 1 || h < 4 || nframes < 1) return fail(OFDIS_ERR_INVALID, "bad arguments (need h >= 4)");
-  DerivArgs a{TvGeom{w, h, noc, nframes}, im1, 0, 0, 0, 0, im2w, out, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+  DerivArgs a{TvGeom{w, h, noc, nframes}, im1, 0, 0, 0, 0, im2w, out};
   HIPCHK(launch_derivatives(a, (hipStream_t)stream));
   return OFDIS_OK;
 }
@@ -1208,13 +1250,13 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   if (!rc) rc = dalloc(&b, &b.derivs, npx * 8 * p->noc);
   if (!rc) rc = dalloc(&b, &b.sys, npx * 7);
   const TvConsts tc = tv_consts(p->tv_alpha, p->tv_gamma, p->tv_delta);
-  const bool want_fused = p->noc == 1 && p->selectmode != 2 && !getenv("OFDIS_NO_FUSED") &&
+  const bool want_fused = p->noc == 1 && p->selectmode != 2 && tuning().fused_tv &&
                           tv_fused_supported(TvGeom{g.w, g.h, g.noc, nframes}, p->tv_solverit) &&
+                          tv_prep_supported(TvGeom{g.w, g.h, g.noc, nframes}) &&
                           tv_fused_params_ok(tc.quarter_alpha, tc.half_delta_over3, tc.half_gamma_over3);
   if (!rc && want_fused) {
-    rc = dalloc(&b, &b.wx_d, npx);
-    if (!rc) rc = dalloc(&b, &b.wy_d, npx);
-    if (!rc) rc = dalloc(&b, &b.mask_d, npx);
+    rc = dalloc(&b, &b.wrec, npx * 2);
+    if (!rc) rc = dalloc(&b, &b.uv, npx * 2);
   }
   if (!rc && p->selectmode == 2) rc = dalloc(&b, &b.uu, npx);
   if (!rc) rc = dcommit(&b);
@@ -1225,11 +1267,9 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
     if (e != hipSuccess) rc = hipfail(e, "stereo flow copy");
     if (!rc) rc = run_varref_de(&b, g, im_a, im_b, flow, s);
   } else {
-    if (!rc) {
+    if (!rc && !want_fused) {  // (the fused path starts from the AoS flow)
       TvGeom t{g.w, g.h, g.noc, nframes};
       hipError_t e = launch_flow_split(t, flow, b.wx, b.wy, s);
-      if (e == hipSuccess && want_fused) e = launch_to_diag(b.wx, b.wx_d, g.w, g.h, nframes, s);
-      if (e == hipSuccess && want_fused) e = launch_to_diag(b.wy, b.wy_d, g.w, g.h, nframes, s);
       if (e != hipSuccess) rc = hipfail(e, "flow_split");
     }
     if (!rc) rc = run_varref(&b, g, im_a, im_b, flow, s);
@@ -1241,23 +1281,20 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   return rc;
 }
 
-// test hook (not declared in ofdis.h): wave_sum over groups of 64
-int ofdis_test_wave_sum(const float* in, float* out, int n, void* stream) {
-  HIPCHK(launch_wave_sum_test(in, out, n, (hipStream_t)stream));
+// ------------------------------------------------------------------------------------ kernel-selection knobs
+int ofdis_get_tuning(ofdis_tuning* out) {
+  if (!out) return fail(OFDIS_ERR_INVALID, "out is NULL");
+  *out = ofdis::tuning();
   return OFDIS_OK;
 }
-
-// test hook (not declared in ofdis.h; host only, needs no GPU): the squared outlier threshold of the patch kernels
-float ofdis_test_outlier_sq(float t) { return outlier_sq_threshold(t); }
-
-// test hook (not declared in ofdis.h): frame-group limit of the multi-wave fused TV kernels (0 = single-wave kernel only,
-// large = multi-wave whenever the iteration count allows, < 0 = default)
-void ofdis_test_set_fused_mw_max(int waves) { set_tv_fused_mw_max(waves); }
-void ofdis_test_set_fused_split(int on) { set_tv_fused_split(on); }
-
-// test hook (not declared in ofdis.h): trimmed divide / sqrt next to the compiler's IEEE expansion
-int ofdis_test_div_sqrt(const float* a, const float* b, float* out, int n, void* stream) {
-  HIPCHK(launch_div_sqrt_test(a, b, out, n, (hipStream_t)stream));
+int ofdis_set_tuning(const ofdis_tuning* in) {
+  if (!in) return fail(OFDIS_ERR_INVALID, "tuning is NULL");
+  if (in->rgb12_lpp != 64 && in->rgb12_lpp != 32) return fail(OFDIS_ERR_INVALID, "rgb12_lpp must be 64 or 32");
+  if (in->fused_mw_max < 0 || in->fused_strip < 0 || in->prep_band_rows < 0) return fail(OFDIS_ERR_INVALID, "negative knob");
+  ofdis::tuning();  // initialise from the environment first
+  std::lock_guard<std::mutex> lock(ofdis::g_tuning_mutex);
+  ofdis::g_tuning = *in;
+  ++ofdis::g_tuning_epoch;
   return OFDIS_OK;
 }
 

@@ -4,6 +4,7 @@
 // -ffp-contract=off), IEEE divide/sqrt (hipcc default), reference operation order.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "../../include/ofdis.h"
@@ -40,14 +41,6 @@ __device__ __forceinline__ float dpp_mov0(float x) {
 // lane l <- lane l-1 (lane 0 keeps `old`); lane l <- lane l+1 (lane 63 keeps `old`)
 __device__ __forceinline__ float wave_from_prev(float x) { return dpp_mov0<0x138>(x); }  // wave_shr:1, lane 0 <- 0
 __device__ __forceinline__ float wave_from_next(float x) { return dpp_mov0<0x130>(x); }  // wave_shl:1, lane 63 <- 0
-
-// The same lane shifts through the LDS crossbar (ds_bpermute_b32; no LDS memory involved).  On gfx950 every DPP (and SDWA,
-// v_permlane*, v_readlane, transcendental, packed-fp32, mad24) instruction drops the issuing wavefront out of the 2-clock
-// VALU issue rate for the next ~50-100 instructions (profiles/README.md "VALU issue model"); ds_bpermute does not.
-// byte address = 4 * source lane; the shift wraps around (lane 0 <- lane 63) instead of filling with zero.
-__device__ __forceinline__ float lane_read(float x, int byte_addr) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, x)));
-}
 
 // 64-lane butterfly all-reduce.  Order of the additions (this IS the documented reduction order,
 // mirrored by oracle/eigen_shim -DOFDIS_SHIM_WAVE64 and oracle_set_reduce_order(1)):
@@ -107,65 +100,6 @@ __device__ __forceinline__ float rcp_refined(float b) {
   const float e = __builtin_fmaf(-b, r0, 1.0f);
   return __builtin_fmaf(e, r0, r0);
 }
-// Reciprocal and square root without a transcendental instruction (v_rcp_f32 / v_sqrt_f32 are among the instructions that
-// cost a wavefront its 2-clock issue rate, see lane_read; in the fused TV kernel's stream a v_sqrt_f32 costs ~120 clocks
-// where the 20 plain instructions below cost ~45).
-//   rcp_newton(b):  integer seed (relative error <= 5.1 %) and four Newton steps, the last two at rounding level: the
-//                   correctly rounded 1/b except when 1/b lies within ~2^-47 of a rounding boundary (measured: 2e-7 of
-//                   random operands, then 1 ulp off) -- the quality of v_rcp_f32 + one Newton step (rcp_refined), which
-//                   is what the quotient sequences below are specified for.  The one systematic exception of the Newton
-//                   step, a denominator whose significand is all ones (the step ties to even, downwards), is patched by
-//                   the integer increment at the end (Markstein: with the correctly rounded reciprocal the final quotient
-//                   step is exact for every numerator; 1.0f / 1.9999999f is the counter-example without the patch).
-//                   b normal, 2^-120 <= |b| <= 2^120, either sign.  nb = -b.
-//   rcp_from(b, nb, y): the same from a seed y with relative error <= 1e-4 (two steps).
-//   sqrt_newton(x, y): correctly rounded sqrt(x) for normal x >= 2^-96: integer seed of 1/sqrt(x) (3.4 %), two Newton steps
-//                   (4.7e-6), s = x*y corrected once (error 2e-11 before rounding), then the same +-1 ulp residual
-//                   selection as sqrt_rn.  y returns the 1/sqrt(x) estimate: the seed of the reciprocal that always
-//                   follows a square root in the TV system (quotients by a norm).
-__device__ __forceinline__ float rcp_allones_patch(float r, float b) {
-  const int bi = __builtin_bit_cast(int, b);
-  return __builtin_bit_cast(float, __builtin_bit_cast(int, r) + ((bi & 0x7fffff) == 0x7fffff ? 1 : 0));
-}
-__device__ __forceinline__ float rcp_from(float b, float nb, float y) {
-  float r = y;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float e = __builtin_fmaf(nb, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-  }
-  return rcp_allones_patch(r, b);
-}
-__device__ __forceinline__ float rcp_newton(float b, float nb) {
-  float r = __builtin_bit_cast(float, 0x7EF31000 - __builtin_bit_cast(int, b));
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float e = __builtin_fmaf(nb, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-  }
-  return rcp_from(b, nb, r);
-}
-__device__ __forceinline__ float sqrt_newton(float x, float& y_out) {
-  float y = __builtin_bit_cast(float, 0x5f376400 - (__builtin_bit_cast(int, x) >> 1));
-  const float h = 0.5f * x;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float t = y * y;
-    const float u = __builtin_fmaf(-h, t, 1.5f);
-    y = y * u;
-  }
-  float s = x * y;
-  const float e = __builtin_fmaf(-s, s, x);
-  s = __builtin_fmaf(e, 0.5f * y, s);
-  const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
-  const float su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
-  const float ed = __builtin_fmaf(-sd, s, x);
-  const float eu = __builtin_fmaf(-su, s, x);
-  float r = (ed <= 0.0f) ? sd : s;
-  r = (eu > 0.0f) ? su : r;
-  y_out = y;
-  return r;
-}
 __device__ __forceinline__ float div_by(float a, float b, float r) {
   float q = a * r;
   float e = __builtin_fmaf(-b, q, a);
@@ -200,6 +134,16 @@ __device__ __forceinline__ float sqrt_rn(float x) {
   return r;
 }
 
+// norm > outlierthresh (patch.cpp:199) is tested on the SQUARED norm: sqrt is monotonic and correctly rounded, so
+// sqrtf(x) > t  <=>  x > X with X = the largest float whose square root rounds to <= t (host sqrtf is correctly rounded)
+inline float outlier_sq_threshold(float t) {
+  if (!(t >= 0.0f) || !isfinite(t)) return t;  // NaN / negative / inf: keep the comparison's outcome (never / always / never)
+  float x = t * t;
+  while (x > 0.0f && sqrtf(x) > t) x = nextafterf(x, 0.0f);
+  while (sqrtf(nextafterf(x, INFINITY)) <= t) x = nextafterf(x, INFINITY);
+  return x;
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // "diag" plane layout used for the SOR solver's operands (7 system planes, du, dv): pixel (x,y) of a
@@ -213,6 +157,20 @@ __host__ __device__ __forceinline__ int diag_index(int x, int y, int w, int h) {
   if (d >= w) d -= w;
   if (d >= w) d %= w;
   return d * h + y;
+}
+
+// "sdiag" record layout of the fused TV path (ofdis_prep.hip writes it, ofdis_fused.hip walks it): S consecutive frames form
+// a STRIP, laid side by side as one image of S*w columns; pixel (x, y) of the strip's frame fs lives in diag row
+// d = (fs*w + x + y) mod (S*w), slot y -- every wrapped anti-diagonal of the strip is one contiguous row of h records, and a
+// wavefront whose lane j handles column t - j at step t reads / writes exactly one such row per step.  S = 1 is the plain
+// per-frame diag layout above.  The index is in records; a record is 8 floats (derivatives), 3 (wx, wy, mask) or 2 (du, dv).
+__host__ __device__ __forceinline__ size_t sdiag_index(int frame, int x, int y, int w, int h, int S) {
+  const int sg = frame / S, fs = frame - sg * S;
+  const int rw = S * w;
+  int d = fs * w + x + y;
+  if (d >= rw) d -= rw;
+  if (d >= rw) d %= rw;  // h > S*w only
+  return ((size_t)sg * rw + d) * h + y;
 }
 
 // Blocks of one frame stay on one XCD: the dispatcher places block n on XCD n % 8 (observed, used for L2

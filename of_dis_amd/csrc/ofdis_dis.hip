@@ -373,24 +373,12 @@ __device__ __forceinline__ f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y *
 __device__ __forceinline__ f2 operator-(f2 a, float b) { return f2{a.x - b, a.y - b}; }
 __device__ __forceinline__ f2 operator*(float a, f2 b) { return f2{a * b.x, a * b.y}; }
 
-#ifndef OFDIS_GRAY8_SWZ
-#define OFDIS_GRAY8_SWZ 0
-#endif
-// quad permutation through the LDS crossbar (ds_swizzle_b32, no LDS memory involved): unlike a DPP move it does not cost
-// the wavefront its paired VALU issue (profiles/README.md "VALU issue model")
-template <int QP>
-__device__ __forceinline__ float quad_swz(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x8000 | QP));
-}
-template <int QP>
-__device__ __forceinline__ float quad_perm(float x) {
-  return OFDIS_GRAY8_SWZ ? quad_swz<QP>(x) : dpp_mov<QP>(x);
-}
 __device__ __forceinline__ float gray8_combine(float c0, float c1) {  // column sums p_2pl, p_2pl+1 of this lane
-  c0 = c0 + quad_perm<0x4E>(c0);  // lane distance 2 = column distance 4: q_(2pl mod 4)
-  c1 = c1 + quad_perm<0x4E>(c1);  //                                       q_(2pl mod 4 + 1)
-  float q = c0 + c1;              // lanes 0,2: q0 + q1; lanes 1,3: q2 + q3
-  q = q + quad_perm<0xB1>(q);     // lane distance 1
+  // (the same exchanges through the LDS crossbar, ds_swizzle_b32, measured the same kernel time: profiles/README.md r03_a)
+  c0 = c0 + dpp_mov<0x4E>(c0);  // lane distance 2 = column distance 4: q_(2pl mod 4)
+  c1 = c1 + dpp_mov<0x4E>(c1);  //                                       q_(2pl mod 4 + 1)
+  float q = c0 + c1;            // lanes 0,2: q0 + q1; lanes 1,3: q2 + q3
+  q = q + dpp_mov<0xB1>(q);     // lane distance 1
   return q;
 }
 __device__ __forceinline__ float gray8_sum(const f2 (&x)[8]) {
@@ -614,26 +602,18 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
   }
 }
 
-float outlier_sq_threshold(float t) {
-  if (!(t >= 0.0f) || !isfinite(t)) return t;  // NaN / negative / inf: keep the comparison's outcome (never / always / never)
-  float x = t * t;
-  while (x > 0.0f && sqrtf(x) > t) x = nextafterf(x, 0.0f);
-  while (sqrtf(nextafterf(x, INFINITY)) <= t) x = nextafterf(x, INFINITY);
-  return x;
-}
-
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   const int M = (a.g.novals + 63) / 64;
   const bool full = a.g.novals == 64 * M;
-  const bool gray8 = a.g.noc == 1 && a.g.P == 8 && !a.stereo && !getenv("OFDIS_NO_GRAY8");
-  // RGB 12x12 (operating points 3 and 4, BASELINE configs[3]): 432 entries, 6 full groups of 64 + 48.  OFDIS_RGB12_LPP=32:
+  const ofdis_tuning tn = tuning();
+  const bool gray8 = a.g.noc == 1 && a.g.P == 8 && !a.stereo && tn.gray8;
+  // RGB 12x12 (operating points 3 and 4, BASELINE configs[3]): 432 entries, 6 full groups of 64 + 48.  ofdis_tuning::rgb12_lpp = 32:
   // two patches per wavefront (the scalar solve, predicates and every reduction instruction shared by two patches:
   // 929 -> 705 instructions per patch and iteration, 82 -> 127 VGPRs).  Measured on configs[3] the same 19.6 +- 0.4 ms per
   // 16-pair level-1 launch either way -- patches that reset early leave their wavefront's other half running alone
   // (PMC: 18 % fewer VALU instructions, same time) -- so one patch per wavefront stays the default.
-  const char* const lpp_env = getenv("OFDIS_RGB12_LPP");
-  const int rgb12_lpp = lpp_env ? atoi(lpp_env) : 64;
-  const bool rgb12 = a.g.novals == 432 && !a.stereo && (a.costfct == 0 || a.costfct == 1) && !getenv("OFDIS_NO_RGB12");
+  const int rgb12_lpp = tn.rgb12_lpp;
+  const bool rgb12 = a.g.novals == 432 && !a.stereo && (a.costfct == 0 || a.costfct == 1) && tn.rgb12;
   const int lpp = (M <= 1) ? (gray8 ? 4 : 8) : ((rgb12 && rgb12_lpp == 32) ? 32 : 64);  // lanes per patch
   const int ppw = 64 / lpp;                           // patches per wavefront
   const int wpf = (a.g.nop + ppw - 1) / ppw;          // wavefronts per frame
@@ -697,24 +677,15 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
   xcd_frame_map(blockIdx.x, blocks_per_frame, a.nframes, frame, blk);  // a frame's blocks share one XCD's L2
   if (frame >= a.nframes) return;
   const bool fb = a.cg_p != nullptr;
-  const bool diag_enum = PLANAR && a.wx == nullptr && !fb;  // diag-only output: enumerate pixels in diag order
   const int i = blk * 256 + threadIdx.x;
   const bool active = i < npx;
   if (!active && !fb) return;
   const long long idx = (long long)frame * npx + i;
   int y, x;
-  // i / d by multiply-high with ceil(2^32 / d) (exact for i * d < 2^32, checked by the launcher; 0 = divide)
+  // i / w by multiply-high with ceil(2^32 / w) (exact for i * w < 2^32, checked by the launcher; 0 = divide)
   auto split = [&](int n, int d) { return a.idx_magic ? (int)__umulhi((unsigned)n, a.idx_magic) : n / d; };
-  if (diag_enum) {  // coalesced stores
-    const int d = split(i, g.h);
-    y = i - d * g.h;
-    x = d - y;
-    if (x < 0) x += g.w;          // 0 <= d < w, 0 <= y < h
-    if (x < 0) x += g.w * ((-x + g.w - 1) / g.w);
-  } else {
-    y = split(i, g.w);
-    x = i - y * g.w;
-  }
+  y = split(i, g.w);
+  x = i - y * g.w;
   const int P = g.P, lb = -P / 2, ub = P / 2 - 1, st = g.steps, noc = g.noc;
   float we = 0.0f, fu = 0.0f, fv = 0.0f;
   if (active) {
@@ -804,18 +775,8 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
     fv /= we;
   }
   if (PLANAR) {
-    const size_t dg = (size_t)frame * npx + diag_index(x, y, g.w, g.h);
-    if (a.wx) {
-      a.wx[idx] = fu;
-      a.wy[idx] = fv;
-    }
-    if (diag_enum) {  // idx IS the diag-linear index
-      a.wx_diag[idx] = fu;
-      a.wy_diag[idx] = fv;
-    } else if (a.wx_diag) {
-      a.wx_diag[dg] = fu;
-      a.wy_diag[dg] = fv;
-    }
+    a.wx[idx] = fu;
+    a.wy[idx] = fv;
   } else if (a.stereo) {
     a.flow_aos[idx] = fu;  // one channel (patchgrid.cpp:267,390)
   } else {
@@ -823,11 +784,72 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
   }
 }
 
+// Gray patches with P = 8 on a grid of step 4 (operating point 2), AoS output: the 4 pixels x0 .. x0+3 of a row with
+// x0 = 4 bx + offw - 4 are covered by the same (at most) 2 x 2 patches -- columns bx-1 and bx of the grid, where they are the
+// patch entries 4..7 and 0..3 of one patch row -- so a thread takes such a quad: one aligned 16-byte load of weights and
+// one 8-byte load of the displacement per patch instead of four scattered 4-byte loads per PIXEL, the index arithmetic
+// once per quad, and 32 contiguous bytes out.  Same candidates in the same order (grid column ascending, then grid row),
+// the same additions: same bits as densify_kernel.
+__global__ __launch_bounds__(256) void densify_quad_kernel(const DensifyArgs a, const int nbx) {
+  const LevelGeom& g = a.g;
+  const int w = g.w, h = g.h;
+  const int quads = nbx * h;
+  const int blocks_per_frame = (quads + 255) / 256;
+  int frame, blk;
+  xcd_frame_map(blockIdx.x, blocks_per_frame, a.nframes, frame, blk);  // a frame's blocks share one XCD's L2
+  if (frame >= a.nframes) return;
+  const int q = blk * 256 + threadIdx.x;
+  if (q >= quads) return;
+  const int y = q / nbx, bx = q - y * nbx;
+  const int x0 = 4 * bx + g.offw - 4;
+  const int yy = y - g.offh + 4;  // >= 0: offh < steps
+  const int by = yy >> 2, ty = yy & 3;
+  const float* __restrict__ pf = a.p + (size_t)frame * g.nop * 2;
+  const float* __restrict__ pwf = a.pweight + (size_t)frame * g.nop * 64;
+  float4 pw[4];
+  float2 pp[4];
+  bool ok[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {  // c = 2 * (grid column: 0 = bx-1, 1 = bx) + (grid row: 0 = by-1, 1 = by)
+    const int gx = bx - 1 + (c >> 1), gy = by - 1 + (c & 1);
+    ok[c] = (gx >= 0) & (gx < g.nopw) & (gy >= 0) & (gy < g.noph);
+    const int ip = clampi(gx, 0, g.nopw - 1) * g.noph + clampi(gy, 0, g.noph - 1);
+    const int kx0 = (c >> 1) ? 0 : 4, ky = (c & 1) ? ty : ty + 4;
+    pw[c] = *reinterpret_cast<const float4*>(pwf + (size_t)ip * 64 + ky * 8 + kx0);
+    pp[c] = *reinterpret_cast<const float2*>(pf + 2 * ip);
+  }
+  float2* out = reinterpret_cast<float2*>(a.flow_aos) + ((size_t)frame * h + y) * w;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    float we = 0.0f, fu = 0.0f, fv = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float r = t == 0 ? pw[c].x : (t == 1 ? pw[c].y : (t == 2 ? pw[c].z : pw[c].w));
+      const float absw = div_rn(1.0f, fmaxf(2.0f, r));  // == 1.0f / x: numerator 1, denominator >= 2 (ofdis_dev.h)
+      const float nwe = we + absw, nfu = fu + pp[c].x * absw, nfv = fv + pp[c].y * absw;
+      we = ok[c] ? nwe : we;
+      fu = ok[c] ? nfu : fu;
+      fv = ok[c] ? nfv : fv;
+    }
+    if (we > 0) {
+      fu /= we;
+      fv /= we;
+    }
+    const int x = x0 + t;
+    if (x >= 0 && x < w) out[x] = make_float2(fu, fv);
+  }
+}
+
 hipError_t launch_densify(const DensifyArgs& a_in, hipStream_t s) {
   DensifyArgs a = a_in;
+  if (a.flow_aos && !a.stereo && !a.cg_p && a.g.noc == 1 && a.g.P == 8 && a.g.steps == 4 && a.g.offw < 4 && a.g.offh < 4) {
+    const int nbx = (a.g.w + 3 - a.g.offw) / 4 + 1;  // quads per row: the last one holds column w - 1
+    const int blocks_per_frame = (nbx * a.g.h + 255) / 256;
+    hipLaunchKernelGGL(densify_quad_kernel, dim3(((a.nframes + 7) / 8) * 8 * blocks_per_frame), dim3(256), 0, s, a, nbx);
+    return hipGetLastError();
+  }
   {
-    const bool diag_enum = !a.flow_aos && a.wx == nullptr && a.cg_p == nullptr;
-    const unsigned long long d = diag_enum ? a.g.h : a.g.w, npx = (unsigned long long)a.g.w * a.g.h;
+    const unsigned long long d = a.g.w, npx = (unsigned long long)a.g.w * a.g.h;
     // floor(n * ceil(2^32/d) / 2^32) == floor(n / d) for n * (d - 1) < 2^32 (n < npx here)
     a.idx_magic = (d > 1 && npx * d < (1ull << 32)) ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u;
   }
@@ -839,38 +861,6 @@ hipError_t launch_densify(const DensifyArgs& a_in, hipStream_t s) {
     hipLaunchKernelGGL(densify_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL(densify_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------ test hook
-__global__ void wave_sum_test_kernel(const float* in, float* out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = wave_sum(in[i]);
-}
-// out[0][i] = {div_rn(a,b), a/b}, out[1][i] = {sqrt_rn(|a|), sqrtf(|a|)} interleaved: [4][n] = trimmed q, IEEE q,
-// trimmed sqrt, IEEE sqrt
-__global__ void div_sqrt_test_kernel(const float* a, const float* b, float* out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float x = a[i], y = b[i];
-  out[i] = div_rn(x, y);
-  out[n + i] = x / y;
-  out[2 * n + i] = sqrt_rn(fabsf(x));
-  out[3 * n + i] = sqrtf(fabsf(x));
-  // the fused TV kernel's quotient: reciprocal without v_rcp_f32 (rcp_newton), no v_div_fixup (finite operands only)
-  out[4 * n + i] = div_by_finite(x, 0.0f - y, rcp_newton(y, 0.0f - y));
-  out[5 * n + i] = rcp_newton(y, 0.0f - y);
-  float rs;
-  const float sq = sqrt_newton(fabsf(x), rs);
-  out[6 * n + i] = sq;
-  out[7 * n + i] = div_by_finite(y, 0.0f - sq, rcp_from(sq, 0.0f - sq, rs));  // y / sqrt(|x|) as the fused TV kernel forms it
-}
-hipError_t launch_div_sqrt_test(const float* a, const float* b, float* out, int n, hipStream_t s) {
-  hipLaunchKernelGGL(div_sqrt_test_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
-  return hipGetLastError();
-}
-hipError_t launch_wave_sum_test(const float* in, float* out, int n, hipStream_t s) {
-  hipLaunchKernelGGL(wave_sum_test_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
   return hipGetLastError();
 }
 

@@ -7,9 +7,15 @@
 // the order the wavefront SOR consumes them.  This kernel is the SOR of ofdis_sor.hip (lane = image row,
 // step t -> column t - j, NS software-pipelined sweeps) with its nine row loads replaced by a producer
 // that runs a few diagonals ahead in the same wavefront and hands each pixel's seven coefficients over
-// IN REGISTERS.  Per pixel and iteration HBM sees 13 row reads (8 derivatives, mask, wx, wy, du, dv) and the
+// IN REGISTERS.  Per pixel and iteration HBM sees the pixel's records (8 derivatives; wx, wy, mask; du, dv) and the
 // final du, dv: 60 B instead of 141 B for the tv_system + sor pair (the 7-plane system never exists in
 // memory), and the producer's arithmetic fills the issue slots the SOR's dependency chains leave empty.
+// The operands are the "sdiag" records written by ofdis_prep.hip (ofdis_dev.h: sdiag_index): one diag row of a strip is
+// h consecutive records, so a step costs two 16-byte loads (derivatives; all zero where the warp's mask is zero), one
+// 8-byte load (wx, wy) and one 8-byte load / store (du, dv) per lane -- 5 memory instructions instead of the 15 of one
+// 4-byte plane per operand, 56 bytes per pixel and iteration.
+// Strips: S frames laid side by side form one image of S*w columns whose diag rows wrap at S*w; a wavefront walks the
+// whole strip, so the fill / drain of the skewed sweep (h steps) is paid once per S frames.
 //
 // In diag coordinates (row d = (x+y) mod w, lane = y) the 4-neighbourhood is row-local:
 //     (x+1,y) -> (d+1, lane)     (x-1,y) -> (d-1, lane)     (x,y+1) -> (d+1, lane+1)     (x,y-1) -> (d-1, lane-1)
@@ -51,67 +57,18 @@ namespace ofdis {
 
 // Quotients of this kernel: denominators are normal and positive by construction (n >= 0.01, sqrt(.. + 1e-6) >= 1e-3,
 // det >= (sum of edge weights)^2 > 0) and numerators are finite for finite images, so v_div_fixup_f32 has nothing to
-// fix (ofdis_dev.h: div_by_finite).  OFDIS_FUSED_FIXUP=1 at build time keeps it (A/B builds, tools/ab_build.py).
-#ifndef OFDIS_FUSED_FIXUP
-#define OFDIS_FUSED_FIXUP 0
-#endif
+// fix (ofdis_dev.h: div_by_finite).
 struct FDen {  // a denominator prepared once for all its quotients
-  float b, nb, r;
+  float nb, r;
 };
-#ifndef OFDIS_FUSED_RCPNR
-#define OFDIS_FUSED_RCPNR 0  // 1: reciprocals by rcp_newton (no transcendental instruction) instead of v_rcp_f32 + one step
-#endif
-#ifndef OFDIS_FUSED_BPERM
-#define OFDIS_FUSED_BPERM 0  // 1: lane shifts by ds_bpermute_b32 instead of DPP moves
-#endif
-#ifndef OFDIS_FUSED_SQRTNR
-#define OFDIS_FUSED_SQRTNR 0  // 1: square roots by sqrt_newton (no transcendental instruction) instead of v_sqrt_f32 + selection
-#endif
 __device__ __forceinline__ FDen fden(float b) {
   // 0 - b, not -b: a subtraction from +0 is not a negation for the compiler (signed zeros), so it stays one plain
   // instruction and is not folded back into a source modifier (VOP3) of every fma that uses it
-  const float nb = 0.0f - b;
-#if OFDIS_FUSED_RCPNR == 2  // experiment: v_rcp_f32 followed by a scalar instruction
-  float r0;
-  asm("v_rcp_f32 %0, %1\n\ts_nop 0" : "=v"(r0) : "v"(b));
-  const float e0 = __builtin_fmaf(nb, r0, 1.0f);
-  return FDen{b, nb, __builtin_fmaf(e0, r0, r0)};
-#endif
-  return FDen{b, nb, OFDIS_FUSED_RCPNR ? rcp_newton(b, nb) : rcp_refined(b)};
+  return FDen{0.0f - b, rcp_refined(b)};
 }
-__device__ __forceinline__ float fdiv_by(float a, const FDen& d) {
-#ifdef OFDIS_FUSED_NODIV  // timing experiment only (results wrong): quotient = one multiplication, root = v_sqrt_f32 alone
-  return a * d.r;
-#endif
-  return OFDIS_FUSED_FIXUP ? div_by(a, d.b, d.r) : div_by_finite(a, d.nb, d.r);
-}
+__device__ __forceinline__ float fdiv_by(float a, const FDen& d) { return div_by_finite(a, d.nb, d.r); }
 __device__ __forceinline__ float fdiv_rn(float a, float b) { return fdiv_by(a, fden(b)); }
-// num / sqrt(x): the root and, from its by-product 1/sqrt(x), the reciprocal of the root
-__device__ __forceinline__ float fdiv_by_sqrt(float num, float x) {
-#ifdef OFDIS_FUSED_NODIV
-  return num * __builtin_amdgcn_rsqf(x);
-#endif
-  if (OFDIS_FUSED_SQRTNR == 1) {
-    float y;
-    const float s = sqrt_newton(x, y);
-    const float ns = 0.0f - s;
-    return fdiv_by(num, FDen{s, ns, rcp_from(s, ns, y)});
-  }
-#if OFDIS_FUSED_SQRTNR == 2  // experiment: v_sqrt_f32 followed by a scalar instruction
-  {
-    float s;
-    asm("v_sqrt_f32 %0, %1\n\ts_nop 0" : "=v"(s) : "v"(x));
-    const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
-    const float su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
-    const float ed = __builtin_fmaf(-sd, s, x);
-    const float eu = __builtin_fmaf(-su, s, x);
-    float r = (ed <= 0.0f) ? sd : s;
-    r = (eu > 0.0f) ? su : r;
-    return fdiv_by(num, fden(r));
-  }
-#endif
-  return fdiv_rn(num, sqrt_rn(x));
-}
+__device__ __forceinline__ float fdiv_by_sqrt(float num, float x) { return fdiv_rn(num, sqrt_rn(x)); }  // num / sqrt(x)
 
 struct FSlot {
   float a11, a12, a22, b1, b2, sh, sv;  // system of pixel (j, tau - j); a** become the block inverse at step tau
@@ -119,28 +76,29 @@ struct FSlot {
   float hl, vt;                         // left / top edge weights (= sh of the left, sv of the upper pixel)
 };
 struct FRow {
-  float wx, wy, du, dv;
+  float wx, wy, du, dv;  // the pixel's (wx, wy) record and its du, dv of before this iteration
 };
-struct FDer {
-  float d[8];
-  float m;
+struct FDer {  // the pixel's derivative record, in the order ofdis_prep.hip stores it
+  float ix, iz, ixx, ixz, iy, ixy, iyz, iyy;
 };
 
 // Data term of one gray pixel: ofdis_tvmath.h data_term() with the divisions and square roots written out
 // (ofdis_dev.h: div_by / sqrt_rn; same bits for the operand ranges the launcher guarantees) and the refined
 // reciprocal of each normaliser shared by the two quotients that use it.
+// The warp's mask (opticalflow_aux.c:352,381: it multiplies both weights) is not an operand: ofdis_prep.hip stores an
+// all-zero record for a masked pixel, and zero derivatives give the same coefficients as zero weights -- every product
+// below is then +-0 * finite and every accumulator ends as +0 either way (sums of signed zeros starting from +0).
 template <bool BRIGHT>
 __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, float hd3, float hg3, float& a11,
                                                float& a12, float& a22, float& b1, float& b2) {
-  const float ix = D.d[0], iy = D.d[1], iz = D.d[2], ixx = D.d[3], ixy = D.d[4], iyy = D.d[5], ixz = D.d[6],
-              iyz = D.d[7], m = D.m;
+  const float ix = D.ix, iy = D.iy, iz = D.iz, ixx = D.ixx, ixy = D.ixy, iyy = D.iyy, ixz = D.ixz, iyz = D.iyz;
   a11 = 0.0f; a12 = 0.0f; a22 = 0.0f; b1 = 0.0f; b2 = 0.0f;
   float tmp, tmp2, n1, n2;
   if (BRIGHT) {  // hd3 != 0 (opticalflow_aux.c:352)
     tmp = iz + ix * u + iy * v;
     n1 = ix * ix + iy * iy + DATANORM;
     const FDen d1 = fden(n1);
-    tmp = fdiv_by_sqrt(m * hd3, fdiv_by(3 * tmp * tmp, d1) + EPS_COLOR);
+    tmp = fdiv_by_sqrt(hd3, fdiv_by(3 * tmp * tmp, d1) + EPS_COLOR);
     tmp = fdiv_by(tmp, d1);
     a11 += tmp * ix * ix;
     a12 += tmp * ix * iy;
@@ -153,7 +111,7 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
   const FDen d1 = fden(n1), d2 = fden(n2);
   tmp = ixz + ixx * u + ixy * v;
   tmp2 = iyz + ixy * u + iyy * v;
-  tmp = fdiv_by_sqrt(m * hg3, fdiv_by(3 * tmp * tmp, d1) + fdiv_by(3 * tmp2 * tmp2, d2) + EPS_GRAD);
+  tmp = fdiv_by_sqrt(hg3, fdiv_by(3 * tmp * tmp, d1) + fdiv_by(3 * tmp2 * tmp2, d2) + EPS_GRAD);
   tmp2 = fdiv_by(tmp, d2);
   tmp = fdiv_by(tmp, d1);
   a11 += tmp * ixx * ixx + tmp2 * ixy * ixy;
@@ -177,11 +135,7 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
 // Workgroup barrier of the multi-wave variant's step loop.  Only LDS traffic crosses wavefronts there (the du/dv ring), so
 // only the LDS counter is drained: __syncthreads() also waits for vmcnt(0), i.e. for the global row loads that are
 // deliberately kept 3-5 steps in flight, and would expose one memory latency per step.
-__device__ __forceinline__ void mw_step_barrier() {
-#ifndef OFDIS_MW_NOBARRIER  // (timing experiment only: without the barrier the results are wrong)
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
+__device__ __forceinline__ void mw_step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int MW_LAG = 10;       // MODE 1: steps between consecutive iterations' wavefronts: PDW + 2*(NS-1) + 1 for NS = 3
 constexpr int MW_MAX_ITERS = 8;  // MODE 1: wavefronts per workgroup (= fixed-point iterations it handles)
@@ -190,8 +144,10 @@ constexpr int SP_LAG = 9;        // MODE 2: du/dv are read 4 rows ahead instead 
 constexpr int SP_MAX_ITERS = 6;  // MODE 2: 2 wavefronts per iteration, 12 per workgroup (3 per SIMD: 168 VGPRs each)
 constexpr int SLOT_FLOATS = 11;  // FSlot
 
-// MODE 0: one wavefront walks all fixed-point iterations of its frame group (the throughput kernel).
-// MODE 1: "multi-wave" -- one workgroup per frame group, wavefront k runs iteration k (header comment).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// MODE 0: one wavefront walks all fixed-point iterations of its strip(s) (the throughput kernel).
+// MODE 1: "multi-wave" -- one workgroup per frame group, wavefront k runs iteration k (header comment); S = 1.
 // MODE 2: "split" -- as MODE 1 with every iteration's work divided between TWO wavefronts: a producer (row loads, flow
 //         gradients, smoothness, data term, Laplacian: parts 1-4 of a step, ~2/3 of its instructions) and a solver (block
 //         inverse and the NS pipelined sweeps, part 5).  The producer hands each pixel's FSlot to its solver through a
@@ -200,47 +156,25 @@ constexpr int SLOT_FLOATS = 11;  // FSlot
 //         iteration's producer through the same LDS ring MODE 1 uses.  A lone wavefront issues one instruction per ~6
 //         clocks (dependent-issue latency), so halving the instructions per wavefront and step nearly halves the step.
 template <int NS, bool BRIGHT, int MODE>
-#ifndef OFDIS_FUSED_MINWAVES
-#define OFDIS_FUSED_MINWAVES 1
-#endif
-__global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * MW_MAX_ITERS : 256),
-                             MODE == 0 ? OFDIS_FUSED_MINWAVES : 1) void tv_fused_kernel(
+__global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * MW_MAX_ITERS : 256)) void tv_fused_kernel(
     const FusedArgs a, const int R) {
   constexpr int U = 6;
   constexpr bool MW = MODE != 0;
   constexpr int MAXIT = MODE == 2 ? SP_MAX_ITERS : MW_MAX_ITERS;
   // du/dv rows handed from iteration k to iteration k+1: [k][step & 7][lane]
   __shared__ float2 xring[MW ? (MAXIT - 1) * MW_RING * 64 : 1];
-#ifdef OFDIS_FUSED_LDS_DUMMY  // occupancy experiment (tools/ab_build.py ... -DOFDIS_FUSED_LDS_DUMMY=15500: 62 KB per block
-  // = 2 wavefronts per SIMD instead of the 3 that 144 VGPRs allow): SAME kernel time, 2.64 ms per 4096-pair step
-  __shared__ float lds_dummy[MODE == 0 ? OFDIS_FUSED_LDS_DUMMY : 1];
-  if (a.n_inner < 0) lds_dummy[threadIdx.x] = a.omega;  // never true; keeps the array
-#endif
-#ifndef OFDIS_FUSED_SLOTLDS
-#define OFDIS_FUSED_SLOTLDS 0
-#endif
-  // SL (MODE 0, -DOFDIS_FUSED_SLOTLDS=1): the systems waiting for sweeps 1 ... NS-1 live in LDS instead of a six-deep register
-  // ring (8 floats per pixel: block inverse, right-hand side, sh, sv, vt; hl is the previous row's sh): 8 KB per wavefront,
-  // ~40 VGPRs less -- the register budget of four wavefronts per SIMD.  [wavefront of the block][row & 3][half][lane]
-  constexpr bool SL = OFDIS_FUSED_SLOTLDS != 0 && MODE == 0;
-  __shared__ float4 slds[SL ? 4 * 4 * 2 * 64 : 1];
   // MODE 2: FSlot of the pixel row handed from an iteration's producer to its solver: [iteration][step & 1][field][lane]
   __shared__ float sring[MODE == 2 ? SP_MAX_ITERS * 2 * SLOT_FLOATS * 64 : 1];
-  // prefetch distances: the W row (wx,wy,du,dv) of diag row t+PDW and the D row (8 derivatives + mask) of row t+PDD are
-  // requested at step t; first uses are rows t+3 (uu, vv) and t+1 (data term).  (5, 3) = two steps of slack, 141 VGPRs,
-  // 3 wavefronts per SIMD; (4, 2) = one step of slack, 128 VGPRs, 4 wavefronts per SIMD measured the same kernel time
-  // and 1 % less end to end (tools/ab_build.py), so the occupancy is not what limits this kernel.
-#ifndef OFDIS_FUSED_PDW
-#define OFDIS_FUSED_PDW 5
-#define OFDIS_FUSED_PDD 3
-#endif
-  constexpr int PDW = OFDIS_FUSED_PDW, PDD = OFDIS_FUSED_PDD;
+  // prefetch distances: the (wx, wy) record (MODE 0: and du, dv) of diag row t+PDW and the derivative record of row
+  // t+PDD are requested at step t; first uses are rows t+3 (uu, vv) and t+1 (data term): two steps of slack.  (One step of
+  // slack, 128 VGPRs = 4 wavefronts per SIMD, measured the same kernel time: occupancy is not what limits this kernel.)
+  constexpr int PDW = 5, PDD = 3;
   constexpr int PDU = MODE == 2 ? 4 : PDW;  // read-ahead of du/dv (MODE 2: from LDS, one step before their first use)
   constexpr int LAG = MODE == 2 ? SP_LAG : MW_LAG;
   static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
   static_assert(!MW || LAG >= PDU + 2 * (NS - 1) + 1, "a row must be published before the next iteration reads it");
   const int w = a.t.w, h = a.t.h;
-  const int npx = w * h;
+  const int rw = a.S * w;  // diag rows of a strip = its columns
   const int lane = threadIdx.x & 63;
   // MW: one frame group per workgroup; MODE 1: wavefront `it` runs iteration `it`; MODE 2: wavefronts 0..n-1 are the
   // producers of iterations 0..n-1, wavefronts n..2n-1 their solvers (a producer and its solver share a SIMD when n = 4)
@@ -251,72 +185,39 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   const bool do_p = MODE != 2 || !is_solver;  // parts 1-4 of a step
   const bool do_s = MODE != 2 || is_solver;   // part 5
   const int wid = MW ? (int)blockIdx.x : __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  const int G = 64 / R;  // frames per wavefront
-  const int f0 = wid * G;
-  if (f0 >= a.t.nframes) return;  // whole wave idle (uniform; MW: the whole workgroup)
-  int fl = lane / R;              // frame of this lane within the wavefront
+  const int G = 64 / R;  // strips per wavefront (lane groups of R lanes)
+  const int nstrips = a.t.nframes / a.S;  // (the launcher picks S among the divisors of nframes)
+  const int s0 = wid * G;                 // first strip of this wavefront
+  if (s0 >= nstrips) return;  // whole wave idle (uniform; MW: the whole workgroup)
+  int fl = lane / R;          // strip of this lane within the wavefront
   const int jr = lane % R;
-  const bool row_ok = (f0 + fl < a.t.nframes) && (jr < h);
-  if (f0 + fl >= a.t.nframes) fl = a.t.nframes - 1 - f0;
+  const bool row_ok = (s0 + fl < nstrips) && (jr < h);
+  if (s0 + fl >= nstrips) fl = nstrips - 1 - s0;
   const int j = jr < h ? jr : h - 1;
   const bool has_top = j > 0, has_bot = j < h - 1;
   const float omega = a.omega, qa = a.quarter_alpha, hd3 = a.half_delta_over3, hg3 = a.half_gamma_over3;
-  // (x, y-1) / (x, y+1) live in the neighbouring lanes.  Through the LDS crossbar the shift wraps around instead of
-  // filling with zero; every consumer either selects the value away on its border row or multiplies it by an edge weight
-  // that is zero there (and the weight itself is zero in the source lane: last / idle rows have sv = 0), see "Border
-  // handling" below.
-  const int a_prev = ((lane + 63) & 63) * 4, a_next = ((lane + 1) & 63) * 4;
-#if OFDIS_FUSED_BPERM == 2  // experiment: DPP moves, each followed by a scalar instruction (ends the slow issue mode it starts)
-  auto from_prev = [&](float x) {
-    float r;
-    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 0" : "=v"(r) : "v"(x));
-    return r;
-  };
-  auto from_next = [&](float x) {
-    float r;
-    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 0" : "=v"(r) : "v"(x));
-    return r;
-  };
-#else
-  auto from_prev = [&](float x) { return OFDIS_FUSED_BPERM ? lane_read(x, a_prev) : wave_from_prev(x); };
-  auto from_next = [&](float x) { return OFDIS_FUSED_BPERM ? lane_read(x, a_next) : wave_from_next(x); };
-#endif
+  // (x, y-1) / (x, y+1) live in the neighbouring lanes; DPP wave shifts fill lane 0 / 63 with zero.  Every consumer either
+  // selects the value away on its border row or multiplies it by an edge weight that is zero there, see "Border handling".
+  auto from_prev = [&](float x) { return wave_from_prev(x); };
+  auto from_next = [&](float x) { return wave_from_next(x); };
 
-  // one buffer resource per operand, based at the wavefront's first frame: a lane's byte offset within it is
-  // constant, the moving part (plane, diag row) is a scalar offset
-  const int nfr = min(G, a.t.nframes - f0);
-  const int plane_bytes = npx * 4;
-#ifdef OFDIS_FUSED_ALIAS  // timing experiment only (results wrong): every wavefront works on one of the first few frame
-  // groups' memory, so that the operands stay in L2 -- separates the kernel's HBM time from its issue time
-  const int fmem = (wid % OFDIS_FUSED_ALIAS) * G;
-#else
-  const int fmem = f0;
-#endif
-  auto rsrc = [&](const float* base, int planes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)fmem * planes * npx), 0, nfr * planes * plane_bytes,
-                                             0x00020000);
+  // one buffer resource per record array, based at the wavefront's first strip: a lane's byte offset within it is
+  // constant, the moving part (the diag row) is a scalar offset
+  const int nst = min(G, nstrips - s0);
+  const size_t strip_recs = (size_t)rw * h;
+  auto rsrc = [&](const float* base, int rec_floats) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)s0 * strip_recs * rec_floats), 0,
+                                             (int)(nst * strip_recs * rec_floats * 4), 0x00020000);
   };
-  const __amdgpu_buffer_rsrc_t rsD = rsrc(a.derivs, 8), rsM = rsrc(a.mask, 1), rsWx = rsrc(a.wx, 1),
-                               rsWy = rsrc(a.wy, 1), rsU = rsrc(a.du, 1), rsV = rsrc(a.dv, 1);
-  const int vo1 = (fl * npx + j) * 4;      // single-plane operands
-  const int vo8 = (fl * 8 * npx + j) * 4;  // the 8 derivative planes of a frame
-#ifdef OFDIS_FUSED_NOLOAD  // timing experiment only (results wrong): one load per operand before the loop, then the value
-  // is only made opaque again at every use site -- the step loop issues no VMEM loads at all
-  const float ld_once = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsWx, vo1, 0, 0));
-  auto ldf = [&](const __amdgpu_buffer_rsrc_t&, int, int) {
-    float v = ld_once;
-    asm volatile("" : "+v"(v));
-    return v;
-  };
-#else
-  auto ldf = [&](const __amdgpu_buffer_rsrc_t& rs, int voff, int soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
-  };
-#endif
+  const __amdgpu_buffer_rsrc_t rsD = rsrc(a.d8, 8), rsW = rsrc(a.wrec, 2), rsU = rsrc(a.uv, 2);
+  const int vrec = fl * (int)strip_recs + j;  // this lane's record within a diag row 0 of its strip
+  const int vo8 = vrec * 32, vo2 = vrec * 8;
+  auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
 
-  // this lane's row of the AoS output (multi-wave variants with flow_out)
+  // this lane's row of the AoS output (multi-wave variants with flow_out; S = 1: strip = frame)
+  const int npx = w * h;
   float2* const flow_row = MW && a.flow_out
-                               ? reinterpret_cast<float2*>(a.flow_out) + ((size_t)(f0 + fl) * npx + (size_t)j * w)
+                               ? reinterpret_cast<float2*>(a.flow_out) + ((size_t)(s0 + fl) * npx + (size_t)j * w)
                                : nullptr;
 
   FRow W[6];
@@ -332,28 +233,15 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   for (int r = 0; r < 3; ++r) {
     uu[r] = vv[r] = 0.0f;
     sm[r] = 1.0f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) D[r].d[q] = 0.0f;
-    D[r].m = 0.0f;
+    D[r] = FDer{0, 0, 0, 0, 0, 0, 0, 0};
   }
   float ru[NS], rv[NS], ru2[NS], rv2[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) { ru[s] = rv[s] = ru2[s] = rv2[s] = 0.0f; }
-  float4* const myring = slds + (SL ? (threadIdx.x >> 6) * (4 * 2 * 64) + lane : 0);
-  float hlc[NS], pdur = 0.0f, pdvr = 0.0f;  // SL: hl of the row each later sweep handles next; dur, dvr of the row before sweep 0's
-#pragma unroll
-  for (int s = 0; s < NS; ++s) hlc[s] = 1.0f;
-  if constexpr (SL) {  // fill-phase systems: unit diagonal and unit weights, as the register ring starts
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      myring[r * 128] = make_float4(1.0f, 0.0f, 1.0f, 0.0f);
-      myring[r * 128 + 64] = make_float4(0.0f, 1.0f, 1.0f, 0.0f);
-    }
-  }
 
-  auto wrap = [&](int r) { r %= w; return r < 0 ? r + w : r; };
-  auto next_row = [&](int r) { return (r + 1 == w) ? 0 : r + 1; };
-  const int row_bytes = h * 4;
+  auto wrap_row = [&](int r) { r %= rw; return r < 0 ? r + rw : r; };  // diag row of the strip
+  auto wrap_col = [&](int c) { c %= w; return c < 0 ? c + w : c; };    // column within a frame
+  auto next_row = [&](int r) { return (r + 1 == rw) ? 0 : r + 1; };
   // du/dv of the previous iteration for the row with unwrapped step number tau (MW): from the LDS ring; zero in the
   // first fixed-point iteration (image_erase, refine_variational.cpp:186-187)
   auto ring_uv = [&](FRow& r, int tau) {
@@ -366,19 +254,26 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   };
   // tau = unwrapped step number of the row (MW only): the LDS ring slot
   auto load_w = [&](FRow& r, int drow, int tau) {
-    const int o = drow * row_bytes;
-    r.wx = ldf(rsWx, vo1, o); r.wy = ldf(rsWy, vo1, o);
+    const int o = drow * h * 8;
+    const auto t = __builtin_amdgcn_raw_buffer_load_b64(rsW, vo2, o, 0);
+    // (through scalars: __builtin_bit_cast applied directly to a vector element reads element 0, ROCm 7.2)
+    const unsigned t0 = t[0], t1 = t[1];
+    r.wx = asf(t0); r.wy = asf(t1);
     if constexpr (MODE == 1) {
       ring_uv(r, tau);
     } else if constexpr (MODE == 0) {
-      r.du = ldf(rsU, vo1, o); r.dv = ldf(rsV, vo1, o);
+      const auto q = __builtin_amdgcn_raw_buffer_load_b64(rsU, vo2, o, 0);
+      const unsigned q0 = q[0], q1 = q[1];
+      r.du = asf(q0); r.dv = asf(q1);
     }  // MODE 2: du/dv follow one step later (PDU = 4)
   };
   auto load_d = [&](FDer& r, int drow) {
-    const int o = drow * row_bytes;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) r.d[q] = ldf(rsD, vo8, q * plane_bytes + o);
-    r.m = ldf(rsM, vo1, o);
+    const int o = drow * h * 32;
+    const auto lo = __builtin_amdgcn_raw_buffer_load_b128(rsD, vo8, o, 0);
+    const auto hi = __builtin_amdgcn_raw_buffer_load_b128(rsD, vo8 + 16, o, 0);
+    const unsigned l0 = lo[0], l1 = lo[1], l2 = lo[2], l3 = lo[3], h0 = hi[0], h1 = hi[1], h2 = hi[2], h3 = hi[3];
+    r.ix = asf(l0); r.iz = asf(l1); r.ixx = asf(l2); r.ixz = asf(l3);
+    r.iy = asf(h0); r.ixy = asf(h1); r.iyz = asf(h2); r.iyy = asf(h3);
   };
 
   // ring index of diag row rho is (rho + 3) mod ring size; the loop variable is k = t + 3, u = k % 6,
@@ -393,9 +288,9 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   }
   // prologue: W rows -1, 0, 1 (indices 2, 3, 4)
   if (do_p) {
-    load_w(W[2], wrap(-1), -1);
-    load_w(W[3], wrap(0), 0);
-    if (PDW == 5) load_w(W[4], wrap(1), 1);
+    load_w(W[2], wrap_row(-1), -1);
+    load_w(W[3], wrap_row(0), 0);
+    if (PDW == 5) load_w(W[4], wrap_row(1), 1);
     if constexpr (MODE == 2) {  // du/dv rows -1, 0: the loop starts with row t + PDU = 1
       ring_uv(W[2], -1);
       ring_uv(W[3], 0);
@@ -404,14 +299,14 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   // du, dv are zero before the first fixed-point iteration (refine_variational.cpp:186-187): the kernel never reads
   // them during its first pass over the columns, so the caller does not have to clear them
   if (!MW) W[2].du = W[2].dv = W[3].du = W[3].dv = W[4].du = W[4].dv = 0.0f;
-  int rowW = wrap(PDW - 3);  // next W row to load (row t+PDW at t = -3)
-  int tauW = PDW - 3;        // ... and its unwrapped step number
-  int rowD = wrap(PDD - 3);  // next D row to load (row t+PDD at t = -3)
-  int srow = wrap(-3 - 2 * (NS - 1));  // row finished by the last sweep at step t = -3
-  int x2 = wrap(-1 - j);               // this lane's x on diag row t+2 (per lane)
-  bool x1_last = (wrap(-2 - j) == w - 1);  // row t+1 is this lane's last column
+  int rowW = wrap_row(PDW - 3);  // next W row to load (row t+PDW at t = -3)
+  int tauW = PDW - 3;            // ... and its unwrapped step number
+  int rowD = wrap_row(PDD - 3);  // next D row to load (row t+PDD at t = -3)
+  int srow = wrap_row(-3 - 2 * (NS - 1));  // row finished by the last sweep at step t = -3
+  int x2 = wrap_col(-1 - j);               // this lane's x (within its frame) on diag row t+2
+  bool x1_last = (wrap_col(-2 - j) == w - 1);  // row t+1 is the last column of this lane's frame
 
-  const int wtot = (MW ? 1 : a.n_inner) * w;  // columns per lane over all iterations of this wavefront
+  const int wtot = (MW ? 1 : a.n_inner) * rw;  // columns per lane over all iterations of this wavefront
   const int tend = (wtot - 1) + (h - 1) + 2 * (NS - 1);
   int ig = -3 - j - 2 * (NS - 1);  // global column (over all iterations) the last sweep finishes at step t
   bool first_w = !MW;              // row t+5 at t = -3 is column 2 - j: first iteration (w >= 16)
@@ -421,15 +316,6 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // step t = k0 + u - 3; up to U-1 steps past tend are executed: every pixel is then out of range
-      float4 qa_[NS], qb_[NS];
-      if constexpr (SL) {  // the systems of rows t-2, t-4, ... (issued first: consumed at the end of the step)
-#pragma unroll
-        for (int sw = 1; sw < NS; ++sw) {
-          const int row = (k0 + u - 3 - 2 * sw) & 3;
-          qa_[sw] = myring[row * 128];
-          qb_[sw] = myring[row * 128 + 64];
-        }
-      }
       if (do_p) {
         // ---- (1) loads: W row t+5, D row t+3
         load_w(W[(u + PDW) % 6], rowW, tauW);
@@ -524,29 +410,15 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           c.a11 = fdiv_by(A11, dd);
           c.a22 = fdiv_by(A22, dd);
           c.a12 = -fdiv_by(c.a12, dd);
-          if constexpr (SL && NS > 1) {  // (after this step's reads of the same ring row in program order)
-            const int row = (k0 + u - 3) & 3;
-            myring[row * 128] = make_float4(c.a11, c.a12, c.a22, c.b1);
-            myring[row * 128 + 64] = make_float4(c.b2, c.sh, c.sv, c.vt);
-          }
         }
         float nu[NS], nv[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          FSlot cl;
-          if constexpr (SL) {
-            if (s > 0) {
-              cl.a11 = qa_[s].x; cl.a12 = qa_[s].y; cl.a22 = qa_[s].z; cl.b1 = qa_[s].w;
-              cl.b2 = qb_[s].x; cl.sh = qb_[s].y; cl.sv = qb_[s].z; cl.vt = qb_[s].w;
-              cl.hl = hlc[s];
-              hlc[s] = qb_[s].y;  // the next row's left weight
-            }
-          }
-          const FSlot& c = (SL && s > 0) ? cl : slot[(u - 2 * s + 12) % 6];
+          const FSlot& c = slot[(u - 2 * s + 12) % 6];
           float ou, ov, rgu, rgv, bu, bv;
           if (s == 0) {
             const FSlot& p = slot[(u + 5) % 6];
-            ou = SL ? pdur : p.dur; ov = SL ? pdvr : p.dvr;
+            ou = p.dur; ov = p.dvr;
             rgu = c.dur; rgv = c.dvr;
             bu = from_next(c.dur);
             bv = from_next(c.dvr);
@@ -565,22 +437,19 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
         }
         {
-          if (!MW) first_w = ig + (PDW + 1 + 2 * (NS - 1)) < w;  // for the next step's row
+          if (!MW) first_w = ig + (PDW + 1 + 2 * (NS - 1)) < rw;  // for the next step's row
           if (MW && it < n_iters - 1) {  // hand the row to the next iteration (lanes outside their columns publish finite
             // values nobody reads as a pixel: the reader's lane is outside its columns at the same step number)
             xring[(it * MW_RING + (taus & (MW_RING - 1))) * 64 + lane] = make_float2(nu[NS - 1], nv[NS - 1]);
           } else if (MW && a.flow_out) {  // last iteration: the refined flow itself, AoS (one 8-byte store per lane;
             // a lane's consecutive columns fill its cache lines over the next steps)
-            const float fwx = ldf(rsWx, vo1, srow * row_bytes), fwy = ldf(rsWy, vo1, srow * row_bytes);
+            const auto q = __builtin_amdgcn_raw_buffer_load_b64(rsW, vo2, srow * h * 8, 0);
+            const unsigned q0 = q[0], q1 = q[1];
             if (row_ok && ig >= 0 && ig < wtot)
-              flow_row[ig] = make_float2(fwx + nu[NS - 1], fwy + nv[NS - 1]);
+              flow_row[ig] = make_float2(asf(q0) + nu[NS - 1], asf(q1) + nv[NS - 1]);
           } else if (row_ok && ig >= 0 && ig < wtot) {
-#ifdef OFDIS_FUSED_NOSTORE  // timing experiment only (results wrong): the results are only kept alive, never stored
-            asm volatile("" ::"v"(nu[NS - 1]), "v"(nv[NS - 1]));
-#else
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nu[NS - 1]), rsU, vo1, srow * row_bytes, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nv[NS - 1]), rsV, vo1, srow * row_bytes, 0);
-#endif
+            const u32x2 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), __builtin_bit_cast(unsigned, nv[NS - 1])};
+            __builtin_amdgcn_raw_buffer_store_b64(v, rsU, vo2, srow * h * 8, 0);
           }
         }
 #pragma unroll
@@ -588,7 +457,6 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           ru2[s] = ru[s]; rv2[s] = rv[s];
           ru[s] = nu[s]; rv[s] = nv[s];
         }
-        if constexpr (SL) { pdur = slot[u % 6].dur; pdvr = slot[u % 6].dvr; }
       }
       srow = next_row(srow);
       ++ig;
@@ -617,49 +485,40 @@ bool tv_fused_params_ok(float qa, float hd3, float hg3) {
 //     2048 (2 x 1024): T = 0: 2.93, 256 / 512: 3.00         4096 (2 x 2048): T = 0 / 256: 5.06-5.16, 512: 5.39-5.44
 // i.e. up to two rounds of workgroups (256 CUs) they beat the throughput mapping as long as the WHOLE batch is small;
 // once the other sub-batch has enough work to fill the SIMDs a workgroup that owns a CU for a whole level only gets
-// in the way.  Rule: at most 512 frame groups in the launch AND at most 1024 frames in the whole batch.
-// OFDIS_FUSED_MW_MAX overrides the group limit (0 = never use the multi-wave variants); read once.
+// in the way (at 4096 pairs per launch they take 4.5-4.9 ms against 2.65, profiles/README.md round 3).  Rule: at most
+// FusedArgs::mw_max_groups (default 512) frame groups in the launch AND at most 1024 frames in the whole batch.
 constexpr int MW_MAX_BATCH_FRAMES = 1024;
-static int g_mw_max = -1;  // -1: not initialised
-static int mw_max_groups() {
-  if (g_mw_max < 0) {
-    const char* e = getenv("OFDIS_FUSED_MW_MAX");
-    g_mw_max = e ? atoi(e) : 512;
-    if (g_mw_max < 0) g_mw_max = 0;
-  }
-  return g_mw_max;
-}
-void set_tv_fused_mw_max(int waves) { g_mw_max = waves; }  // test hook / tuning: < 0 = back to the default
 
-static int g_split = -1;  // test hook / tuning: 0 = never use the split (producer / solver) variant; OFDIS_FUSED_NO_SPLIT
-void set_tv_fused_split(int on) { g_split = on; }
-static bool split_enabled() {
-  if (g_split < 0) g_split = getenv("OFDIS_FUSED_NO_SPLIT") ? 0 : 1;
-  return g_split != 0;
+int tv_fused_mode(const FusedArgs& a) {
+  const int h = a.t.h;
+  const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
+  const int groups = (a.t.nframes + 64 / R - 1) / (64 / R);
+  const int total = a.total_frames > 0 ? a.total_frames : a.t.nframes;
+  const bool mw = a.S == 1 && a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS && groups <= a.mw_max_groups &&
+                  (total <= MW_MAX_BATCH_FRAMES || a.mw_max_groups >= (1 << 30));
+  return mw ? ((a.split && a.n_inner <= SP_MAX_ITERS) ? 2 : 1) : 0;
 }
 
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow) {
   if (wrote_flow) *wrote_flow = false;
-  if (!tv_fused_supported(a.t, a.iterations) || a.n_inner < 1 ||
+  if (!tv_fused_supported(a.t, a.iterations) || a.n_inner < 1 || a.S < 1 || a.t.nframes % a.S != 0 ||
       !tv_fused_params_ok(a.quarter_alpha, a.half_delta_over3, a.half_gamma_over3))
     return hipErrorInvalidValue;
   const int h = a.t.h;
   const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
   const int G = 64 / R;
-  const int waves = (a.t.nframes + G - 1) / G;
+  const int nstrips = a.t.nframes / a.S;
+  const int waves = (nstrips + G - 1) / G;
   const int blocks = (waves + 3) / 4;
   const bool bright = a.half_delta_over3 != 0.0f;
   // small batches: one workgroup per frame group, one (MODE 1) or two (MODE 2) wavefronts per fixed-point iteration
-  const int total = a.total_frames > 0 ? a.total_frames : a.t.nframes;
-  const bool mw = a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS && waves <= mw_max_groups() &&
-                  (total <= MW_MAX_BATCH_FRAMES || mw_max_groups() >= (1 << 30));
-  const bool split = mw && split_enabled() && a.n_inner <= SP_MAX_ITERS;
-  if (wrote_flow) *wrote_flow = mw && a.flow_out != nullptr;
+  const int mode = tv_fused_mode(a);
+  if (wrote_flow) *wrote_flow = mode != 0 && a.flow_out != nullptr;
 #define OFDIS_FUSED_LAUNCH(NS)                                                                                         \
-  if (split) {                                                                                                         \
+  if (mode == 2) {                                                                                                     \
     if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 2>), dim3(waves), dim3(128 * a.n_inner), 0, s, a, R);    \
     else hipLaunchKernelGGL((tv_fused_kernel<NS, false, 2>), dim3(waves), dim3(128 * a.n_inner), 0, s, a, R);          \
-  } else if (mw) {                                                                                                     \
+  } else if (mode == 1) {                                                                                              \
     if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 1>), dim3(waves), dim3(64 * a.n_inner), 0, s, a, R);     \
     else hipLaunchKernelGGL((tv_fused_kernel<NS, false, 1>), dim3(waves), dim3(64 * a.n_inner), 0, s, a, R);           \
   } else if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 0>), dim3(blocks), dim3(256), 0, s, a, R);          \

@@ -23,8 +23,8 @@ struct DisArgs {
   float* p_out;            // [B][nop][2]
   float* pweight;          // [B][nop][novals]
 };
-// largest float x with sqrtf(x) <= t (host sqrtf is correctly rounded)
-float outlier_sq_threshold(float t);
+// snapshot of the kernel-selection knobs (include/ofdis.h: ofdis_tuning; ofdis_capi.hip); *epoch counts the changes
+ofdis_tuning tuning(unsigned* epoch = nullptr);
 // PatGridClass::{InitializeGrid, SetTargetImage, InitializeFromCoarserOF, Optimize}
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s);
 
@@ -36,11 +36,9 @@ struct DensifyArgs {
   float* flow_aos;       // if non-null: AoS output
   float* wx;             // else planar outputs (row-major)
   float* wy;
-  float* wx_diag;        // optional second copy in the solver's diag layout (fused TV path)
-  float* wy_diag;
   // forward-backward merging (usefbcon, patchgrid.cpp:277-375): the complementary grid's results, or null
-  int stereo;               // one flow channel: flow_aos is [B][h][w], wy / wy_diag are not written
-  unsigned idx_magic;       // set by launch_densify: ceil(2^32 / d) for the pixel-index split by d = h (diag order) or w
+  int stereo;               // one flow channel: flow_aos is [B][h][w], wy is not written
+  unsigned idx_magic;       // set by launch_densify: ceil(2^32 / w) for the pixel-index split
   const float* cg_p;        // [B][nop][2]
   const float* cg_pweight;  // [B][nop][novals]
 };
@@ -63,10 +61,6 @@ struct WarpArgs {
   float* mask;
 };
 hipError_t launch_warp(const WarpArgs& a, hipStream_t s);
-// same computation with wx, wy read from and mask written to the solver's diag layout (fused TV path);
-// src must be the padded pyramid plane, dst stays row-major (the derivative stencils read it)
-hipError_t launch_warp_diag(const WarpArgs& a, hipStream_t s);
-
 // get_derivatives.  im1 as for WarpArgs.src; im2w packed planar [B][noc][h][w].
 // out [B][8][noc][h][w]
 struct DerivArgs {
@@ -74,18 +68,25 @@ struct DerivArgs {
   const float* im1;
   int im1_padded, pad, tmp_w, tmp_h;
   const float* im2w;
-  float* out;            // [B][8][noc][h][w] row-major, or [B][8][noc][w*h] diag when out_diag
-  int out_diag;
-  const float* mask_rm;  // with out_diag: row-major mask to be copied ...
-  float* mask_diag;      // ... into diag layout (may be null)
-  // fused image_warp (gray, out_diag, im1_padded): when warp_src is set, im2w is not read -- the second image is warped
-  // inside the kernel (opticalflow_aux.c:18-60, same arithmetic as warp_kernel) from the padded plane warp_src with the
-  // flow planes wx_diag / wy_diag (diag layout), and the warp's mask goes to mask_diag
-  const float* warp_src;
-  const float* wx_diag;
-  const float* wy_diag;
+  float* out;  // [B][8][noc][h][w] row-major
 };
 hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s);
+
+// image_warp + get_derivatives of the fused TV path in one row-marching kernel (ofdis_prep.hip): densified AoS flow and the
+// two padded gray planes in, the sdiag records of the fused TV kernel out (ofdis_dev.h: sdiag_index)
+struct PrepArgs {
+  TvGeom t;           // noc = 1
+  const float* im1;   // padded plane of the first image  [B][tmp_h][tmp_w]
+  const float* im2;   // padded plane of the second image
+  int pad, tmp_w, tmp_h;
+  const float* flow;  // AoS [B][h][w][2], row-major: the flow to warp with (wx, wy)
+  float* d8;          // [records][8] = Ix, Iz, Ixx, Ixz, Iy, Ixy, Iyz, Iyy; all zero where the warp's mask is zero
+  float* wrec;        // [records][2] = wx, wy
+  int S;              // frames per strip
+  int band_rows;      // output rows per wavefront (0 = chosen by the launcher from the batch size)
+};
+bool tv_prep_supported(const TvGeom& t);
+hipError_t launch_tv_prep(const PrepArgs& a, hipStream_t s);
 
 // compute_smoothness + compute_data + sub_laplacian x2 -> sys [B][7][w*h] in DIAG layout (ofdis_dev.h)
 struct SystemArgs {
@@ -112,17 +113,15 @@ struct SorArgs {
 };
 hipError_t launch_sor(const SorArgs& a, hipStream_t s);
 
-// One TV fixed-point iteration fused: compute_smoothness + compute_data + 2x sub_laplacian produce each
+// All fixed-point iterations of a level fused: compute_smoothness + compute_data + 2x sub_laplacian produce each
 // anti-diagonal's system coefficients in registers, immediately consumed by the wavefront SOR of
-// ofdis_sor.hip (h <= 64, gray).  Every plane in diag layout.
+// ofdis_sor.hip (h <= 64, gray).  Operands = the sdiag records of ofdis_prep.hip.
 struct FusedArgs {
   TvGeom t;
-  const float* derivs;  // [B][8][w*h]
-  const float* mask;    // [B][w*h]
-  const float* wx;      // [B][w*h]
-  const float* wy;
-  float* du;            // in/out
-  float* dv;
+  const float* d8;    // [records][8] derivatives (all zero where the warp's mask is zero)
+  const float* wrec;  // [records][2] wx, wy
+  float* uv;          // [records][2] du, dv (in/out; never read during the first iteration)
+  int S;              // frames per strip (divides t.nframes)
   float quarter_alpha, half_delta_over3, half_gamma_over3;
   int iterations;  // SOR sweeps per fixed-point iteration (tv_solverit)
   float omega;
@@ -130,18 +129,21 @@ struct FusedArgs {
   int total_frames;  // frames of the whole batch this launch is a part of (pipelined sub-batches); 0 = t.nframes
   // optional: AoS flow [B][h][w][2].  When the launcher picks a multi-wave variant it writes uu = wx + du, vv = wy + dv
   // of the last fixed-point iteration there itself (refine_variational.cpp:209-221, 92-99) instead of storing du, dv --
-  // tv_finish_kernel and its launch are then not needed; launch_tv_fused reports that through *wrote_flow.
+  // tv_finish is then not needed; launch_tv_fused reports that through *wrote_flow.
   float* flow_out;
+  int mw_max_groups;  // frame groups (workgroups) up to which the multi-wave variants are launched (0 = never)
+  int split;          // 0 = never the split (producer / solver wavefronts) variant of the multi-wave kernel
 };
 bool tv_fused_supported(const TvGeom& t, int iterations);
 // the fused kernel's trimmed divisions (ofdis_dev.h) need the three weights to be 0 or of ordinary magnitude
 bool tv_fused_params_ok(float quarter_alpha, float half_delta_over3, float half_gamma_over3);
+// 0 = one wavefront per strip group (throughput), 1 = a wavefront per fixed-point iteration, 2 = producer + solver each
+int tv_fused_mode(const FusedArgs& a);
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow = nullptr);
-// number of frame groups (workgroups) up to which the multi-wave (iteration-pipelined) variants are launched; < 0 restores
-// the default
-void set_tv_fused_mw_max(int waves);
-// 0 = never launch the split (producer / solver wavefronts) variant of the multi-wave kernel
-void set_tv_fused_split(int on);
+
+// uu = wx + du, vv = wy + dv (refine_variational.cpp:209-221, 92-99) in place: flow (AoS, row-major) holds wx, wy on entry
+// and the refined flow on return; uv = the fused kernel's du, dv records
+hipError_t launch_tv_finish_records(const TvGeom& t, float* flow_aos, const float* uv, int S, hipStream_t s);
 
 // layout conversion of `nplanes` planes of w x h (row-major <-> diag); used by the per-function entry
 // points, whose public interface is row-major
@@ -150,7 +152,7 @@ hipError_t launch_from_diag(const float* src_diag, float* dst_rm, int w, int h, 
 
 // uu=wx+du, vv=wy+dv -> AoS flow (refine_variational.cpp:209-221, 92-99); wx,wy row-major, du,dv DIAG
 hipError_t launch_tv_finish(const TvGeom& t, const float* wx, const float* wy, const float* du, const float* dv,
-                            float* flow_aos, int wxy_diag, hipStream_t s);
+                            float* flow_aos, hipStream_t s);
 // AoS flow -> planar wx, wy (refine_variational.cpp:56-68)
 hipError_t launch_flow_split(const TvGeom& t, const float* flow_aos, float* wx, float* wy, hipStream_t s);
 
@@ -187,10 +189,5 @@ struct DeSorArgs {
 hipError_t launch_de_sor(const DeSorArgs& a, hipStream_t s);
 hipError_t launch_de_update(const TvGeom& t, const float* wx, const float* du, float* uu, float* out, int camlr,
                             hipStream_t s);
-
-// test hook: out[i] = wave_sum over each consecutive group of 64 inputs (n multiple of 64)
-hipError_t launch_wave_sum_test(const float* in, float* out, int n, hipStream_t s);
-// test hook: out[4][n] = div_rn(a,b), a/b, sqrt_rn(|a|), sqrtf(|a|)
-hipError_t launch_div_sqrt_test(const float* a, const float* b, float* out, int n, hipStream_t s);
 
 }  // namespace ofdis

@@ -1,0 +1,339 @@
+// ofdis_prep.hip -- image_warp + get_derivatives of the fused TV path in ONE row-marching kernel
+//     image_warp        opticalflow_aux.c:18-60
+//     get_derivatives   opticalflow_aux.c:65-116 (+ image.c:401-434, 466-502)
+//
+// A wavefront owns whole image rows of its frame(s): lane = column (two adjacent columns per lane when 64 < w <= 128;
+// two / four frames per wavefront when w <= 32 / 16) and marches down the rows.  Per row r it
+//   stage 0   warps the second image at (x, r) with the densified flow, forms avg = 0.5 (I2w + I1) and Iz = I2w - I1,
+//             exchanges the row through LDS and takes the three HORIZONTAL 5-tap filters of that row (Ix, Ixz, then Ixx);
+//   stage 1   takes the VERTICAL filters centred on row r-2 (Iy, Ixy, Iyz) from five-row register windows of avg, Ix, Iz;
+//   stage 2   takes Iyy of row r-4 from the window of Iy.
+// Every pixel is warped once and every filter tap is a register or one LDS word: no tile halo is recomputed (the tiled
+// kernels of ofdis_tv.hip warp a pixel up to 1.9 times and spend ~440 instructions per pixel in warp + derivatives; this
+// one ~125).  The vertical filters never read outside the image -- the reference folds the border coefficients of the
+// first / last two rows (image.c:401-434) -- and the horizontal ones read replicated columns (image.c:466-502), which the
+// LDS row provides as two pad entries on each side.
+//
+// Output = the "sdiag" records the fused TV kernel walks (ofdis_dev.h: sdiag_index):
+//     d8  : { Ix, Iz, Ixx, Ixz, Iy, Ixy, Iyz, Iyy }, all zero where the warp's mask is zero
+//     wrec: { wx, wy }
+// The mask needs no storage of its own: it only ever multiplies the data term's weights (opticalflow_aux.c:352-427), and a
+// pixel whose eight derivatives are zero gets exactly the same +0 coefficients as one whose weights are zero (finite
+// images; ofdis_fused.hip data_term_gray).
+// A record of row y is complete at iteration y+4 (Ix, Iz wait in the register windows, Ixy / Iyz two iterations in delay
+// registers, Ixx / Ixz -- horizontal filters of rows that are still in the windows -- are taken then).  In the sdiag layout
+// the records of one image row are h records apart (lane = column here, lane = row in the consumer), so the wavefront
+// stages KD rows of records in LDS in diag order and then writes every diag row's KD consecutive records with
+// consecutive lanes: full sectors, contiguous runs.  (Storing each piece from the lane that computed it -- 16 + 12 + 4
+// bytes into a different cache line per lane -- was measured at 2.1 ms per 4096-pair step: partial-sector writes.)
+//
+// Small batches: the rows are cut into bands (one wavefront each) that recompute four rows of stage 0 and two of stage 1
+// either side, so that a handful of frames still spreads over the chip.
+#include <algorithm>
+#include <type_traits>
+
+#include "ofdis_kernels.h"
+#include "ofdis_tvmath.h"
+
+namespace ofdis {
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// image_warp of one gray pixel from the frame's padded plane (same expression order as warp_pixel, ofdis_tv.hip)
+__device__ __forceinline__ float warp_gray(const float* __restrict__ s, int tmp_w, int pad, int w, int h, int i, int j,
+                                           float fx, float fy, float& m) {
+  const float xx = i + fx;
+  const float yy = j + fy;
+  const int x = (int)floorf(xx), y = (int)floorf(yy);
+  const float dx = xx - (float)x, dy = yy - (float)y;
+  m = (xx >= 0 && xx <= (float)(w - 1) && yy >= 0 && yy <= (float)(h - 1)) ? 1.0f : 0.0f;
+  const int x1 = clampi(x, 0, w - 1) + pad, x2 = clampi(x + 1, 0, w - 1) + pad;
+  const int y1 = (clampi(y, 0, h - 1) + pad) * tmp_w, y2 = (clampi(y + 1, 0, h - 1) + pad) * tmp_w;
+  const float s11 = s[y1 + x1], s12 = s[y1 + x2], s21 = s[y2 + x1], s22 = s[y2 + x2];
+  return s11 * (1.0f - dx) * (1.0f - dy) + s12 * dx * (1.0f - dy) + s21 * (1.0f - dx) * dy + s22 * dx * dy;
+}
+
+// vertical 5-tap centred on an image row with the folded coefficients of the first / last two rows (image.c:401-434).
+// FORM: 0 = row 0, 1 = row 1, 2 = interior, 3 = row h-2, 4 = row h-1 (h >= 4: the four border rows are distinct); the row
+// is wave-uniform, so a stage picks the form once by scalar branches (vform) for all its filters
+template <int FORM>
+__device__ __forceinline__ float v5r(float m2, float m1, float s0, float p1, float p2) {
+  if (FORM == 0) return (D5_C0 + D5_C1 + D5_C2) * s0 + D5_C3 * p1 + D5_C4 * p2;
+  if (FORM == 1) return (D5_C0 + D5_C1) * m1 + D5_C2 * s0 + D5_C3 * p1 + D5_C4 * p2;
+  if (FORM == 3) return D5_C0 * m2 + D5_C1 * m1 + D5_C2 * s0 + (D5_C3 + D5_C4) * p1;
+  if (FORM == 4) return D5_C0 * m2 + D5_C1 * m1 + (D5_C2 + D5_C3 + D5_C4) * s0;
+  return D5_C0 * m2 + D5_C1 * m1 + D5_C2 * s0 + D5_C3 * p1 + D5_C4 * p2;
+}
+template <typename F>
+__device__ __forceinline__ void vform(int j, int h, F&& f) {
+  if (j == 0) f(std::integral_constant<int, 0>());
+  else if (j == 1) f(std::integral_constant<int, 1>());
+  else if (j == h - 2) f(std::integral_constant<int, 3>());
+  else if (j == h - 1) f(std::integral_constant<int, 4>());
+  else f(std::integral_constant<int, 2>());
+}
+__device__ __forceinline__ float h5r(float m2, float m1, float s0, float p1, float p2) {
+  return D5_C0 * m2 + D5_C1 * m1 + D5_C2 * s0 + D5_C3 * p1 + D5_C4 * p2;
+}
+
+constexpr int PREP_KD = 2;  // rows of derivative records staged before a flush (runs of KD * 32 bytes)
+constexpr int PREP_KW = 4;  // rows of (wx, wy) records staged before a flush (runs of KW * 8 bytes)
+
+// LDS per wavefront (one wavefront per block), in floats.  C = columns per lane.
+template <int C>
+struct PrepLds {
+  static constexpr int ROW = 64 * C + 16;  // one exchanged row: 64 lanes x C columns + 4 pads per frame segment (<= 4)
+  // staging: per frame (lpf * C + K - 1) diag rows x K records; the worst case over 1 / 2 / 4 frames per wavefront
+  static constexpr int nq(int lpf, int K) { return lpf * C + K - 1; }
+  static constexpr int STD = C == 2 ? nq(64, PREP_KD) * PREP_KD * 8 : 4 * nq(16, PREP_KD) * PREP_KD * 8;
+  static constexpr int STW = C == 2 ? nq(64, PREP_KW) * PREP_KW * 2 : 4 * nq(16, PREP_KW) * PREP_KW * 2;
+  static constexpr int TOTAL = 3 * ROW + STD + STW;
+};
+
+template <int C>
+__global__ __launch_bounds__(64) void tv_prep_kernel(const PrepArgs a, const int lpf_shift, const int nbands) {
+  using L = PrepLds<C>;
+  __shared__ __attribute__((aligned(16))) float lds[L::TOTAL];
+  const int lane = threadIdx.x;
+  const int w = a.t.w, h = a.t.h, S = a.S;
+  const int lpf = 1 << lpf_shift;     // lanes per frame
+  const int fpw = 64 >> lpf_shift;    // frames per wavefront
+  const int unit = blockIdx.x;
+  const int fg = unit / nbands, band = unit - fg * nbands;
+  const int fl = lane >> lpf_shift, li = lane & (lpf - 1);
+  int frame = fg * fpw + fl;
+  const bool fok = frame < a.t.nframes;
+  if (!fok) frame = a.t.nframes - 1;  // idle lane group: shadows the last frame, never flushed
+  const int yb0 = band * a.band_rows, yb1 = min(h, yb0 + a.band_rows);  // band_rows is a multiple of KW (launcher)
+  if (yb0 >= h) return;
+  const int r_begin = max(yb0 - 4, 0), r_s0end = min(yb1 + 4, h);  // rows of stage 0
+  const int y1lo = max(yb0 - 2, 0), y1hi = min(yb1 + 2, h);       // rows of stage 1
+  const int r_last = yb1 + 3;
+
+  const int seg = lpf * C + 4;  // floats of one frame's segment of an exchanged row
+  float* const rowA = lds + fl * seg;
+  float* const rowX = lds + L::ROW + fl * seg;
+  float* const rowZ = lds + 2 * L::ROW + fl * seg;
+  const int nqd = L::nq(lpf, PREP_KD), nqw = L::nq(lpf, PREP_KW);  // diag rows a frame's staged block touches
+  float* const stD = lds + 3 * L::ROW;       // [frame of the wavefront][q][k][8]
+  float* const stW = stD + L::STD;           // [frame of the wavefront][q][k][2]
+  float* const stDf = stD + fl * nqd * PREP_KD * 8;
+  float* const stWf = stW + fl * nqw * PREP_KW * 2;
+  const int e0 = 2 + li * C;  // LDS entry of this lane's first column
+
+  int xc[C];
+  const int rw = S * w;
+#pragma unroll
+  for (int k = 0; k < C; ++k) xc[k] = min(li * C + k, w - 1);  // columns beyond the image replicate the last one
+  const int sg0 = (fg * fpw) / S;  // first strip this wavefront touches: the buffer resources are based there
+  const size_t strip_recs = (size_t)rw * h;
+  const int nstrips = (a.t.nframes + S - 1) / S;
+  const unsigned span = (unsigned)min(nstrips - sg0, fpw + 1);  // strips reachable from sg0
+  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.d8 + (size_t)sg0 * strip_recs * 8), 0, (int)(span * strip_recs * 32), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.wrec + (size_t)sg0 * strip_recs * 2), 0, (int)(span * strip_recs * 8), 0x00020000);
+  const float* __restrict__ p1 = a.im1 + (size_t)frame * a.tmp_w * a.tmp_h + a.pad * a.tmp_w + a.pad;  // pixel (0,0)
+  const float* __restrict__ p2 = a.im2 + (size_t)frame * a.tmp_w * a.tmp_h;
+  const float2* __restrict__ pf = reinterpret_cast<const float2*>(a.flow) + (size_t)frame * w * h;
+
+  // Flush of a staged block (rows y0 .. y0+K-1 of every frame of this wavefront): the block's records sit in LDS as
+  // [q][k] with q = x + k (mod w when S = 1: the diag rows of a frame wrap onto themselves), i.e. in diag order; lane e
+  // copies the e-th 16- (8-) byte piece, consecutive lanes = consecutive bytes of one diag row's run.
+  auto flush = [&](auto kc, auto bytes_c, const float* st, const __amdgpu_buffer_rsrc_t& rs, int nq, int y0, int yend) {
+    constexpr int K = decltype(kc)::value, RB = decltype(bytes_c)::value;  // rows per block, record bytes
+    constexpr int PB = RB >= 16 ? 16 : 8;                                 // piece bytes per lane
+    constexpr int PPR = RB / PB;                                          // pieces per record
+    for (int f = 0; f < fpw; ++f) {
+      const int fr = fg * fpw + f;
+      if (fr >= a.t.nframes) break;
+      const int sgf = fr / S, fsf = fr - sgf * S;
+      const int dbase = (fsf * w + y0) % rw;
+      const int recbase = (sgf - sg0) * rw * h + y0;
+      const float* stf = st + f * nq * K * (RB / 4);
+      const int nqv = S == 1 ? w : w + K - 1;  // diag rows the block touches (S = 1: they wrap onto the frame's own w rows)
+      for (int e = lane; e < nqv * K * PPR; e += 64) {
+        const int piece = e % PPR, k = (e / PPR) % K, q = e / (PPR * K);
+        int x = q - k;
+        if (S == 1 && x < 0) x += w;
+        int d = dbase + q;
+        if (d >= rw) d -= rw;
+        if (x >= 0 && x < w && y0 + k < yend) {
+          const int byte = (recbase + d * h + k) * RB + piece * PB;
+          if constexpr (PB == 16) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stf + e * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte, 0, 0);
+          } else {
+            const u32x2 v = *reinterpret_cast<const u32x2*>(stf + e * 2);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rs, byte, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  // One image row through LDS for the horizontal filters: entry 2 + c = column c, two entries replicating column 0 before and
+  // two replicating column w - 1 after (image.c:466-502).  Lanes whose columns lie beyond the image write nothing.
+  auto put_row = [&](float* row, const float (&v)[C]) {
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const int c = li * C + k;
+      if (c < w) row[2 + c] = v[k];
+      if (c == w - 1) row[2 + w] = row[3 + w] = v[k];
+    }
+    if (li == 0) row[0] = row[1] = v[0];
+  };
+  // staging position of column x in block row k
+  auto stq = [&](int x, int k) { int q = x + k; if (S == 1 && q >= w) q -= w; return q; };
+
+  float A[5][C], Z[5][C], IX[5][C], IY[5][C];
+  float ixy1[C], ixy2[C], iyz1[C], iyz2[C];  // Ixy, Iyz of rows r-3 and r-4 at stage 2 (computed at stage 1, two iterations before)
+  unsigned mbits[C];                          // bit j = warp mask of row r-j
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) A[q][k] = Z[q][k] = IX[q][k] = IY[q][k] = 0.0f;
+    ixy1[k] = ixy2[k] = iyz1[k] = iyz2[k] = 0.0f;
+    mbits[k] = 0;
+  }
+
+  for (int rb = r_begin; rb <= r_last; rb += 5) {
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int r = rb + u;  // wave-uniform
+      if (r > r_last) break;
+      // ------------------------------------------------------------------ stage 0: row r
+      if (r < r_s0end) {
+        float fx[C], fy[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const float2 f = pf[r * w + xc[k]];
+          const float i1 = p1[r * a.tmp_w + xc[k]];
+          fx[k] = f.x; fy[k] = f.y;
+          float m;
+          const float i2 = warp_gray(p2, a.tmp_w, a.pad, w, h, xc[k], r, f.x, f.y, m);
+          mbits[k] = (mbits[k] << 1) | (m != 0.0f ? 1u : 0u);
+          A[u][k] = 0.5f * (i2 + i1);
+          Z[u][k] = i2 - i1;
+        }
+        // the row through LDS: entries 2 .. 2 + lpf*C - 1 = columns, two replicated pads either side
+        put_row(rowA, A[u]);
+        if (r >= yb0 && r < yb1) {  // (wx, wy) of this row into its staging block
+          const int kk = (r - yb0) % PREP_KW;
+#pragma unroll
+          for (int k = 0; k < C; ++k)
+            if (li * C + k < w) *reinterpret_cast<float2*>(stWf + (stq(xc[k], kk) * PREP_KW + kk) * 2) = make_float2(fx[k], fy[k]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+          const float al0 = rowA[e0 - 2], al1 = rowA[e0 - 1], ar0 = rowA[e0 + C], ar1 = rowA[e0 + C + 1];
+          if constexpr (C == 1) {
+            IX[u][0] = h5r(al0, al1, A[u][0], ar0, ar1);
+          } else {
+            IX[u][0] = h5r(al0, al1, A[u][0], A[u][1], ar0);
+            IX[u][1] = h5r(al1, A[u][0], A[u][1], ar0, ar1);
+            // a second column beyond the image replicates column w - 1 like avg and Iz do (they are computed at clamped
+            // coordinates): the next filter reads it from this register
+            if (li * 2 + 1 >= w) IX[u][1] = IX[u][0];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();  // later writes of these rows come after the reads
+        if (r >= yb0 && r < yb1 && ((r - yb0) % PREP_KW == PREP_KW - 1 || r == yb1 - 1)) {
+          const int y0 = r - (r - yb0) % PREP_KW;
+          flush(std::integral_constant<int, PREP_KW>(), std::integral_constant<int, 8>(), stW, rsW, nqw, y0, yb1);
+          __builtin_amdgcn_wave_barrier();
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < C; ++k) mbits[k] <<= 1;
+      }
+      // ------------------------------------------------------------------ stage 1: row y1 = r - 2 (windows: rows r-4 .. r)
+      const int y1 = r - 2;
+      float ixyn[C], iyzn[C];  // Ixy, Iyz of row r-2: they enter the delay registers at the end of the iteration
+#pragma unroll
+      for (int k = 0; k < C; ++k) ixyn[k] = iyzn[k] = 0.0f;
+      if (y1 >= y1lo && y1 < y1hi) {
+        vform(y1, h, [&](auto form) {
+          constexpr int F = decltype(form)::value;
+#pragma unroll
+          for (int k = 0; k < C; ++k) {
+            IY[(u + 3) % 5][k] = v5r<F>(A[(u + 1) % 5][k], A[(u + 2) % 5][k], A[(u + 3) % 5][k], A[(u + 4) % 5][k], A[u][k]);
+            ixyn[k] = v5r<F>(IX[(u + 1) % 5][k], IX[(u + 2) % 5][k], IX[(u + 3) % 5][k], IX[(u + 4) % 5][k], IX[u][k]);
+            iyzn[k] = v5r<F>(Z[(u + 1) % 5][k], Z[(u + 2) % 5][k], Z[(u + 3) % 5][k], Z[(u + 4) % 5][k], Z[u][k]);
+          }
+        });
+      }
+      // ------------------------------------------------------------------ stage 2: row y2 = r - 4: the record is complete
+      const int y2 = r - 4;
+      if (y2 >= yb0 && y2 < yb1) {
+        const int o = (u + 1) % 5;  // ring slot of row r-4 (a constant after unrolling)
+        // horizontal filters of Ix and Iz of row y2 (the rows are still in the windows)
+        put_row(rowX, IX[o]);
+        put_row(rowZ, Z[o]);
+        __builtin_amdgcn_wave_barrier();
+        float ixx[C], ixz[C], iyy[C];
+        {
+          const float xl0 = rowX[e0 - 2], xl1 = rowX[e0 - 1], xr0 = rowX[e0 + C], xr1 = rowX[e0 + C + 1];
+          const float zl0 = rowZ[e0 - 2], zl1 = rowZ[e0 - 1], zr0 = rowZ[e0 + C], zr1 = rowZ[e0 + C + 1];
+          if constexpr (C == 1) {
+            ixx[0] = h5r(xl0, xl1, IX[o][0], xr0, xr1);
+            ixz[0] = h5r(zl0, zl1, Z[o][0], zr0, zr1);
+          } else {
+            ixx[0] = h5r(xl0, xl1, IX[o][0], IX[o][1], xr0);
+            ixx[1] = h5r(xl1, IX[o][0], IX[o][1], xr0, xr1);
+            ixz[0] = h5r(zl0, zl1, Z[o][0], Z[o][1], zr0);
+            ixz[1] = h5r(zl1, Z[o][0], Z[o][1], zr0, zr1);
+          }
+        }
+        vform(y2, h, [&](auto form) {
+          constexpr int F = decltype(form)::value;
+#pragma unroll
+          for (int k = 0; k < C; ++k)
+            iyy[k] = v5r<F>(IY[(u + 4) % 5][k], IY[u][k], IY[(u + 1) % 5][k], IY[(u + 2) % 5][k], IY[(u + 3) % 5][k]);
+        });
+        const int kk = (y2 - yb0) % PREP_KD;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          if (li * C + k < w) {
+            const bool on = (mbits[k] >> 4) & 1u;  // the warp mask of row r-4
+            float* dst = stDf + (stq(xc[k], kk) * PREP_KD + kk) * 8;
+            *reinterpret_cast<float4*>(dst) =
+                on ? make_float4(IX[o][k], Z[o][k], ixx[k], ixz[k]) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            *reinterpret_cast<float4*>(dst + 4) =
+                on ? make_float4(IY[o][k], ixy2[k], iyz2[k], iyy[k]) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (kk == PREP_KD - 1 || y2 == yb1 - 1) {
+          flush(std::integral_constant<int, PREP_KD>(), std::integral_constant<int, 32>(), stD, rsD, nqd, y2 - kk, yb1);
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < C; ++k) { ixy2[k] = ixy1[k]; iyz2[k] = iyz1[k]; ixy1[k] = ixyn[k]; iyz1[k] = iyzn[k]; }
+    }
+  }
+}
+
+bool tv_prep_supported(const TvGeom& t) { return t.noc == 1 && t.w >= 16 && t.w <= 128 && t.h >= 4 && t.h <= 64; }
+
+hipError_t launch_tv_prep(const PrepArgs& a_in, hipStream_t s) {
+  if (!tv_prep_supported(a_in.t) || a_in.S < 1) return hipErrorInvalidValue;
+  PrepArgs a = a_in;
+  const int w = a.t.w, h = a.t.h;
+  const int lpf_shift = w > 32 ? 6 : (w > 16 ? 5 : 4);
+  const int fpw = 64 >> lpf_shift;
+  const int fgroups = (a.t.nframes + fpw - 1) / fpw;
+  // bands: enough wavefronts for ~2 per SIMD (1024 SIMDs), at least 8 output rows each, a multiple of the staging blocks
+  int nbands = a.band_rows > 0 ? (h + a.band_rows - 1) / a.band_rows : (2048 + fgroups - 1) / fgroups;
+  nbands = std::max(1, std::min(nbands, (h + 7) / 8));
+  a.band_rows = (((h + nbands - 1) / nbands + PREP_KW - 1) / PREP_KW) * PREP_KW;
+  nbands = (h + a.band_rows - 1) / a.band_rows;
+  const long long units = (long long)fgroups * nbands;
+  const dim3 g((unsigned)units), b(64);
+  if (w > 64) hipLaunchKernelGGL(tv_prep_kernel<2>, g, b, 0, s, a, lpf_shift, nbands);
+  else hipLaunchKernelGGL(tv_prep_kernel<1>, g, b, 0, s, a, lpf_shift, nbands);
+  return hipGetLastError();
+}
+
+}  // namespace ofdis

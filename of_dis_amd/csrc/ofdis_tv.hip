@@ -126,96 +126,8 @@ hipError_t launch_warp(const WarpArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-// Tile variant for the fused TV path: wx, wy arrive in the diag layout (written by the densify kernel) and
-// the mask leaves in it.  A 32x32 tile is gathered through LDS with the rotated enumeration (contiguous runs
-// on the global side, conflict-free on the LDS side), processed row-major 4 px per thread so that the
-// bilinear taps stay local and the warped image is stored with 16-byte writes, and the mask is
-// transposed back through LDS.
-template <int NOC>
-__global__ __launch_bounds__(256) void warp_diag_kernel(const WarpArgs a) {
-  constexpr int TW = 32, TH = 32;
-  __shared__ __attribute__((aligned(16))) float wx_t[TH * TW];
-  __shared__ __attribute__((aligned(16))) float wy_t[TH * TW];
-  __shared__ __attribute__((aligned(16))) float m_t[TH * TW];
-  const int w = a.t.w, h = a.t.h;
-  constexpr int noc = NOC;
-  const int npx = w * h;
-  const int tiles_x = (w + TW - 1) / TW;
-  int frame, tile;
-  xcd_frame_map(blockIdx.x, tiles_x * ((h + TH - 1) / TH), a.t.nframes, frame, tile);
-  if (frame >= a.t.nframes) return;
-  const int tx = tile % tiles_x, ty = tile / tiles_x;
-  const int x0 = tx * TW, y0 = ty * TH;
-  const size_t fo = (size_t)frame * npx;
-  for (int n = threadIdx.x; n < TH * TW; n += 256) {
-    const int ry = n % TH, r = n / TH;
-    const int rx = (r - ry) & (TW - 1);
-    const int y = y0 + ry, x = x0 + rx;
-    float fx = 0.0f, fy = 0.0f;
-    if (y < h && x < w) {
-      const size_t o = fo + diag_index(x, y, w, h);
-      fx = a.wx[o];
-      fy = a.wy[o];
-    }
-    wx_t[ry * TW + rx] = fx;
-    wy_t[ry * TW + rx] = fy;
-  }
-  __syncthreads();
-  {
-    const int ry = threadIdx.x >> 3, q4 = (threadIdx.x & 7) * 4;
-    const int y = y0 + ry, x = x0 + q4;
-    if (y < h && x < w) {
-      const float4 fx = *reinterpret_cast<const float4*>(&wx_t[ry * TW + q4]);
-      const float4 fy = *reinterpret_cast<const float4*>(&wy_t[ry * TW + q4]);
-      const float fxs[4] = {fx.x, fx.y, fx.z, fx.w}, fys[4] = {fy.x, fy.y, fy.z, fy.w};
-      float m[4], r[4][3];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        m[k] = 0.0f;
-        r[k][0] = r[k][1] = r[k][2] = 0.0f;
-        if (x + k < w) warp_pixel<true, NOC>(a, frame, x + k, y, fxs[k], fys[k], m[k], r[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) m_t[ry * TW + q4 + k] = m[k];
-#pragma unroll
-      for (int c = 0; c < noc; ++c) {
-        float* d = a.dst + ((size_t)frame * noc + c) * npx + (size_t)y * w + x;
-        if (x + 3 < w && (w & 3) == 0) {
-          *reinterpret_cast<float4*>(d) = make_float4(r[0][c], r[1][c], r[2][c], r[3][c]);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (x + k < w) d[k] = r[k][c];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int n = threadIdx.x; n < TH * TW; n += 256) {
-    const int ry = n % TH, r = n / TH;
-    const int rx = (r - ry) & (TW - 1);
-    const int y = y0 + ry, x = x0 + rx;
-    if (y < h && x < w) a.mask[fo + diag_index(x, y, w, h)] = m_t[ry * TW + rx];
-  }
-}
-
-hipError_t launch_warp_diag(const WarpArgs& a, hipStream_t s) {
-  if (!a.src_padded) return hipErrorInvalidValue;
-  const int tiles = ((a.t.w + 31) / 32) * ((a.t.h + 31) / 32);
-  if (a.t.noc == 1) hipLaunchKernelGGL(warp_diag_kernel<1>, dim3(((a.t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, a);
-  else if (a.t.noc == 3) hipLaunchKernelGGL(warp_diag_kernel<3>, dim3(((a.t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, a);
-  else return hipErrorInvalidValue;
-  return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------ derivatives
-// 5-tap derivative filter of refine_variational.cpp:45-46 through convolve_extract_coeffs(even=0)
-// (image.c:338-349): coeffs = { 1/12, -8/12, -0, 8/12, -1/12 }
-#define D5_C0 (1.0f / 12.0f)
-#define D5_C1 (-8.0f / 12.0f)
-#define D5_C2 (-0.0f)
-#define D5_C3 (-(-8.0f / 12.0f))
-#define D5_C4 (-(1.0f / 12.0f))
+// (the 5-tap derivative filter coefficients D5_C* live in ofdis_tvmath.h)
 
 constexpr int DT_W = 32, DT_H = 16;         // output tile
 constexpr int DA_W = DT_W + 8, DA_H = DT_H + 8;  // avg / Iz tile (halo 4)
@@ -238,20 +150,15 @@ __device__ __forceinline__ float v5(const float* t, int pitch, int qy, int qx, i
   return D5_C0 * m2 + D5_C1 * m1 + D5_C2 * s0 + D5_C3 * p1 + D5_C4 * p2;
 }
 
-// WARP (fused TV path, gray): the warped second image is not read from memory but computed here, on the tile and its
-// halo, from the padded plane and the diag-layout flow planes -- image_warp folded into get_derivatives' first stage.
-// Removes the warped image's round trip through HBM and one launch per level; the halo pixels are warped by up to four
-// neighbouring tiles (x1.9 of the warp's arithmetic, about 45 instructions per pixel against this kernel's ~350).
-template <bool PADDED, bool DIAG, bool WARP>
+// (The fused TV path has its own warp + derivatives kernel, ofdis_prep.hip; this tiled one serves RGB / tall levels and
+// the per-function entry point.)
+template <bool PADDED>
 __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
-  constexpr int IN_FLOATS = 2 * DA_H * DA_W + 2 * DX_H * DX_W + (WARP ? DT_H * DT_W : 0);
-  constexpr int OUT_FLOATS = DIAG ? 9 * DT_H * DT_W : 0;  // staging for the diag transposition (8 planes + mask)
-  __shared__ float lds[IN_FLOATS > OUT_FLOATS ? IN_FLOATS : OUT_FLOATS];
+  __shared__ float lds[2 * DA_H * DA_W + 2 * DX_H * DX_W];
   float* avg_t = lds;
   float* iz_t = avg_t + DA_H * DA_W;
   float* ix_t = iz_t + DA_H * DA_W;
   float* iy_t = ix_t + DX_H * DX_W;
-  float* mask_t = iy_t + DX_H * DX_W;  // WARP: the warp's mask on the output tile
   const int w = a.t.w, h = a.t.h, noc = a.t.noc;
   const int npx = w * h;
   const int tiles_x = (w + DT_W - 1) / DT_W;
@@ -264,38 +171,17 @@ __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
 
   for (int c = 0; c < noc; ++c) {
     // stage 0: avg = 0.5*(im2w + im1), Iz = im2w - im1 on tile + halo 4, at border-clamped coordinates
-    if constexpr (WARP) {
-      // rotated enumeration (consecutive lanes walk an anti-diagonal of the halo tile: contiguous runs of the diag-layout
-      // flow planes); one channel
-      WarpArgs wa;
-      wa.t = a.t; wa.src = a.warp_src; wa.src_padded = 1; wa.pad = a.pad; wa.tmp_w = a.tmp_w; wa.tmp_h = a.tmp_h;
-      for (int n = tid; n < DA_H * DA_W; n += 256) {
-        const int qy = n % DA_H;
-        int qx = n / DA_H - qy;
-        if (qx < 0) qx += DA_W;
-        const int yy = y0 + qy - 4, xx = x0 + qx - 4;
-        const int y = clampi(yy, 0, h - 1), x = clampi(xx, 0, w - 1);
-        const size_t dg = (size_t)frame * npx + diag_index(x, y, w, h);
-        const float i1 = a.im1[(size_t)frame * a.tmp_w * a.tmp_h + (size_t)(y + a.pad) * a.tmp_w + x + a.pad];
-        float m, i2[3];
-        warp_pixel<true, 1>(wa, frame, x, y, a.wx_diag[dg], a.wy_diag[dg], m, i2);
-        avg_t[qy * DA_W + qx] = 0.5f * (i2[0] + i1);
-        iz_t[qy * DA_W + qx] = i2[0] - i1;
-        if (qy >= 4 && qy < 4 + DT_H && qx >= 4 && qx < 4 + DT_W) mask_t[(qy - 4) * DT_W + qx - 4] = m;
-      }
-    } else {
-      for (int n = tid; n < DA_H * DA_W; n += 256) {
-        const int qy = n / DA_W, qx = n - qy * DA_W;
-        const int y = clampi(y0 + qy - 4, 0, h - 1), x = clampi(x0 + qx - 4, 0, w - 1);
-        float i1;
-        if (PADDED)
-          i1 = a.im1[(size_t)frame * a.tmp_w * a.tmp_h * noc + ((size_t)(y + a.pad) * a.tmp_w + x + a.pad) * noc + c];
-        else
-          i1 = a.im1[((size_t)frame * noc + c) * npx + y * w + x];
-        const float i2 = a.im2w[((size_t)frame * noc + c) * npx + y * w + x];
-        avg_t[n] = 0.5f * (i2 + i1);
-        iz_t[n] = i2 - i1;
-      }
+    for (int n = tid; n < DA_H * DA_W; n += 256) {
+      const int qy = n / DA_W, qx = n - qy * DA_W;
+      const int y = clampi(y0 + qy - 4, 0, h - 1), x = clampi(x0 + qx - 4, 0, w - 1);
+      float i1;
+      if (PADDED)
+        i1 = a.im1[(size_t)frame * a.tmp_w * a.tmp_h * noc + ((size_t)(y + a.pad) * a.tmp_w + x + a.pad) * noc + c];
+      else
+        i1 = a.im1[((size_t)frame * noc + c) * npx + y * w + x];
+      const float i2 = a.im2w[((size_t)frame * noc + c) * npx + y * w + x];
+      avg_t[n] = 0.5f * (i2 + i1);
+      iz_t[n] = i2 - i1;
     }
     __syncthreads();
     // stage 1: Ix = d/dx avg, Iy = d/dy avg on tile + halo 2.  An entry outside the image holds the
@@ -310,69 +196,31 @@ __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
     __syncthreads();
     // stage 2: the eight derivative values of this thread's (two) pixels
     constexpr int NPIX = DT_W * DT_H / 256;
-    float res[NPIX][8];
     const int qx = tid % DT_W;
 #pragma unroll
     for (int k = 0; k < NPIX; ++k) {
       const int ry = tid / DT_W + k * (256 / DT_W);
-      const int y = clampi(y0 + ry, 0, h - 1);   // rows/columns beyond the image are computed on clamped
+      const int yc = clampi(y0 + ry, 0, h - 1);  // rows/columns beyond the image are computed on clamped
       const int ey = ry + 2, ex = qx + 2;        // coordinates and never stored
       const int ay = ry + 4, ax = qx + 4;
-      res[k][0] = ix_t[ey * DX_W + ex];
-      res[k][1] = iy_t[ey * DX_W + ex];
-      res[k][2] = iz_t[ay * DA_W + ax];
-      res[k][3] = h5(ix_t, DX_W, ey, ex);
-      res[k][4] = v5(ix_t, DX_W, ey, ex, y, h);
-      res[k][5] = v5(iy_t, DX_W, ey, ex, y, h);
-      res[k][6] = h5(iz_t, DA_W, ay, ax);
-      res[k][7] = v5(iz_t, DA_W, ay, ax, y, h);
+      float res[8];
+      res[0] = ix_t[ey * DX_W + ex];
+      res[1] = iy_t[ey * DX_W + ex];
+      res[2] = iz_t[ay * DA_W + ax];
+      res[3] = h5(ix_t, DX_W, ey, ex);
+      res[4] = v5(ix_t, DX_W, ey, ex, yc, h);
+      res[5] = v5(iy_t, DX_W, ey, ex, yc, h);
+      res[6] = h5(iz_t, DA_W, ay, ax);
+      res[7] = v5(iz_t, DA_W, ay, ax, yc, h);
+      const int y = y0 + ry, x = x0 + qx;
+      if (y < h && x < w) {
+        float* out = a.out + ((size_t)frame * 8 * noc + c) * npx + y * w + x;
+        const size_t ks = (size_t)noc * npx;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) out[q * ks] = res[q];
+      }
     }
-    float mk[NPIX];  // WARP: this thread's mask values, read before the staging area overwrites the input tiles
-#pragma unroll
-    for (int k = 0; k < NPIX; ++k) mk[k] = WARP ? mask_t[(tid / DT_W + k * (256 / DT_W)) * DT_W + qx] : 0.0f;
-    if (!DIAG) {
-#pragma unroll
-      for (int k = 0; k < NPIX; ++k) {
-        const int ry = tid / DT_W + k * (256 / DT_W);
-        const int y = y0 + ry, x = x0 + qx;
-        if (y < h && x < w) {
-          float* out = a.out + ((size_t)frame * 8 * noc + c) * npx + y * w + x;
-          const size_t ks = (size_t)noc * npx;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) out[q * ks] = res[k][q];
-        }
-      }
-      __syncthreads();
-    } else {
-      __syncthreads();  // input tiles dead: the LDS becomes the staging area [plane][ry][qx]
-#pragma unroll
-      for (int k = 0; k < NPIX; ++k) {
-        const int ry = tid / DT_W + k * (256 / DT_W);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) lds[(q * DT_H + ry) * DT_W + qx] = res[k][q];
-        if (c == 0 && a.mask_diag) {
-          const int y = y0 + ry, x = x0 + qx;
-          if (WARP) lds[(8 * DT_H + ry) * DT_W + qx] = mk[k];
-          else lds[(8 * DT_H + ry) * DT_W + qx] = (y < h && x < w) ? a.mask_rm[(size_t)frame * npx + y * w + x] : 0.0f;
-        }
-      }
-      __syncthreads();
-      // rotated enumeration: consecutive lanes walk an anti-diagonal of the tile = a contiguous diag run
-      for (int n = tid; n < DT_H * DT_W; n += 256) {
-        const int ry = n % DT_H, r = n / DT_H;
-        const int rx = (r - ry) & (DT_W - 1);
-        const int y = y0 + ry, x = x0 + rx;
-        if (y < h && x < w) {
-          const size_t dg = diag_index(x, y, w, h);
-          float* out = a.out + ((size_t)frame * 8 * noc + c) * npx + dg;
-          const size_t ks = (size_t)noc * npx;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) out[q * ks] = lds[(q * DT_H + ry) * DT_W + rx];
-          if (c == 0 && a.mask_diag) a.mask_diag[(size_t)frame * npx + dg] = lds[(8 * DT_H + ry) * DT_W + rx];
-        }
-      }
-      __syncthreads();
-    }
+    __syncthreads();
   }
 }
 
@@ -380,16 +228,8 @@ hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s) {
   if (a.t.h < 4) return hipErrorInvalidValue;  // the reference's vertical filter reads rows 0..3
   const int tiles = ((a.t.w + DT_W - 1) / DT_W) * ((a.t.h + DT_H - 1) / DT_H);
   const dim3 g(((a.t.nframes + 7) / 8) * 8 * tiles), b(256);
-  if (a.warp_src) {
-    if (!a.out_diag || !a.im1_padded || a.t.noc != 1 || !a.wx_diag || !a.wy_diag || !a.mask_diag) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((derivatives_kernel<true, true, true>), g, b, 0, s, a);
-  } else if (a.out_diag) {
-    if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true, true, false>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((derivatives_kernel<false, true, false>), g, b, 0, s, a);
-  } else {
-    if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true, false, false>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((derivatives_kernel<false, false, false>), g, b, 0, s, a);
-  }
+  if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((derivatives_kernel<false>), g, b, 0, s, a);
   return hipGetLastError();
 }
 
@@ -548,7 +388,6 @@ hipError_t launch_tv_system(const SystemArgs& a, hipStream_t s) {
 // uu = wx + du, vv = wy + dv -> AoS flow.  du/dv live in the solver's diag layout: a 32x32 tile is
 // gathered through LDS with the rotated enumeration (contiguous runs on the global side), then
 // written row-major as float2.
-template <bool WXY_DIAG>
 __global__ __launch_bounds__(256) void tv_finish_kernel(int w, int h, int nframes, const float* wx, const float* wy,
                                                         const float* du, const float* dv, float2* flow) {
   constexpr int TW = 32, TH = 32;
@@ -568,13 +407,8 @@ __global__ __launch_bounds__(256) void tv_finish_kernel(int w, int h, int nframe
     const int y = y0 + ry, x = x0 + rx;
     if (y < h && x < w) {
       const size_t o = fo + diag_index(x, y, w, h);
-      if (WXY_DIAG) {  // the sum is formed here, where all four operands are contiguous runs
-        du_t[ry * TW + rx] = wx[o] + du[o];
-        dv_t[ry * TW + rx] = wy[o] + dv[o];
-      } else {
-        du_t[ry * TW + rx] = du[o];
-        dv_t[ry * TW + rx] = dv[o];
-      }
+      du_t[ry * TW + rx] = du[o];
+      dv_t[ry * TW + rx] = dv[o];
     }
   }
   __syncthreads();
@@ -583,22 +417,52 @@ __global__ __launch_bounds__(256) void tv_finish_kernel(int w, int h, int nframe
     const int y = y0 + ry, x = x0 + qx;
     if (y < h && x < w) {
       const size_t o = fo + (size_t)y * w + x;
-      if (WXY_DIAG)
-        flow[o] = make_float2(du_t[ry * TW + qx], dv_t[ry * TW + qx]);
-      else
-        flow[o] = make_float2(wx[o] + du_t[ry * TW + qx], wy[o] + dv_t[ry * TW + qx]);
+      flow[o] = make_float2(wx[o] + du_t[ry * TW + qx], wy[o] + dv_t[ry * TW + qx]);
     }
   }
 }
 hipError_t launch_tv_finish(const TvGeom& t, const float* wx, const float* wy, const float* du, const float* dv,
-                            float* flow_aos, int wxy_diag, hipStream_t s) {
+                            float* flow_aos, hipStream_t s) {
   const int tiles = ((t.w + 31) / 32) * ((t.h + 31) / 32);
-  if (wxy_diag)
-    hipLaunchKernelGGL(tv_finish_kernel<true>, dim3(((t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, t.w, t.h, t.nframes, wx, wy, du, dv,
-                       reinterpret_cast<float2*>(flow_aos));
-  else
-    hipLaunchKernelGGL(tv_finish_kernel<false>, dim3(((t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, t.w, t.h, t.nframes, wx, wy, du, dv,
-                       reinterpret_cast<float2*>(flow_aos));
+  hipLaunchKernelGGL(tv_finish_kernel, dim3(((t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, t.w, t.h, t.nframes, wx, wy,
+                     du, dv, reinterpret_cast<float2*>(flow_aos));
+  return hipGetLastError();
+}
+
+// The fused path's variant: the densified flow (wx, wy) already sits in the output array, du / dv are the fused kernel's
+// sdiag records (ofdis_dev.h): uu = wx + du, vv = wy + dv in place.
+__global__ __launch_bounds__(256) void tv_finish_records_kernel(int w, int h, int nframes, int S, float2* flow,
+                                                                const float2* __restrict__ uv) {
+  constexpr int TW = 32, TH = 32;
+  __shared__ float2 t[TH * TW];
+  const int npx = w * h;
+  const int tiles_x = (w + TW - 1) / TW;
+  int frame, tile;
+  xcd_frame_map(blockIdx.x, tiles_x * ((h + TH - 1) / TH), nframes, frame, tile);
+  if (frame >= nframes) return;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int x0 = tx * TW, y0 = ty * TH;
+  for (int n = threadIdx.x; n < TH * TW; n += 256) {  // rotated enumeration: contiguous runs of a diag row
+    const int ry = n % TH, r = n / TH;
+    const int rx = (r - ry) & (TW - 1);
+    const int y = y0 + ry, x = x0 + rx;
+    if (y < h && x < w) t[ry * TW + rx] = uv[sdiag_index(frame, x, y, w, h, S)];
+  }
+  __syncthreads();
+  const int qx = threadIdx.x % TW;
+  for (int ry = threadIdx.x / TW; ry < TH; ry += 256 / TW) {
+    const int y = y0 + ry, x = x0 + qx;
+    if (y < h && x < w) {
+      const size_t o = (size_t)frame * npx + (size_t)y * w + x;
+      const float2 f = flow[o], d = t[ry * TW + qx];
+      flow[o] = make_float2(f.x + d.x, f.y + d.y);
+    }
+  }
+}
+hipError_t launch_tv_finish_records(const TvGeom& t, float* flow_aos, const float* uv, int S, hipStream_t s) {
+  const int tiles = ((t.w + 31) / 32) * ((t.h + 31) / 32);
+  hipLaunchKernelGGL(tv_finish_records_kernel, dim3(((t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, t.w, t.h, t.nframes,
+                     S, reinterpret_cast<float2*>(flow_aos), reinterpret_cast<const float2*>(uv));
   return hipGetLastError();
 }
 

@@ -9,6 +9,13 @@ namespace ofdis {
 #define D3_C0 (-0.5f)
 #define D3_C1 (-0.0f)
 #define D3_C2 (0.5f)
+// 5-tap derivative filter of refine_variational.cpp:45-46 through convolve_extract_coeffs(even=0)
+// (image.c:338-349): coeffs = { 1/12, -8/12, -0, 8/12, -1/12 }
+#define D5_C0 (1.0f / 12.0f)
+#define D5_C1 (-8.0f / 12.0f)
+#define D5_C2 (-0.0f)
+#define D5_C3 (-(-8.0f / 12.0f))
+#define D5_C4 (-(1.0f / 12.0f))
 #define EPS_SMOOTH (0.001f * 0.001f)
 #define EPS_COLOR (0.001f * 0.001f)
 #define EPS_GRAD (0.001f * 0.001f)

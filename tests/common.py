@@ -10,6 +10,41 @@ from of_dis_amd.params import oppoint
 _f32 = np.float32
 
 
+def testhooks():
+    """The TEST library (tests/csrc/ofdis_testhooks.hip, built by of_dis_amd.build next to the product): device kernels
+    around the header-only helpers of ofdis_dev.h.  Not part of the shipped library."""
+    import ctypes as C
+    from of_dis_amd import build
+    path = build.testhooks_path()
+    if not __import__("os").path.exists(path):
+        build.build()
+    L = C.CDLL(path)
+    VP = C.c_void_p
+    L.ofdis_test_wave_sum.argtypes = [VP, VP, C.c_int, VP]
+    L.ofdis_test_div_sqrt.argtypes = [VP, VP, VP, C.c_int, VP]
+    L.ofdis_test_outlier_sq.restype = C.c_float
+    L.ofdis_test_outlier_sq.argtypes = [C.c_float]
+    return L
+
+
+def wave_sum_test(gpu, x):
+    x = np.ascontiguousarray(x, _f32)
+    d, o = gpu.Dev(x), gpu.Dev(nbytes=x.nbytes)
+    assert testhooks().ofdis_test_wave_sum(d.ptr, o.ptr, x.size, None) == 0
+    gpu.check(gpu.lib().ofdis_sync(None))
+    return o.get(x.shape)
+
+
+def div_sqrt_test(gpu, a, b):
+    """Rows: div_rn(a,b), a/b, sqrt_rn(|a|), sqrtf(|a|), the fused TV kernel's quotient a/b, its quotient b / sqrt(|a|),
+    computed on the device (ofdis_dev.h)."""
+    a, b = np.ascontiguousarray(a, _f32), np.ascontiguousarray(b, _f32)
+    da, db, o = gpu.Dev(a), gpu.Dev(b), gpu.Dev(nbytes=6 * a.nbytes)
+    assert testhooks().ofdis_test_div_sqrt(da.ptr, db.ptr, o.ptr, a.size, None) == 0
+    gpu.check(gpu.lib().ofdis_sync(None))
+    return o.get((6, a.size))
+
+
 @functools.lru_cache(maxsize=16)
 def synth_case(width, height, seed=1234, channels=1, op_point=2, usetvref=None):
     """Returns (params, pyr_a[img,dx,dy], pyr_b[img,dx,dy], gt_flow, (ia, ib)) for a synthetic pair."""

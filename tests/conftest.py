@@ -47,9 +47,7 @@ def tv_variant(gpu, request):
     frame group; a workgroup with one wavefront per iteration; the same with each iteration divided between a producer and
     a solver wavefront (the small-batch variants the launcher would pick by itself for these test sizes, the split one
     up to 6 iterations).  Bit-identical results are required of all."""
-    L = gpu.lib()
-    L.ofdis_test_set_fused_mw_max(0 if request.param == "single-wave" else 1 << 30)
-    L.ofdis_test_set_fused_split(1 if request.param == "multi-wave-split" else 0)
+    old = gpu.set_tuning(fused_mw_max=0 if request.param == "single-wave" else 1 << 30,
+                         fused_split=1 if request.param == "multi-wave-split" else 0)
     yield request.param
-    L.ofdis_test_set_fused_mw_max(-1)
-    L.ofdis_test_set_fused_split(1)
+    gpu.restore_tuning(old)

@@ -270,18 +270,17 @@ def test_rgb_flow_bit_exact(gpu, orc):
 
 
 @pytest.mark.parametrize("size,cost", [((320, 240), 1), ((320, 240), 0), ((203, 131), 1)])
-def test_rgb_two_patches_per_wavefront(gpu, orc, monkeypatch, size, cost):
-    """OFDIS_RGB12_LPP=32: the RGB 12x12 patch kernel with two patches per wavefront (32 lanes each, two accumulation
-    chains per lane standing for the lanes l and l + 32 of the one-patch mapping) gives the same bits -- also with an odd
-    patch count per frame (one half of the last wavefront idle)."""
-    monkeypatch.setenv("OFDIS_RGB12_LPP", "32")
-    gpu.lib().ofdis_flow_cache_clear()
+def test_rgb_two_patches_per_wavefront(gpu, orc, size, cost):
+    """ofdis_tuning.rgb12_lpp = 32: the RGB 12x12 patch kernel with two patches per wavefront (32 lanes each, two
+    accumulation chains per lane standing for the lanes l and l + 32 of the one-patch mapping) gives the same bits -- also
+    with an odd patch count per frame (one half of the last wavefront idle)."""
+    old = gpu.set_tuning(rgb12_lpp=32)
     p, pa, pb, _, _ = synth_case(size[0], size[1], 78, 3, 3, 1)
     p = p.copy(costfct=cost, max_iter=8, min_iter=3)
     try:
         assert_bits_equal(gpu.flow(p, pa[0], pa[1], pa[2], pb[0]), orc.flow(p, pa[0], pa[1], pa[2], pb[0]), "rgb, 2 patches per wave")
     finally:
-        gpu.lib().ofdis_flow_cache_clear()
+        gpu.restore_tuning(old)
 
 
 @pytest.mark.parametrize("cost", [1, 2])
@@ -503,17 +502,54 @@ def test_kernel_selection_does_not_change_results(gpu, orc, nfr):
     b.close()
 
 
-@pytest.mark.parametrize("env", ["OFDIS_NO_GRAY8", "OFDIS_NO_FUSED", "OFDIS_NO_WARP_FUSION"])
-def test_fallback_kernels_at_the_benchmark_geometry(gpu, orc, monkeypatch, env):
-    """The generic patch kernel (8 lanes per patch), the unfused TV path (tiled system kernel + wavefront SOR) and the
-    stand-alone diag-layout warp kernel (large batches; small ones warp inside the derivatives kernel) must give the same
-    bits as the kernels they stand in for; the switches exist for this test."""
-    monkeypatch.setenv(env, "1")
-    gpu.lib().ofdis_flow_cache_clear()   # a cached drop-in context was created (and sized) without the switch
+@pytest.mark.parametrize("knob", ["gray8", "fused_tv", "finish_fusion"])
+def test_fallback_kernels_at_the_benchmark_geometry(gpu, orc, knob):
+    """The generic patch kernel (8 lanes per patch), the unfused TV path (tiled warp / derivatives / system kernels +
+    wavefront SOR) and the separate finish kernel after a multi-wave fused TV launch must give the same bits as the kernels
+    they stand in for (ofdis_tuning, include/ofdis.h)."""
+    old = gpu.set_tuning(**{knob: 0})
     p, pa, pb, _, _ = synth_case(1024, 436, 1600, 1, 2, 1)
     try:
         for rep in range(3):
             got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
-            assert_bits_equal(got, orc.flow(p, pa[0], pa[1], pa[2], pb[0]), f"{env}=1, call {rep}")
+            assert_bits_equal(got, orc.flow(p, pa[0], pa[1], pa[2], pb[0]), f"{knob}=0, call {rep}")
     finally:
-        gpu.lib().ofdis_flow_cache_clear()
+        gpu.restore_tuning(old)
+
+
+@pytest.mark.parametrize("nfr,strip", [(8, 2), (16, 4), (24, 8), (6, 2), (7, 2)])
+@pytest.mark.parametrize("size", [(256, 128), (1024, 436)])
+def test_fused_tv_strips(gpu, orc, nfr, strip, size):
+    """Strips: S frames side by side as one image of S*w columns for the throughput fused TV kernel (the fill / drain of
+    the skewed sweep once per strip).  A frame's bits must not depend on S, on its position in the strip, or on the
+    frames it shares the strip with; a frame count S does not divide falls back to S = 1."""
+    w, h = size
+    cases = [synth_case(w, h, 2300 + k, 1, 2, 1) for k in range(3)]
+    p = cases[0][0]
+    refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
+    old = gpu.set_tuning(fused_mw_max=0, fused_strip=strip)
+    try:
+        b = gpu.Batch(p, nfr)
+        for l in range(p.sc_l, p.sc_f + 1):               # slot s holds frame (s * s + s // 3) % 3: neighbours vary
+            for kind in range(4):
+                planes = [c[1][kind][l] if kind < 3 else c[2][0][l] for c in cases]
+                b.set_input(l, kind, np.stack([planes[(s * s + s // 3) % 3] for s in range(nfr)]))
+        b.run()
+        out = b.download_all()
+        for s in range(nfr):
+            assert_bits_equal(out[s], refs[(s * s + s // 3) % 3], f"{nfr} frames, strips of {strip}, slot {s}")
+        b.close()
+    finally:
+        gpu.restore_tuning(old)
+
+
+@pytest.mark.parametrize("band", [8, 11, 64])
+def test_prep_kernel_row_bands(gpu, orc, band):
+    """The warp + derivatives kernel cut into row bands (small batches: more wavefronts; each band recomputes its margins)
+    gives the same records as one wavefront marching the whole frame."""
+    old = gpu.set_tuning(prep_band_rows=band)
+    p, pa, pb, _, _ = synth_case(1024, 436, 1601, 1, 2, 1)
+    try:
+        assert_bits_equal(gpu.flow(p, pa[0], pa[1], pa[2], pb[0]), orc.flow(p, pa[0], pa[1], pa[2], pb[0]), f"band rows {band}")
+    finally:
+        gpu.restore_tuning(old)

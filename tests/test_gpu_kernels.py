@@ -7,7 +7,7 @@ is switched to the 64-lane butterfly reduction order the kernels use.
 import numpy as np
 import pytest
 
-from common import assert_bits_equal, rand_planes, synth_case
+from common import assert_bits_equal, div_sqrt_test, rand_planes, synth_case, wave_sum_test
 
 pytestmark = pytest.mark.gpu
 _f32 = np.float32
@@ -19,7 +19,7 @@ _SEED_OFFSET = int(__import__("os").environ.get("OFDIS_TEST_SEED_OFFSET", "0"))
 def test_wave_sum_order(gpu, orc):
     rng = np.random.default_rng(0)
     x = (rng.standard_normal((37, 64)) * 100).astype(_f32)
-    got = gpu.wave_sum_test(x)
+    got = wave_sum_test(gpu, x)
     for r in range(x.shape[0]):
         part = x[r].copy()
         o = 1
@@ -47,7 +47,7 @@ def test_trimmed_div_sqrt(gpu):
     b[:100] = np.tile(edge, 10)
     a[100:108] = [0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 0.0]
     b[100:108] = [3.0, 3.0, 2.0, 2.0, 2.0, np.inf, 0.0, 0.0]
-    got = gpu.div_sqrt_test(a, b)
+    got = div_sqrt_test(gpu, a, b)
     with np.errstate(all="ignore"):
         q = (a / b).astype(_f32)
         r = np.sqrt(np.abs(a)).astype(_f32)
@@ -55,22 +55,15 @@ def test_trimmed_div_sqrt(gpu):
                        ("sqrt vs compiler", got[2], got[3]), ("sqrt vs numpy", got[2], r)]:
         same = (x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y))
         assert same.all(), (name, int((~same).sum()), a[~same][:4], b[~same][:4], x[~same][:4], y[~same][:4])
-    # the fused TV kernel's quotient (reciprocal by integer seed + Newton steps instead of v_rcp_f32, no v_div_fixup):
-    # finite numerators and normal finite denominators only; compared by value (a zero may carry the other sign)
+    # the fused TV kernel's quotient (shared refined reciprocal, no v_div_fixup): finite numerators and normal finite
+    # denominators only; compared by value (a zero may carry the other sign)
     fin = np.isfinite(a) & np.isfinite(b) & (b != 0)
     assert np.array_equal(got[4][fin], q[fin]), int((got[4][fin] != q[fin]).sum())
-    with np.errstate(all="ignore"):
-        rr = (np.float32(1.0) / b).astype(_f32)
-    off = got[5][fin] != rr[fin]  # rcp_newton is the correctly rounded reciprocal up to rare 1-ulp cases
-    assert off.mean() < 1e-5, off.mean()
-    assert np.all(np.abs(got[5][fin].view(np.int32) - rr[fin].view(np.int32)) <= 1)
-    # square root without v_sqrt_f32, and the quotient by it (reciprocal seeded with the root's by-product)
-    pos = np.isfinite(a) & (np.abs(a) >= 2.0 ** -96)
-    assert np.array_equal(got[6][pos], r[pos]), int((got[6][pos] != r[pos]).sum())
-    both = pos & np.isfinite(b)
+    # ... and its quotient by a root
+    pos = np.isfinite(a) & (np.abs(a) >= 2.0 ** -96) & np.isfinite(b)
     with np.errstate(all="ignore"):
         qs = (b / r).astype(_f32)
-    assert np.array_equal(got[7][both], qs[both]), int((got[7][both] != qs[both]).sum())
+    assert np.array_equal(got[5][pos], qs[pos]), int((got[5][pos] != qs[pos]).sum())
 
 
 @pytest.mark.parametrize("w,h,noc", [(128, 56, 1), (64, 28, 1), (32, 14, 1), (30, 17, 3), (67, 33, 1), (5, 4, 1)])
