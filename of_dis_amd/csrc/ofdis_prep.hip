@@ -2,8 +2,9 @@
 //     image_warp        opticalflow_aux.c:18-60
 //     get_derivatives   opticalflow_aux.c:65-116 (+ image.c:401-434, 466-502)
 //
-// A wavefront owns whole image rows of its frame(s): lane = column (two adjacent columns per lane when 64 < w <= 128;
-// two / four frames per wavefront when w <= 32 / 16) and marches down the rows.  Per row r it
+// A wavefront owns whole image rows of its frame(s): lane = column (two wavefronts side by side when 64 < w <= 128, sharing
+// the exchanged rows and the staging area; two / four frames per wavefront when w <= 32 / 16) and marches down the rows.
+// Per row r it
 //   stage 0   warps the second image at (x, r) with the densified flow, forms avg = 0.5 (I2w + I1) and Iz = I2w - I1,
 //             exchanges the row through LDS and takes the three HORIZONTAL 5-tap filters of that row (Ix, Ixz, then Ixx);
 //   stage 1   takes the VERTICAL filters centred on row r-2 (Iy, Ixy, Iyz) from five-row register windows of avg, Ix, Iz;
@@ -40,17 +41,27 @@ namespace ofdis {
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// image_warp of one gray pixel from the frame's padded plane (same expression order as warp_pixel, ofdis_tv.hip)
-__device__ __forceinline__ float warp_gray(const float* __restrict__ s, int tmp_w, int pad, int w, int h, int i, int j,
-                                           float fx, float fy, float& m) {
+// image_warp of one gray pixel (opticalflow_aux.c:18-60; same expression order as warp_pixel, ofdis_tv.hip) in two halves
+// so that the taps of the NEXT row are in flight while this row is filtered: warp_taps() turns the flow into the mask, the
+// fractions and the four element offsets within the padded plane, warp_mix() is the bilinear combination.
+struct WarpTaps {
+  float dx, dy, m;
+  int o11, o12, o21, o22;
+};
+__device__ __forceinline__ WarpTaps warp_taps(int tmp_w, int pad, int w, int h, int i, int j, float fx, float fy) {
+  WarpTaps t;
   const float xx = i + fx;
   const float yy = j + fy;
   const int x = (int)floorf(xx), y = (int)floorf(yy);
-  const float dx = xx - (float)x, dy = yy - (float)y;
-  m = (xx >= 0 && xx <= (float)(w - 1) && yy >= 0 && yy <= (float)(h - 1)) ? 1.0f : 0.0f;
+  t.dx = xx - (float)x;
+  t.dy = yy - (float)y;
+  t.m = (xx >= 0 && xx <= (float)(w - 1) && yy >= 0 && yy <= (float)(h - 1)) ? 1.0f : 0.0f;
   const int x1 = clampi(x, 0, w - 1) + pad, x2 = clampi(x + 1, 0, w - 1) + pad;
   const int y1 = (clampi(y, 0, h - 1) + pad) * tmp_w, y2 = (clampi(y + 1, 0, h - 1) + pad) * tmp_w;
-  const float s11 = s[y1 + x1], s12 = s[y1 + x2], s21 = s[y2 + x1], s22 = s[y2 + x2];
+  t.o11 = y1 + x1; t.o12 = y1 + x2; t.o21 = y2 + x1; t.o22 = y2 + x2;
+  return t;
+}
+__device__ __forceinline__ float warp_mix(float s11, float s12, float s21, float s22, float dx, float dy) {
   return s11 * (1.0f - dx) * (1.0f - dy) + s12 * dx * (1.0f - dy) + s21 * (1.0f - dx) * dy + s22 * dx * dy;
 }
 
@@ -78,27 +89,39 @@ __device__ __forceinline__ float h5r(float m2, float m1, float s0, float p1, flo
 }
 
 constexpr int PREP_KD = 2;  // rows of derivative records staged before a flush (runs of KD * 32 bytes)
-constexpr int PREP_KW = 4;  // rows of (wx, wy) records staged before a flush (runs of KW * 8 bytes)
+constexpr int PREP_KW = 8;  // rows of (wx, wy) records staged before a flush (runs of KW * 8 bytes)
+// (measured at 4096 pairs, ms per step of this kernel: KD = 1 / 2 / 4: 1.17 / 0.79 / 0.76, KW = 4 / 8: 0.79 / 0.70 --
+// the run length of the stores is what it is most sensitive to; profiles/README.md r03_b)
 
-// LDS per wavefront (one wavefront per block), in floats.  C = columns per lane.
-template <int C>
+// LDS per block, in floats.  WPF = wavefronts per frame (= per block): 1 (w <= 64; up to four frames in the wavefront) or 2.
+template <int WPF>
 struct PrepLds {
-  static constexpr int ROW = 64 * C + 16;  // one exchanged row: 64 lanes x C columns + 4 pads per frame segment (<= 4)
-  // staging: per frame (lpf * C + K - 1) diag rows x K records; the worst case over 1 / 2 / 4 frames per wavefront
-  static constexpr int nq(int lpf, int K) { return lpf * C + K - 1; }
-  static constexpr int STD = C == 2 ? nq(64, PREP_KD) * PREP_KD * 8 : 4 * nq(16, PREP_KD) * PREP_KD * 8;
-  static constexpr int STW = C == 2 ? nq(64, PREP_KW) * PREP_KW * 2 : 4 * nq(16, PREP_KW) * PREP_KW * 2;
+  static constexpr int ROW = 64 * WPF + 16;  // one exchanged row: the block's columns + 4 pads per frame segment (<= 4)
+  // staging: per frame (lpf + K - 1) diag rows x K records; the worst case over 1 / 2 / 4 frames per wavefront
+  static constexpr int nq(int lpf, int K) { return lpf + K - 1; }
+  static constexpr int STD = WPF == 2 ? nq(128, PREP_KD) * PREP_KD * 8 : 4 * nq(16, PREP_KD) * PREP_KD * 8;
+  static constexpr int STW = WPF == 2 ? nq(128, PREP_KW) * PREP_KW * 2 : 4 * nq(16, PREP_KW) * PREP_KW * 2;
   static constexpr int TOTAL = 3 * ROW + STD + STW;
 };
 
-template <int C>
-__global__ __launch_bounds__(64) void tv_prep_kernel(const PrepArgs a, const int lpf_shift, const int nbands) {
-  using L = PrepLds<C>;
+// LDS hand-over between the lanes of a frame's row: within one wavefront the LDS pipeline keeps program order, so a
+// scheduling barrier is enough; two wavefronts need a workgroup barrier -- one that only drains the LDS counter
+// (__syncthreads() would also wait for vmcnt(0), i.e. for the row and tap loads that are deliberately kept in flight).
+template <int WPF>
+__device__ __forceinline__ void prep_sync() {
+  if (WPF == 1) __builtin_amdgcn_wave_barrier();
+  else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int WPF>
+__global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, const int lpf_shift, const int nbands) {
+  constexpr int C = 1;  // columns per lane
+  using L = PrepLds<WPF>;
   __shared__ __attribute__((aligned(16))) float lds[L::TOTAL];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x;       // lane of the block
   const int w = a.t.w, h = a.t.h, S = a.S;
-  const int lpf = 1 << lpf_shift;     // lanes per frame
-  const int fpw = 64 >> lpf_shift;    // frames per wavefront
+  const int lpf = 1 << lpf_shift;     // lanes per frame: 128 (WPF = 2), else 64 / 32 / 16
+  const int fpw = WPF == 2 ? 1 : (64 >> lpf_shift);  // frames per block
   const int unit = blockIdx.x;
   const int fg = unit / nbands, band = unit - fg * nbands;
   const int fl = lane >> lpf_shift, li = lane & (lpf - 1);
@@ -134,33 +157,55 @@ __global__ __launch_bounds__(64) void tv_prep_kernel(const PrepArgs a, const int
       (void*)(a.d8 + (size_t)sg0 * strip_recs * 8), 0, (int)(span * strip_recs * 32), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(a.wrec + (size_t)sg0 * strip_recs * 2), 0, (int)(span * strip_recs * 8), 0x00020000);
-  const float* __restrict__ p1 = a.im1 + (size_t)frame * a.tmp_w * a.tmp_h + a.pad * a.tmp_w + a.pad;  // pixel (0,0)
-  const float* __restrict__ p2 = a.im2 + (size_t)frame * a.tmp_w * a.tmp_h;
-  const float2* __restrict__ pf = reinterpret_cast<const float2*>(a.flow) + (size_t)frame * w * h;
+  // inputs through buffer resources based at the wavefront's first frame: per-lane offsets are constants (frame, column),
+  // the row is a scalar offset
+  const int f0 = fg * fpw, nfr = min(fpw, a.t.nframes - f0), flc = frame - f0;  // (flc: idle lane groups shadow a frame)
+  const int plane = a.tmp_w * a.tmp_h;
+  const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.flow + (size_t)f0 * w * h * 2), 0, nfr * w * h * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.im1 + (size_t)f0 * plane), 0, nfr * plane * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.im2 + (size_t)f0 * plane), 0, nfr * plane * 4, 0x00020000);
+  int voF[C], voI[C];
+  const int voT = flc * plane * 4;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    voF[k] = (flc * w * h + xc[k]) * 8;
+    voI[k] = (flc * plane + a.pad * a.tmp_w + a.pad + xc[k]) * 4;
+  }
+  auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
 
   // Flush of a staged block (rows y0 .. y0+K-1 of every frame of this wavefront): the block's records sit in LDS as
-  // [q][k] with q = x + k (mod w when S = 1: the diag rows of a frame wrap onto themselves), i.e. in diag order; lane e
-  // copies the e-th 16- (8-) byte piece, consecutive lanes = consecutive bytes of one diag row's run.
+  // [q][k] with q = x + k (mod w when S = 1: the diag rows of a frame wrap onto themselves), i.e. in diag order, so piece e
+  // of the staging array goes to byte (e mod K*PPR) * PB of the run of diag row dbase + e / (K*PPR): consecutive lanes =
+  // consecutive bytes.
   auto flush = [&](auto kc, auto bytes_c, const float* st, const __amdgpu_buffer_rsrc_t& rs, int nq, int y0, int yend) {
     constexpr int K = decltype(kc)::value, RB = decltype(bytes_c)::value;  // rows per block, record bytes
     constexpr int PB = RB >= 16 ? 16 : 8;                                 // piece bytes per lane
     constexpr int PPR = RB / PB;                                          // pieces per record
+    constexpr int RUN = K * PPR;                                          // pieces per diag row (a power of two)
+    const bool full = y0 + K <= yend;                                     // (uniform) every row of the block exists
+    const int nqv = S == 1 ? w : w + K - 1;  // diag rows the block touches (S = 1: they wrap onto the frame's own w rows)
     for (int f = 0; f < fpw; ++f) {
-      const int fr = fg * fpw + f;
+      const int fr = f0 + f;
       if (fr >= a.t.nframes) break;
       const int sgf = fr / S, fsf = fr - sgf * S;
       const int dbase = (fsf * w + y0) % rw;
-      const int recbase = (sgf - sg0) * rw * h + y0;
+      const int base = ((sgf - sg0) * rw * h + y0) * RB;
       const float* stf = st + f * nq * K * (RB / 4);
-      const int nqv = S == 1 ? w : w + K - 1;  // diag rows the block touches (S = 1: they wrap onto the frame's own w rows)
-      for (int e = lane; e < nqv * K * PPR; e += 64) {
-        const int piece = e % PPR, k = (e / PPR) % K, q = e / (PPR * K);
-        int x = q - k;
-        if (S == 1 && x < 0) x += w;
+      for (int e = lane; e < nqv * RUN; e += 64 * WPF) {
+        const int q = e / RUN, lo = e % RUN;
         int d = dbase + q;
         if (d >= rw) d -= rw;
-        if (x >= 0 && x < w && y0 + k < yend) {
-          const int byte = (recbase + d * h + k) * RB + piece * PB;
+        bool ok = true;
+        if (S != 1 || !full) {
+          const int k = lo / PPR;
+          const int x = q - k;
+          ok = (S == 1 || (x >= 0 && x < w)) && y0 + k < yend;
+        }
+        if (ok) {
+          const int byte = base + d * (h * RB) + lo * PB;
           if constexpr (PB == 16) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(stf + e * 4);
             __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte, 0, 0);
@@ -197,6 +242,50 @@ __global__ __launch_bounds__(64) void tv_prep_kernel(const PrepArgs a, const int
     mbits[k] = 0;
   }
 
+  // Software pipeline of stage 0's memory accesses: at iteration r the flow and first-image values of row r+2 are requested,
+  // the taps of row r+1 (whose flow arrived during the previous iteration) are requested, and row r is combined from the
+  // taps requested one iteration ago -- every load has a whole iteration of filter arithmetic to arrive.
+  // Rows beyond the last stage-0 row are requested at the clamped row index and never used.
+  struct Pend {  // a row whose flow is known
+    float fx, fy, i1;
+  };
+  Pend nxt[C], cur[C];     // row r+1 (flow arrived, taps requested), row r (taps arriving)
+  WarpTaps tp[C];          // fractions / mask of row r
+  float t11[C], t12[C], t21[C], t22[C];  // taps of row r
+  unsigned lf0[C], lf1[C], li1[C];       // raw flow / image values of the row requested last (row r+2 after the request)
+  auto request_row = [&](int row) {      // flow + first image of `row`
+    const int rr = min(row, h - 1);
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const auto f = __builtin_amdgcn_raw_buffer_load_b64(rsF, voF[k], rr * w * 8, 0);
+      const unsigned q0 = f[0], q1 = f[1];
+      lf0[k] = q0; lf1[k] = q1;
+      li1[k] = __builtin_amdgcn_raw_buffer_load_b32(rsI, voI[k], rr * a.tmp_w * 4, 0);
+    }
+  };
+  auto request_taps = [&](int row) {  // from nxt (row `row`): tap addresses, fractions, mask; the four loads
+    const int rr = min(row, h - 1);
+    WarpTaps t[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) t[k] = warp_taps(a.tmp_w, a.pad, w, h, xc[k], rr, nxt[k].fx, nxt[k].fy);
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      t11[k] = asf(__builtin_amdgcn_raw_buffer_load_b32(rsT, voT + t[k].o11 * 4, 0, 0));
+      t12[k] = asf(__builtin_amdgcn_raw_buffer_load_b32(rsT, voT + t[k].o12 * 4, 0, 0));
+      t21[k] = asf(__builtin_amdgcn_raw_buffer_load_b32(rsT, voT + t[k].o21 * 4, 0, 0));
+      t22[k] = asf(__builtin_amdgcn_raw_buffer_load_b32(rsT, voT + t[k].o22 * 4, 0, 0));
+      tp[k] = t[k];
+    }
+  };
+  // prologue: row r_begin's taps and row r_begin+1's flow in flight
+  request_row(r_begin);
+#pragma unroll
+  for (int k = 0; k < C; ++k) nxt[k] = Pend{asf(lf0[k]), asf(lf1[k]), asf(li1[k])};
+  request_taps(r_begin);
+#pragma unroll
+  for (int k = 0; k < C; ++k) cur[k] = nxt[k];
+  request_row(r_begin + 1);
+
   for (int rb = r_begin; rb <= r_last; rb += 5) {
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
@@ -206,16 +295,20 @@ __global__ __launch_bounds__(64) void tv_prep_kernel(const PrepArgs a, const int
       if (r < r_s0end) {
         float fx[C], fy[C];
 #pragma unroll
-        for (int k = 0; k < C; ++k) {
-          const float2 f = pf[r * w + xc[k]];
-          const float i1 = p1[r * a.tmp_w + xc[k]];
-          fx[k] = f.x; fy[k] = f.y;
-          float m;
-          const float i2 = warp_gray(p2, a.tmp_w, a.pad, w, h, xc[k], r, f.x, f.y, m);
-          mbits[k] = (mbits[k] << 1) | (m != 0.0f ? 1u : 0u);
-          A[u][k] = 0.5f * (i2 + i1);
-          Z[u][k] = i2 - i1;
+        for (int k = 0; k < C; ++k) {  // row r from the taps requested one iteration ago
+          fx[k] = cur[k].fx; fy[k] = cur[k].fy;
+          const float i2 = warp_mix(t11[k], t12[k], t21[k], t22[k], tp[k].dx, tp[k].dy);
+          mbits[k] = (mbits[k] << 1) | (tp[k].m != 0.0f ? 1u : 0u);
+          A[u][k] = 0.5f * (i2 + cur[k].i1);
+          Z[u][k] = i2 - cur[k].i1;
         }
+        // the flow of row r+1 has arrived: its taps; then the flow of row r+2
+#pragma unroll
+        for (int k = 0; k < C; ++k) nxt[k] = Pend{asf(lf0[k]), asf(lf1[k]), asf(li1[k])};
+        request_taps(r + 1);
+#pragma unroll
+        for (int k = 0; k < C; ++k) cur[k] = nxt[k];
+        request_row(r + 2);
         // the row through LDS: entries 2 .. 2 + lpf*C - 1 = columns, two replicated pads either side
         put_row(rowA, A[u]);
         if (r >= yb0 && r < yb1) {  // (wx, wy) of this row into its staging block
@@ -224,7 +317,7 @@ __global__ __launch_bounds__(64) void tv_prep_kernel(const PrepArgs a, const int
           for (int k = 0; k < C; ++k)
             if (li * C + k < w) *reinterpret_cast<float2*>(stWf + (stq(xc[k], kk) * PREP_KW + kk) * 2) = make_float2(fx[k], fy[k]);
         }
-        __builtin_amdgcn_wave_barrier();
+        prep_sync<WPF>();
         {
           const float al0 = rowA[e0 - 2], al1 = rowA[e0 - 1], ar0 = rowA[e0 + C], ar1 = rowA[e0 + C + 1];
           if constexpr (C == 1) {
@@ -237,12 +330,11 @@ __global__ __launch_bounds__(64) void tv_prep_kernel(const PrepArgs a, const int
             if (li * 2 + 1 >= w) IX[u][1] = IX[u][0];
           }
         }
-        __builtin_amdgcn_wave_barrier();  // later writes of these rows come after the reads
         if (r >= yb0 && r < yb1 && ((r - yb0) % PREP_KW == PREP_KW - 1 || r == yb1 - 1)) {
-          const int y0 = r - (r - yb0) % PREP_KW;
+          const int y0 = r - (r - yb0) % PREP_KW;  // (the block's last write was before the barrier above)
           flush(std::integral_constant<int, PREP_KW>(), std::integral_constant<int, 8>(), stW, rsW, nqw, y0, yb1);
-          __builtin_amdgcn_wave_barrier();
         }
+        // (the next writes of rowA and of the (wx, wy) staging come after a barrier of stage 2 or the one at the end)
       } else {
 #pragma unroll
         for (int k = 0; k < C; ++k) mbits[k] <<= 1;
@@ -270,7 +362,7 @@ __global__ __launch_bounds__(64) void tv_prep_kernel(const PrepArgs a, const int
         // horizontal filters of Ix and Iz of row y2 (the rows are still in the windows)
         put_row(rowX, IX[o]);
         put_row(rowZ, Z[o]);
-        __builtin_amdgcn_wave_barrier();
+        prep_sync<WPF>();
         float ixx[C], ixz[C], iyy[C];
         {
           const float xl0 = rowX[e0 - 2], xl1 = rowX[e0 - 1], xr0 = rowX[e0 + C], xr1 = rowX[e0 + C + 1];
@@ -303,11 +395,14 @@ __global__ __launch_bounds__(64) void tv_prep_kernel(const PrepArgs a, const int
                 on ? make_float4(IY[o][k], ixy2[k], iyz2[k], iyy[k]) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           }
         }
-        __builtin_amdgcn_wave_barrier();
+        prep_sync<WPF>();
         if (kk == PREP_KD - 1 || y2 == yb1 - 1) {
           flush(std::integral_constant<int, PREP_KD>(), std::integral_constant<int, 32>(), stD, rsD, nqd, y2 - kk, yb1);
-          __builtin_amdgcn_wave_barrier();
+          prep_sync<WPF>();
         }
+      }
+      else {
+        prep_sync<WPF>();  // (no stage 2 in this iteration: stage 0's LDS reads before the next iteration's writes)
       }
 #pragma unroll
       for (int k = 0; k < C; ++k) { ixy2[k] = ixy1[k]; iyz2[k] = iyz1[k]; ixy1[k] = ixyn[k]; iyz1[k] = iyzn[k]; }
@@ -321,8 +416,8 @@ hipError_t launch_tv_prep(const PrepArgs& a_in, hipStream_t s) {
   if (!tv_prep_supported(a_in.t) || a_in.S < 1) return hipErrorInvalidValue;
   PrepArgs a = a_in;
   const int w = a.t.w, h = a.t.h;
-  const int lpf_shift = w > 32 ? 6 : (w > 16 ? 5 : 4);
-  const int fpw = 64 >> lpf_shift;
+  const int lpf_shift = w > 64 ? 7 : (w > 32 ? 6 : (w > 16 ? 5 : 4));
+  const int fpw = w > 64 ? 1 : (64 >> lpf_shift);
   const int fgroups = (a.t.nframes + fpw - 1) / fpw;
   // bands: enough wavefronts for ~2 per SIMD (1024 SIMDs), at least 8 output rows each, a multiple of the staging blocks
   int nbands = a.band_rows > 0 ? (h + a.band_rows - 1) / a.band_rows : (2048 + fgroups - 1) / fgroups;
@@ -330,9 +425,8 @@ hipError_t launch_tv_prep(const PrepArgs& a_in, hipStream_t s) {
   a.band_rows = (((h + nbands - 1) / nbands + PREP_KW - 1) / PREP_KW) * PREP_KW;
   nbands = (h + a.band_rows - 1) / a.band_rows;
   const long long units = (long long)fgroups * nbands;
-  const dim3 g((unsigned)units), b(64);
-  if (w > 64) hipLaunchKernelGGL(tv_prep_kernel<2>, g, b, 0, s, a, lpf_shift, nbands);
-  else hipLaunchKernelGGL(tv_prep_kernel<1>, g, b, 0, s, a, lpf_shift, nbands);
+  if (w > 64) hipLaunchKernelGGL(tv_prep_kernel<2>, dim3((unsigned)units), dim3(128), 0, s, a, lpf_shift, nbands);
+  else hipLaunchKernelGGL(tv_prep_kernel<1>, dim3((unsigned)units), dim3(64), 0, s, a, lpf_shift, nbands);
   return hipGetLastError();
 }
 
