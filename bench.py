@@ -29,7 +29,10 @@ The JSON carries, besides the contract fields:
   small_batch       64 pairs per step on one GPU (the per-GPU share of configs[4] at 8 GPUs)
   dropin_latency    ofdis_flow(): one pair per call, host pyramids in, host flow out
   e2e               secondary scope: 8-bit frames in HBM -> pyramids -> flow -> full-resolution flow in HBM
+  host_e2e          the same from / to HOST memory: pinned 8-bit frames -> upload || compute || download, link-bound
   config4           BASELINE configs[3]: run_OF_RGB 1920x1080, L1 cost, 50 iterations, TV on
+  sustained         the headline loop again for >= 1 s of wall time (the K-step figure is the contract's)
+  strong_scaling    fixed totals (512 = BASELINE configs[4], 4096) cut into contiguous per-rank shares, per-rank step times
 """
 import argparse
 import json
@@ -256,6 +259,11 @@ def kernel_table(capi, torch, batch, p, B, stream, nrep=3):
                          "avg_launch_us": round(ms / n * 1e3, 2),
                          "algorithmic_MB_per_step": round(abytes[name] / 1e6, 2),
                          "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        # launch by launch: a pass launches a class once per level, coarsest first (HIP events on the launch stream)
+        per = batch.kernel_times(k)
+        nl = p.sc_f - p.sc_l + 1
+        if len(per) == nrep * nl:
+            kernels[name]["ms_per_level"] = {str(p.sc_f - i): round(sum(per[i::nl]) / nrep, 4) for i in range(nl)}
     batch.timing(False)
     return kernels
 
@@ -377,6 +385,80 @@ def block_e2e(capi, torch, p, batch, ia, ib, stream, dev, args):
                               "achieved_GBs": round(up_b / t_up / 1e6, 1), "frac_of_hbm_peak": round(up_b / t_up / 1e6 / HBM_PEAK_GBS, 4)}}
 
 
+def block_host_e2e(capi, torch, p, batch, ia, ib, stream, dev, args):
+    """Secondary scope from / to HOST memory (SURVEY.md 8d "secondary", run_dense.cpp:208-209,326-344,391-421 without the
+    file I/O): pinned 8-bit frames -> H2D on a copy stream || pyramids + path (+ upsample) on the compute stream || D2H of
+    the result on a third stream, chunk by chunk through double-buffered device arrays.  Two variants: the flow at the
+    finest computed level (57 KB per pair) and the full-resolution flow as written to the .flo (3.6 MB per pair).  Both are
+    bound by the PCIe link, not by the kernels; the link-bound estimate is printed beside the measurement."""
+    chunk, nchunks = 256, 16
+    w3, h3 = p.level_size(p.sc_l)
+    in_bytes = 2 * chunk * HEIGHT * WIDTH                       # two u8 frames per pair
+    out_low, out_full = chunk * h3 * w3 * 8, chunk * HEIGHT * WIDTH * 8
+    ha = [torch.empty((chunk, HEIGHT, WIDTH), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    hb = [torch.empty((chunk, HEIGHT, WIDTH), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    for k in range(2):                                          # the ring's content: frames of this batch
+        ha[k].copy_(ia[k * chunk:(k + 1) * chunk].cpu())
+        hb[k].copy_(ib[k * chunk:(k + 1) * chunk].cpu())
+    da = [torch.empty((chunk, HEIGHT, WIDTH), dtype=torch.uint8, device=dev) for _ in range(2)]
+    db = [torch.empty((chunk, HEIGHT, WIDTH), dtype=torch.uint8, device=dev) for _ in range(2)]
+    bc = capi.Batch(p, chunk)
+    s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ts = torch.cuda.ExternalStream(stream, device=dev)
+    res = {}
+    for variant, obytes in (("level_flow", out_low), ("full_resolution_flow", out_full)):
+        full = variant == "full_resolution_flow"
+        shape = (chunk, HEIGHT, WIDTH, 2) if full else (chunk, h3, w3, 2)
+        dout = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(2)]
+        hout = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        up = [torch.cuda.Event() for _ in range(2)]       # upload of slot k complete
+        done = [torch.cuda.Event() for _ in range(2)]     # compute of slot k complete (inputs + dout[k] free / ready)
+        down = [torch.cuda.Event() for _ in range(2)]     # download of slot k complete
+
+        def run(n):
+            for i in range(n):
+                k = i & 1
+                with torch.cuda.stream(s_in):              # upload chunk i (after the compute that last read slot k)
+                    if i >= 2:
+                        s_in.wait_event(done[k])
+                    da[k].copy_(ha[k], non_blocking=True)
+                    db[k].copy_(hb[k], non_blocking=True)
+                    up[k].record(s_in)
+                ts.wait_event(up[k])
+                if i >= 2:
+                    ts.wait_event(down[k])                 # dout[k] has been downloaded
+                bc.build_pyramids_u8(da[k].data_ptr(), db[k].data_ptr(), WIDTH, HEIGHT, stream)
+                bc.run(stream)
+                if full:
+                    bc.upsample(WIDTH, HEIGHT, out_ptr=dout[k].data_ptr(), stream=stream)
+                else:
+                    capi.check(capi.lib().ofdis_memcpy_d2d(dout[k].data_ptr(), bc.flow_ptr(), obytes, stream))
+                done[k].record(ts)
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(done[k])
+                    hout[k].copy_(dout[k], non_blocking=True)
+                    down[k].record(s_out)
+        run(4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(nchunks)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        pairs = nchunks * chunk
+        link = 55.0e9   # what PCIe Gen5 x16 sustains per direction on pinned memory, about (63 GB/s spec, MI355X_MICROARCH.md)
+        bound = 1.0 / max(in_bytes / chunk / link, obytes / chunk / link)   # uploads and downloads use opposite directions
+        res[variant] = {"value": round(pairs / dt, 1), "unit": "pairs/s", "pairs": pairs, "chunk_pairs": chunk,
+                        "host_to_device_MB_per_pair": round(in_bytes / chunk / 1e6, 3),
+                        "device_to_host_MB_per_pair": round(obytes / chunk / 1e6, 3),
+                        "h2d_GBs": round(in_bytes * nchunks / dt / 1e9, 2), "d2h_GBs": round(obytes * nchunks / dt / 1e9, 2),
+                        "link_bound_pairs_per_s_at_55GBs": round(bound, 1)}
+        del dout, hout
+    bc.close()
+    return {"workload": "pinned 8-bit frames in host memory -> upload || pyramids + path (+ x8 upsample, crop) || download, "
+                        f"{nchunks} chunks of {chunk} pairs, three streams, double-buffered (secondary scope, PCIe-inclusive)",
+            **res}
+
+
 def block_config4(capi, torch, p, batch, ia, ib, stream, dev, args):
     """BASELINE configs[3]: run_OF_RGB operating-point-4 geometry on 1920x1080, L1 cost, 50 iterations, TV on
     (CLI: run_OF_RGB a b out 6 1 50 50 0.05 0.95 0 12 0.75 0 1 1 1 10 10 5 1 3 1.6 2)."""
@@ -423,7 +505,8 @@ def block_config4(capi, torch, p, batch, ia, ib, stream, dev, args):
 
 
 BLOCKS = [("small_batch", block_small_batch), ("dropin_latency", block_dropin_latency),
-          ("warp_standalone", block_warp_standalone), ("e2e", block_e2e), ("config4", block_config4)]
+          ("warp_standalone", block_warp_standalone), ("e2e", block_e2e), ("host_e2e", block_host_e2e),
+          ("config4", block_config4)]
 
 
 def free_port():
@@ -469,7 +552,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="frame pairs per GPU per step (weak scaling)")
+    ap.add_argument("--batch", type=int, default=16384,
+                    help="frame pairs per GPU per step (weak scaling); 16384 pairs = 20 GB of the 288 GB (4096: -6 %% frames/s)")
     ap.add_argument("--total-frames", type=int, default=0,
                     help="strong scaling: this many pairs per step in total, cut into contiguous per-rank shares "
                          "(BASELINE configs[4]: 512)")
@@ -507,6 +591,9 @@ def main():
         raise SystemExit(f"bench.py: {world} ranks but only {ndev} HIP device(s) visible (one GPU per rank)")
     torch.cuda.set_device(local_rank)
     capi.check(L.ofdis_set_device(local_rank))
+    if world > 1 and not os.environ.get("OFDIS_BENCH_SHARE_GPU"):
+        # one GPU per rank: the ranks of a node must sit on different devices (checked again in the JSON: ranks.pci_bus_ids)
+        assert local_rank < ndev
     dist = None
     # (OFDIS_BENCH_FORCE_DIST: initialise the process group even for one rank -- a one-GPU box then still exercises every
     # RCCL call of the multi-rank path: communicator creation, barrier, MAX all-reduce, object gather)
@@ -591,31 +678,57 @@ def main():
                     "how": "rank 0 re-computed " + ("every frame" if strong else f"the first {CHUNK} frames")
                            + " of each other rank on its own GPU and compared per-frame checksums of the flow bits"}
 
-    # ---- BASELINE configs[4]: 512 pairs in total over the ranks of this run (a secondary block in every mode)
-    batch512 = None
-    if not args.no_extras and not e2e and tv:
-        total = 512
+    # ---- strong scaling (a secondary block in every mode): fixed totals cut into contiguous per-rank shares --
+    #      512 pairs = BASELINE configs[4], and 4096; per-rank step times next to the whole-job figure
+    def strong_block(total):
         slo, shi = shard.frame_range(total, rank, world)
         n5 = shi - slo
         fits = shard.gather_objects(1 <= n5 <= B, dist, world)  # the same decision on every rank (collectives below)
-        if all(fits):
-            b5 = capi.Batch(p, n5)
-            torch.cuda.synchronize()
-            # (timing only: the first n5 frames this rank already holds)
-            b5.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
-            for _ in range(max(3, args.warmup)):
-                b5.run(stream)
-            k5 = max(20, args.steps)
-            barrier()
-            t5 = time.perf_counter()
-            for _ in range(k5):
-                b5.run(stream)
-            barrier()
-            e5 = shard.max_over_ranks(time.perf_counter() - t5, dist, red_dev)
-            b5.close()
-            batch512 = {"workload": "BASELINE configs[4]: 512 independent 1024x436 pairs per step, contiguous shares "
-                                    f"over {world} GPU(s) ({n5} pairs on rank 0)", "value": round(total * k5 / e5, 1),
-                        "unit": "frames/s", "ms_per_step": round(e5 / k5 * 1e3, 4), "steps": k5, "scaling": "strong"}
+        if not all(fits):
+            return None
+        b5 = capi.Batch(p, n5)
+        b5.set_pipeline(args.pipeline if n5 >= 1024 else 1)
+        torch.cuda.synchronize()
+        # (timing only: the first n5 frames this rank already holds)
+        b5.build_pyramids_u8(ia.data_ptr(), ib.data_ptr(), WIDTH, HEIGHT, stream)
+        for _ in range(max(3, args.warmup)):
+            b5.run(stream)
+        k5 = max(20, args.steps)
+        barrier()
+        t5 = time.perf_counter()
+        for _ in range(k5):
+            b5.run(stream)
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t5
+        barrier()
+        e5 = shard.max_over_ranks(time.perf_counter() - t5, dist, red_dev)
+        per_rank = shard.gather_objects(round(mine / k5 * 1e3, 4), dist, world)
+        b5.close()
+        return {"workload": f"{total} independent 1024x436 pairs per step, contiguous shares over {world} GPU(s) "
+                            f"({n5} pairs on rank 0)", "value": round(total * k5 / e5, 1), "unit": "frames/s",
+                "ms_per_step": round(e5 / k5 * 1e3, 4), "ms_per_step_per_rank": per_rank, "steps": k5, "scaling": "strong"}
+
+    batch512, strong4096 = None, None
+    if not args.no_extras and not e2e and tv:
+        batch512 = strong_block(512)
+        strong4096 = strong_block(4096)
+
+    # ---- the headline loop again for >= 1 s of wall time (the K-step figure above is the contract's; this one shows
+    #      that it is sustained)
+    sustained = None
+    if not args.no_extras:
+        k_s = max(args.steps, int(1.05 / max(elapsed / args.steps, 1e-6)) + 1)
+        barrier()
+        t_s = time.perf_counter()
+        for _ in range(k_s):
+            step()
+        barrier()
+        e_s = shard.max_over_ranks(time.perf_counter() - t_s, dist, red_dev)
+        sustained = {"steps": k_s, "seconds": round(e_s, 3), "value": round(shard.throughput(counts, k_s, e_s), 1),
+                     "unit": "frames/s", "ms_per_step": round(e_s / k_s * 1e3, 4)}
+
+    # ---- which GPUs: every rank reports the PCI bus id of its device
+    pci = shard.gather_objects(capi.device_pci_bus_id(local_rank), dist, world)
 
     result = None
     if rank == 0:
@@ -679,7 +792,8 @@ def main():
                        "frames_per_gpu_per_step": counts[0] if len(set(counts)) == 1 else counts,
                        "global_frames_per_step": sum(counts),
                        "parallelism": f"frame-sharded x{world}", "tv": args.tv,
-                       "ranks": {"world_size": dist.get_world_size() if dist is not None else 1,
+                       "ranks": {"pci_bus_ids": pci, "distinct_gpus": len(set(pci)),
+                                 "world_size": dist.get_world_size() if dist is not None else 1,
                                  "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if dist is not None else "none",
                                  "launch": "self-spawned by bench.py --gpus" if os.environ.get("OFDIS_BENCH_SPAWNED") else
                                            ("torch.distributed.run" if world > 1 else "single process")},
@@ -691,8 +805,12 @@ def main():
             result["roofline_valu"] = roofline_valu
         if mg_check:
             result["multi_gpu_check"] = mg_check
+        if sustained:
+            result["sustained"] = sustained
         if batch512:
             result["batch512"] = batch512
+        if batch512 or strong4096:
+            result["strong_scaling"] = {k: v for k, v in (("512", batch512), ("4096", strong4096)) if v}
         if not args.no_parity:
             try:
                 import oracle
@@ -731,7 +849,7 @@ def main():
                     result[name] = fn(capi, torch, p, batch, ia, ib, stream, dev, args)
                 except Exception as e:
                     result[name] = {"value": None, "error": f"{type(e).__name__}: {e}"}
-        if world == 1 and args.cpu_seconds > 0:
+        if args.cpu_seconds > 0:  # (rank 0 only, whatever the world size: the other ranks wait in the barrier below)
             try:
                 result["cpu_baseline"] = cpu_baseline(p, batch, min(16, B), args.cpu_seconds)
                 result["speedup_vs_cpu_1core"] = round(fps / result["cpu_baseline"]["value"], 1)

@@ -74,6 +74,9 @@ int ofdis_version(void);
 /* number of HIP devices visible / select one (one process per GPU: call once at start) */
 int ofdis_device_count(void);
 int ofdis_set_device(int device);
+/* PCI bus id ("0000:c1:00.0") of a visible device into buf (at least 16 bytes): a multi-rank launcher can check that the
+ * ranks really sit on different GPUs */
+int ofdis_device_pci_bus_id(int device, char* buf, int len);
 
 /* ---------------------------------------------------------------------------------------------
  * Drop-in for the constructor: host pointers in, host flow out, synchronous.
@@ -171,14 +174,18 @@ enum { OFDIS_K_WARP = 0, OFDIS_K_DERIV = 1, OFDIS_K_SYSTEM = 2, OFDIS_K_SOR = 3,
        OFDIS_K_DENSIFY = 5, OFDIS_K_UPDATE = 6, OFDIS_K_FUSED = 7, OFDIS_K_COUNT = 8 };
 int ofdis_batch_timing(ofdis_batch* b, int enable);
 int ofdis_batch_kernel_time(ofdis_batch* b, int kernel_class, double* ms_sum, long* launches);
+/* the same launch by launch, in launch order (a pass launches a class once per level, coarsest level first): fills
+ * ms_out[0 .. min(capacity, *launches) - 1] */
+int ofdis_batch_kernel_times(ofdis_batch* b, int kernel_class, double* ms_out, int capacity, int* launches);
 
 /* ---------------------------------------------------------------------------------------------
  * Kernel-selection knobs.  Several stages exist in more than one mapping of the SAME arithmetic (every setting gives
  * bit-identical results); the library picks by geometry and batch size.  The knobs are process-wide, are initialised
  * ONCE from the environment variables named below at the first call into the library and can be changed at run time
  * (the parity tests run every mapping; a maintainer can pin one).  A change takes effect at the next ofdis_batch_run /
- * ofdis_flow; contexts created while fused_tv was 0 stay on the unfused path (they do not own the fused path's buffers),
- * and a captured launch graph (ofdis_batch_set_graph) is re-captured after a change.
+ * ofdis_flow, except fused_tv, which a context fixes at creation (it allocates the scratch of the path it will take:
+ * ofdis_flow_cache_clear() before ofdis_flow picks up a change).  A captured launch graph (ofdis_batch_set_graph) is
+ * re-captured after a change.
  * ------------------------------------------------------------------------------------------- */
 typedef struct ofdis_tuning {
   int gray8;          /* 1: gray 8x8 patches use the 4-lanes-per-patch kernel; 0: generic kernel     OFDIS_NO_GRAY8 -> 0 */

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "ofdis_batch_level_flow", "ofdis_batch_download", "ofdis_batch_upsample", "ofdis_batch_timing", "ofdis_batch_kernel_time",
     "ofdis_image_warp", "ofdis_get_derivatives", "ofdis_tv_system", "ofdis_sor_coupled", "ofdis_patchgrid_level",
     "ofdis_varref_level", "ofdis_dev_alloc", "ofdis_dev_free", "ofdis_memcpy_h2d", "ofdis_memcpy_d2h", "ofdis_memcpy_d2d", "ofdis_sync",
-    "ofdis_batch_set_graph", "ofdis_flow_cache_clear", "ofdis_get_tuning", "ofdis_set_tuning",
+    "ofdis_batch_set_graph", "ofdis_flow_cache_clear", "ofdis_get_tuning", "ofdis_set_tuning", "ofdis_batch_kernel_times", "ofdis_device_pci_bus_id",
 ]
 
 
@@ -98,6 +98,7 @@ def lib():
         L.ofdis_batch_initflow_elems.argtypes = [VP]
         L.ofdis_batch_set_initflow.argtypes = [VP, VP]
         L.ofdis_batch_upload_initflow.argtypes = [VP, C.c_int, FP, VP]
+        L.ofdis_batch_kernel_times.argtypes = [VP, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
         L.ofdis_get_tuning.argtypes = [C.POINTER(OfdisTuning)]
         L.ofdis_set_tuning.argtypes = [C.POINTER(OfdisTuning)]
         _lib = L
@@ -107,6 +108,12 @@ def lib():
 def check(rc):
     if rc != 0:
         raise OfdisError(f"ofdis status {rc}: {lib().ofdis_last_error().decode()}")
+
+
+def device_pci_bus_id(device):
+    buf = C.create_string_buffer(32)
+    check(lib().ofdis_device_pci_bus_id(device, buf, 32))
+    return buf.value.decode()
 
 
 def get_tuning():
@@ -374,3 +381,9 @@ class Batch:
         ms, n = C.c_double(0), C.c_long(0)
         check(lib().ofdis_batch_kernel_time(self.h, k, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernel_times(self, k, capacity=4096):
+        """Per-launch milliseconds of a kernel class in launch order (a pass launches a class once per level, coarsest first)."""
+        buf, n = (C.c_double * capacity)(), C.c_int(0)
+        check(lib().ofdis_batch_kernel_times(self.h, k, buf, capacity, C.byref(n)))
+        return [buf[i] for i in range(min(n.value, capacity))]

@@ -283,14 +283,17 @@ TvConsts tv_consts(float alpha, float gamma, float delta) {  // refine_variation
   return c;
 }
 
-// Frames per strip of the throughput fused TV kernel: the largest of 8, 4, 2 that divides the frame count and still
-// leaves two wavefronts per SIMD (2048 strips groups per launch), else 1; ofdis_tuning::fused_strip overrides.
+// Frames per strip of the throughput fused TV kernel.  A strip pays the fill / drain of the skewed sweep (h steps) once
+// instead of once per frame, but its wavefront runs S times as long, and a launch of few, long wavefronts ends with idle
+// SIMDs: measured at 16384 pairs (level 3, ms per 4096 pairs): S = 1 / 2 / 4 / 8 -> 2.30 / 2.18 / 2.21 / 2.24
+// (profiles/README.md r03_b).  Rule: the largest S in {4, 2} that divides the frame count and leaves >= 4096 wavefronts in
+// the launch, else 1; ofdis_tuning::fused_strip overrides.
 int strip_length(const ofdis_batch* b, const LevelGeom& g, const ofdis_tuning& tn) {
   const int n = b->nframes;
   if (tn.fused_strip > 0) return (n % tn.fused_strip == 0) ? tn.fused_strip : 1;
   const int R = g.h <= 16 ? 16 : (g.h <= 32 ? 32 : 64);
-  for (int S = 8; S > 1; S >>= 1)
-    if (n % S == 0 && (n / S) / (64 / R) >= 2048) return S;
+  for (int S = 4; S > 1; S >>= 1)
+    if (n % S == 0 && (n / S) / (64 / R) >= 4096) return S;
   return 1;
 }
 
@@ -300,7 +303,8 @@ int strip_length(const ofdis_batch* b, const LevelGeom& g, const ofdis_tuning& t
 bool use_fused(const ofdis_batch* b, const LevelGeom& g) {
   const TvConsts c = tv_consts(b->p.tv_alpha, b->p.tv_gamma, b->p.tv_delta);
   const TvGeom t{g.w, g.h, g.noc, b->nframes};
-  return b->wrec && tuning().fused_tv && tv_fused_supported(t, b->p.tv_solverit) && tv_prep_supported(t) &&
+  // (a context created with every level on the fused path owns no unfused scratch: b->wx == nullptr keeps it there)
+  return b->wrec && (tuning().fused_tv || !b->wx) && tv_fused_supported(t, b->p.tv_solverit) && tv_prep_supported(t) &&
          tv_fused_params_ok(c.quarter_alpha, c.half_delta_over3, c.half_gamma_over3);
 }
 
@@ -431,6 +435,11 @@ int ofdis_set_device(int device) {
   HIPCHK(hipSetDevice(device));
   return OFDIS_OK;
 }
+int ofdis_device_pci_bus_id(int device, char* buf, int len) {
+  if (!buf || len < 16) return fail(OFDIS_ERR_INVALID, "need a buffer of at least 16 bytes");
+  HIPCHK(hipDeviceGetPCIBusId(buf, len, device));
+  return OFDIS_OK;
+}
 
 // run_dense.cpp:225-265 (operating points) and :180-183 (AutoFirstScaleSelect)
 int ofdis_params_oppoint(ofdis_params* p, int op_point, int width_org, int noc) {
@@ -501,16 +510,29 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
   if (!rc && p->usefbcon) rc = dalloc(b, &b->pvec_bw, nop_max * 2 * nframes);
   if (!rc && p->usefbcon) rc = dalloc(b, &b->pweight_bw, nop_max * g0.novals * nframes);
   if (!rc && p->usetvref) {
-    if (!rc) rc = dalloc(b, &b->wx, npx);
-    if (!rc) rc = dalloc(b, &b->wy, npx);
-    if (!rc) rc = dalloc(b, &b->du, npx);
-    if (!rc) rc = dalloc(b, &b->dv, npx);
-    if (!rc) rc = dalloc(b, &b->mask, npx);
-    if (!rc) rc = dalloc(b, &b->w_im2, npx * p->noc);
+    // TV scratch.  The fused path (gray levels of <= 64 rows and <= 128 columns) needs the three record arrays; the planes
+    // of the unfused kernels are only allocated when some level of this context can take that path (13 of the 25 floats
+    // per pixel otherwise: a third of the context)
+    const TvConsts tc = tv_consts(p->tv_alpha, p->tv_gamma, p->tv_delta);
+    const bool may_fuse = p->noc == 1 && p->selectmode != 2 && tuning().fused_tv &&
+                          tv_fused_params_ok(tc.quarter_alpha, tc.half_delta_over3, tc.half_gamma_over3);
+    bool all_fused = may_fuse;
+    for (auto& g : b->geom) {
+      const TvGeom t{g.w, g.h, g.noc, nframes};
+      all_fused = all_fused && tv_fused_supported(t, p->tv_solverit) && tv_prep_supported(t);
+    }
+    if (!all_fused) {
+      if (!rc) rc = dalloc(b, &b->wx, npx);
+      if (!rc) rc = dalloc(b, &b->wy, npx);
+      if (!rc) rc = dalloc(b, &b->du, npx);
+      if (!rc) rc = dalloc(b, &b->dv, npx);
+      if (!rc) rc = dalloc(b, &b->mask, npx);
+      if (!rc) rc = dalloc(b, &b->w_im2, npx * p->noc);
+      if (!rc) rc = dalloc(b, &b->sys, npx * 7);
+    }
     if (!rc) rc = dalloc(b, &b->derivs, npx * 8 * p->noc);
-    if (!rc) rc = dalloc(b, &b->sys, npx * 7);
     if (!rc && p->selectmode == 2) rc = dalloc(b, &b->uu, npx);
-    if (!rc && p->noc == 1 && p->selectmode != 2 && tuning().fused_tv) {
+    if (!rc && may_fuse) {
       rc = dalloc(b, &b->wrec, npx * 2);
       if (!rc) rc = dalloc(b, &b->uv, npx * 2);
     }
@@ -980,6 +1002,18 @@ int ofdis_batch_kernel_time(ofdis_batch* b, int k, double* ms_sum, long* launche
   }
   if (ms_sum) *ms_sum = sum;
   if (launches) *launches = (long)b->ev_used[k];
+  return OFDIS_OK;
+}
+
+int ofdis_batch_kernel_times(ofdis_batch* b, int k, double* ms_out, int capacity, int* launches) {
+  if (!b || k < 0 || k >= OFDIS_K_COUNT || capacity < 0 || (capacity > 0 && !ms_out)) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  for (size_t i = 0; i < b->ev_used[k] && (int)i < capacity; ++i) {
+    HIPCHK(hipEventSynchronize(b->ev[k][i].b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev[k][i].a, b->ev[k][i].b));
+    ms_out[i] = ms;
+  }
+  if (launches) *launches = (int)b->ev_used[k];
   return OFDIS_OK;
 }
 

@@ -96,11 +96,12 @@ constexpr int PREP_KW = 8;  // rows of (wx, wy) records staged before a flush (r
 // LDS per block, in floats.  WPF = wavefronts per frame (= per block): 1 (w <= 64; up to four frames in the wavefront) or 2.
 template <int WPF>
 struct PrepLds {
-  static constexpr int ROW = 64 * WPF + 16;  // one exchanged row: the block's columns + 4 pads per frame segment (<= 4)
+  static constexpr int ROW = 64 * WPF + 32;  // one exchanged row: the block's columns + 4 pads + 4 dummies per frame segment (<= 4)
   // staging: per frame (lpf + K - 1) diag rows x K records; the worst case over 1 / 2 / 4 frames per wavefront
   static constexpr int nq(int lpf, int K) { return lpf + K - 1; }
-  static constexpr int STD = WPF == 2 ? nq(128, PREP_KD) * PREP_KD * 8 : 4 * nq(16, PREP_KD) * PREP_KD * 8;
-  static constexpr int STW = WPF == 2 ? nq(128, PREP_KW) * PREP_KW * 2 : 4 * nq(16, PREP_KW) * PREP_KW * 2;
+  // (+ one dummy record at the end of each array: where the lanes beyond the image write)
+  static constexpr int STD = (WPF == 2 ? nq(128, PREP_KD) * PREP_KD : 4 * nq(16, PREP_KD) * PREP_KD) * 8 + 8;
+  static constexpr int STW = (WPF == 2 ? nq(128, PREP_KW) * PREP_KW : 4 * nq(16, PREP_KW) * PREP_KW) * 2 + 2;
   static constexpr int TOTAL = 3 * ROW + STD + STW;
 };
 
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
   const int y1lo = max(yb0 - 2, 0), y1hi = min(yb1 + 2, h);       // rows of stage 1
   const int r_last = yb1 + 3;
 
-  const int seg = lpf * C + 4;  // floats of one frame's segment of an exchanged row
+  const int seg = lpf * C + 8;  // floats of one frame's segment of an exchanged row: 2 pads, the columns, 2 pads, 4 dummies
   float* const rowA = lds + fl * seg;
   float* const rowX = lds + L::ROW + fl * seg;
   float* const rowZ = lds + 2 * L::ROW + fl * seg;
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
     constexpr int RUN = K * PPR;                                          // pieces per diag row (a power of two)
     const bool full = y0 + K <= yend;                                     // (uniform) every row of the block exists
     const int nqv = S == 1 ? w : w + K - 1;  // diag rows the block touches (S = 1: they wrap onto the frame's own w rows)
+    const int iters = (nqv * RUN + 64 * WPF - 1) / (64 * WPF);  // (uniform trip count: no divergent loop)
     for (int f = 0; f < fpw; ++f) {
       const int fr = f0 + f;
       if (fr >= a.t.nframes) break;
@@ -194,39 +196,37 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
       const int dbase = (fsf * w + y0) % rw;
       const int base = ((sgf - sg0) * rw * h + y0) * RB;
       const float* stf = st + f * nq * K * (RB / 4);
-      for (int e = lane; e < nqv * RUN; e += 64 * WPF) {
+      for (int it = 0; it < iters; ++it) {
+        const int e = min(lane + it * 64 * WPF, nqv * RUN);  // (pieces beyond the block: a valid LDS address, dropped below)
         const int q = e / RUN, lo = e % RUN;
         int d = dbase + q;
-        if (d >= rw) d -= rw;
-        bool ok = true;
-        if (S != 1 || !full) {
-          const int k = lo / PPR;
-          const int x = q - k;
-          ok = (S == 1 || (x >= 0 && x < w)) && y0 + k < yend;
-        }
-        if (ok) {
-          const int byte = base + d * (h * RB) + lo * PB;
-          if constexpr (PB == 16) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(stf + e * 4);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte, 0, 0);
-          } else {
-            const u32x2 v = *reinterpret_cast<const u32x2*>(stf + e * 2);
-            __builtin_amdgcn_raw_buffer_store_b64(v, rs, byte, 0, 0);
-          }
+        d -= d >= rw ? rw : 0;
+        // (bitwise operators: no short-circuit branches.)  A piece is stored if its diag row, its pixel and its row exist
+        const int k = lo / PPR, x = q - k;
+        const bool ok = (q < nqv) & ((S == 1) | ((x >= 0) & (x < w))) & (full | (y0 + k < yend));
+        // a store that must not happen gets an offset beyond the resource's range: the hardware drops it (no branch)
+        const int byte = ok ? base + d * (h * RB) + lo * PB : 0x7ffffff0;
+        if constexpr (PB == 16) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(stf + e * 4);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte, 0, 0);
+        } else {
+          const u32x2 v = *reinterpret_cast<const u32x2*>(stf + e * 2);
+          __builtin_amdgcn_raw_buffer_store_b64(v, rs, byte, 0, 0);
         }
       }
     }
   };
   // One image row through LDS for the horizontal filters: entry 2 + c = column c, two entries replicating column 0 before and
-  // two replicating column w - 1 after (image.c:466-502).  Lanes whose columns lie beyond the image write nothing.
+  // two replicating column w - 1 after (image.c:466-502).  Branch-free: every lane writes its column (lanes beyond the image
+  // into a dummy entry) and one pair of pads (the first lane the left pair, the lane of column w - 1 the right pair, the
+  // others a dummy pair).
+  const int col_entry = li < w ? 2 + li : lpf + 4;
+  const int pad_entry = li == 0 ? 0 : (li == w - 1 ? 2 + w : lpf + 6);
   auto put_row = [&](float* row, const float (&v)[C]) {
-#pragma unroll
-    for (int k = 0; k < C; ++k) {
-      const int c = li * C + k;
-      if (c < w) row[2 + c] = v[k];
-      if (c == w - 1) row[2 + w] = row[3 + w] = v[k];
-    }
-    if (li == 0) row[0] = row[1] = v[0];
+    static_assert(C == 1, "one column per lane");
+    row[col_entry] = v[0];
+    row[pad_entry] = v[0];
+    row[pad_entry + 1] = v[0];
   };
   // staging position of column x in block row k
   auto stq = [&](int x, int k) { int q = x + k; if (S == 1 && q >= w) q -= w; return q; };
@@ -313,9 +313,8 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
         put_row(rowA, A[u]);
         if (r >= yb0 && r < yb1) {  // (wx, wy) of this row into its staging block
           const int kk = (r - yb0) % PREP_KW;
-#pragma unroll
-          for (int k = 0; k < C; ++k)
-            if (li * C + k < w) *reinterpret_cast<float2*>(stWf + (stq(xc[k], kk) * PREP_KW + kk) * 2) = make_float2(fx[k], fy[k]);
+          float* dst = li < w ? stWf + (stq(xc[0], kk) * PREP_KW + kk) * 2 : stW + (L::STW - 2);  // (beyond the image: dummy)
+          *reinterpret_cast<float2*>(dst) = make_float2(fx[0], fy[0]);
         }
         prep_sync<WPF>();
         {
@@ -384,16 +383,14 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
             iyy[k] = v5r<F>(IY[(u + 4) % 5][k], IY[u][k], IY[(u + 1) % 5][k], IY[(u + 2) % 5][k], IY[(u + 3) % 5][k]);
         });
         const int kk = (y2 - yb0) % PREP_KD;
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-          if (li * C + k < w) {
-            const bool on = (mbits[k] >> 4) & 1u;  // the warp mask of row r-4
-            float* dst = stDf + (stq(xc[k], kk) * PREP_KD + kk) * 8;
-            *reinterpret_cast<float4*>(dst) =
-                on ? make_float4(IX[o][k], Z[o][k], ixx[k], ixz[k]) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            *reinterpret_cast<float4*>(dst + 4) =
-                on ? make_float4(IY[o][k], ixy2[k], iyz2[k], iyy[k]) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          }
+        {
+          constexpr int k = 0;
+          const bool on = (mbits[k] >> 4) & 1u;  // the warp mask of row r-4
+          float* dst = li < w ? stDf + (stq(xc[k], kk) * PREP_KD + kk) * 8 : stD + (L::STD - 8);  // (beyond the image: dummy)
+          *reinterpret_cast<float4*>(dst) =
+              on ? make_float4(IX[o][k], Z[o][k], ixx[k], ixz[k]) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          *reinterpret_cast<float4*>(dst + 4) =
+              on ? make_float4(IY[o][k], ixy2[k], iyz2[k], iyy[k]) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         prep_sync<WPF>();
         if (kk == PREP_KD - 1 || y2 == yb1 - 1) {

@@ -149,7 +149,10 @@ def test_bench_two_ranks_under_torchrun(gpu):
            "--warmup", "1", "--batch", "64", "--cpu-seconds", "0", "--no-extras"]
     d = _run_bench(cmd, env)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_frames_per_step"] == 128
-    assert d["config"]["ranks"] == {"world_size": 2, "backend": backend, "launch": "torch.distributed.run"}
+    rk = d["config"]["ranks"]
+    assert (rk["world_size"], rk["backend"], rk["launch"]) == (2, backend, "torch.distributed.run")
+    # one PCI bus id per rank; distinct GPUs under RCCL (the one-GPU developer mode shares device 0)
+    assert len(rk["pci_bus_ids"]) == 2 and rk["distinct_gpus"] == (2 if backend.startswith("rccl") else 1)
     assert d["parity_check"].startswith("bit-exact")
     assert d["multi_gpu_check"]["bit_identical_to_1gpu"] and d["multi_gpu_check"]["frames_compared"] == 32
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
@@ -167,7 +170,8 @@ def test_bench_spawns_its_own_ranks(gpu):
     d = _run_bench([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                     "--batch", "96", "--cpu-seconds", "0", "--no-extras"], env)
     assert d["n_gpus"] == 2 and d["config"]["global_frames_per_step"] == 192
-    assert d["config"]["ranks"] == {"world_size": 2, "backend": backend, "launch": "self-spawned by bench.py --gpus"}
+    rk = d["config"]["ranks"]
+    assert (rk["world_size"], rk["backend"], rk["launch"]) == (2, backend, "self-spawned by bench.py --gpus")
     assert d["multi_gpu_check"]["bit_identical_to_1gpu"]
 
 
@@ -185,7 +189,10 @@ def test_bench_batch512_block_with_two_ranks(gpu):
     assert d["n_gpus"] == 2 and d["multi_gpu_check"]["bit_identical_to_1gpu"]
     b5 = d["batch512"]
     assert b5["scaling"] == "strong" and b5["value"] > 0 and "256 pairs on rank 0" in b5["workload"]
-    assert "small_batch" not in d and "cpu_baseline" not in d      # one-GPU blocks only
+    assert len(b5["ms_per_step_per_rank"]) == 2 and d["strong_scaling"]["512"] == b5
+    assert "4096" not in d["strong_scaling"]                       # 2048 pairs per rank do not fit a 256-pair share
+    assert d["sustained"]["seconds"] >= 1.0 and d["sustained"]["value"] > 0
+    assert "small_batch" not in d and "cpu_baseline" not in d      # one-GPU blocks only; --cpu-seconds 0
 
 
 @pytest.mark.gpu
