@@ -8,6 +8,7 @@
 #include <sys/time.h>
 
 #include <algorithm>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1024,89 +1025,91 @@ namespace {
 
 // The reference constructs one OFClass per frame pair (run_dense.cpp:391-400) and a video loop calls it again and again
 // with the same parameters.  Creating a device context per call would cost more than the computation, so ofdis_flow keeps
-// the contexts of the last few parameter sets (per device): device buffers in one allocation, a stream, pinned staging
-// for one upload of the whole pyramid and the download of the flow, and (from the second call on) the captured launch
-// graph.  Calls are serialised by a mutex -- the reference's constructor is single-threaded and synchronous too.
+// the contexts of the last few (parameter set, device) combinations: device buffers in one allocation, a stream and pinned
+// staging for the pyramid upload and the flow download.  A context serves one call at a time (its own mutex: calls with the
+// same parameters on the same device are serialised, like the reference's synchronous constructor); the global mutex only
+// guards the cache's lookup, insertion and eviction, so calls with different parameters or on different devices run
+// concurrently.  A context that is evicted or cleared while a call is using it is released when that call returns.
 struct FlowCtx {
   ofdis_params p;
   int device = -1;
+  unsigned epoch = 0;     // state of the kernel-selection knobs the context was created under (ofdis_set_tuning)
   ofdis_batch* b = nullptr;
   hipStream_t s = nullptr;
   char* stage = nullptr;  // pinned: [in_bytes of input planes][flow]
   size_t flow_bytes = 0;
   unsigned long stamp = 0;
+  std::mutex busy;        // held for the duration of a call
+  ~FlowCtx() {
+    if (s) (void)hipStreamSynchronize(s);
+    if (b) ofdis_batch_destroy(b);
+    if (stage) (void)hipHostFree(stage);
+    if (s) (void)hipStreamDestroy(s);
+  }
 };
 std::mutex g_flow_mutex;
-std::vector<FlowCtx> g_flow_cache;
+std::vector<std::shared_ptr<FlowCtx>> g_flow_cache;
 unsigned long g_flow_stamp = 0;
 constexpr size_t kFlowCacheEntries = 4;
 
-void flow_ctx_release(FlowCtx& c) {
-  if (c.s) (void)hipStreamSynchronize(c.s);
-  if (c.b) ofdis_batch_destroy(c.b);
-  if (c.stage) (void)hipHostFree(c.stage);
-  if (c.s) (void)hipStreamDestroy(c.s);
-  c = FlowCtx();
+void flow_ctx_evict(const std::shared_ptr<FlowCtx>& c) {  // (released when its last user is done)
+  std::lock_guard<std::mutex> lock(g_flow_mutex);
+  for (size_t i = 0; i < g_flow_cache.size(); ++i)
+    if (g_flow_cache[i] == c) {
+      g_flow_cache.erase(g_flow_cache.begin() + i);
+      break;
+    }
 }
 
-int flow_ctx_get(const ofdis_params* p, FlowCtx** out) {
+int flow_ctx_get(const ofdis_params* p, std::shared_ptr<FlowCtx>* out) {
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
-  for (auto& c : g_flow_cache)
-    if (c.device == dev && memcmp(&c.p, p, sizeof(*p)) == 0) {
-      c.stamp = ++g_flow_stamp;
-      *out = &c;
+  unsigned epoch = 0;
+  (void)ofdis::tuning(&epoch);
+  std::lock_guard<std::mutex> lock(g_flow_mutex);
+  for (size_t i = 0; i < g_flow_cache.size(); ++i) {
+    auto& c = g_flow_cache[i];
+    if (c->device == dev && memcmp(&c->p, p, sizeof(*p)) == 0) {
+      if (c->epoch != epoch) {  // created under other knob settings (it owns that path's scratch): replace it
+        g_flow_cache.erase(g_flow_cache.begin() + i);
+        break;
+      }
+      c->stamp = ++g_flow_stamp;
+      *out = c;
       return OFDIS_OK;
     }
-  FlowCtx c;
-  int rc = ofdis_batch_create(&c.b, p, 1);
-  if (rc) return rc;
-  c.p = *p;
-  c.device = dev;
-  const LevelGeom& g0 = c.b->geom[0];
-  c.flow_bytes = (size_t)g0.w * g0.h * c.b->nop * sizeof(float);
-  hipError_t e = hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c.stage, c.b->in_bytes + c.flow_bytes, hipHostMallocDefault);
-  if (e != hipSuccess) {
-    flow_ctx_release(c);
-    return hipfail(e, "ofdis_flow context");
   }
+  auto c = std::make_shared<FlowCtx>();
+  int rc = ofdis_batch_create(&c->b, p, 1);
+  if (rc) return rc;
+  c->p = *p;
+  c->device = dev;
+  c->epoch = epoch;
+  const LevelGeom& g0 = c->b->geom[0];
+  c->flow_bytes = (size_t)g0.w * g0.h * c->b->nop * sizeof(float);
+  hipError_t e = hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->stage, c->b->in_bytes + c->flow_bytes, hipHostMallocDefault);
+  if (e != hipSuccess) return hipfail(e, "ofdis_flow context");
   if (g_flow_cache.size() >= kFlowCacheEntries) {  // evict the least recently used
     size_t lru = 0;
     for (size_t i = 1; i < g_flow_cache.size(); ++i)
-      if (g_flow_cache[i].stamp < g_flow_cache[lru].stamp) lru = i;
-    flow_ctx_release(g_flow_cache[lru]);
+      if (g_flow_cache[i]->stamp < g_flow_cache[lru]->stamp) lru = i;
     g_flow_cache.erase(g_flow_cache.begin() + lru);
   }
-  c.stamp = ++g_flow_stamp;
+  c->stamp = ++g_flow_stamp;
   g_flow_cache.push_back(c);
-  *out = &g_flow_cache.back();
+  *out = c;
   return OFDIS_OK;
 }
 
 }  // namespace
 
-extern "C" {
-
-void ofdis_flow_cache_clear(void) {
-  std::lock_guard<std::mutex> lock(g_flow_mutex);
-  for (auto& c : g_flow_cache) flow_ctx_release(c);
-  g_flow_cache.clear();
-}
-
-int ofdis_flow(const ofdis_params* p, const float* const* im_a, const float* const* im_a_dx,
-               const float* const* im_a_dy, const float* const* im_b, const float* const* im_b_dx,
-               const float* const* im_b_dy, float* outflow, const float* initflow) {
-  if (!outflow) return fail(OFDIS_ERR_INVALID, "outflow is NULL");
-  int rc = check_params(p);
-  if (rc) return rc;
-  if (!im_a || !im_a_dx || !im_a_dy || !im_b) return fail(OFDIS_ERR_INVALID, "pyramid array is NULL");
-  if (p->usefbcon && (!im_b_dx || !im_b_dy))  // otherwise never read (SURVEY.md a4)
-    return fail(OFDIS_ERR_INVALID, "usefbcon needs the gradient pyramids of the second image");
-  std::lock_guard<std::mutex> lock(g_flow_mutex);
-  FlowCtx* c = nullptr;
-  rc = flow_ctx_get(p, &c);
-  if (rc) return rc;
+namespace {
+int flow_with_ctx(FlowCtx& ctx, const ofdis_params* p, const float* const* im_a, const float* const* im_a_dx,
+                  const float* const* im_a_dy, const float* const* im_b, const float* const* im_b_dx,
+                  const float* const* im_b_dy, float* outflow, const float* initflow) {
+  int rc = OFDIS_OK;
+  FlowCtx* c = &ctx;
   ofdis_batch* b = c->b;
   // The pyramid goes through pinned staging (the planes mirror the device layout), coarsest level first: a level is
   // copied into the staging buffer, pulled to the device by a copy kernel and its kernels are launched; while the GPU
@@ -1157,6 +1160,37 @@ int ofdis_flow(const ofdis_params* p, const float* const* im_a, const float* con
   HIPCHK(hipStreamSynchronize(c->s));
   memcpy(outflow, out_stage, c->flow_bytes);
   return OFDIS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+void ofdis_flow_cache_clear(void) {
+  std::lock_guard<std::mutex> lock(g_flow_mutex);
+  g_flow_cache.clear();  // (a context in use by another thread is released when that call returns)
+}
+
+int ofdis_flow(const ofdis_params* p, const float* const* im_a, const float* const* im_a_dx,
+               const float* const* im_a_dy, const float* const* im_b, const float* const* im_b_dx,
+               const float* const* im_b_dy, float* outflow, const float* initflow) {
+  if (!outflow) return fail(OFDIS_ERR_INVALID, "outflow is NULL");
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (!im_a || !im_a_dx || !im_a_dy || !im_b) return fail(OFDIS_ERR_INVALID, "pyramid array is NULL");
+  if (p->usefbcon && (!im_b_dx || !im_b_dy))  // otherwise never read (SURVEY.md a4)
+    return fail(OFDIS_ERR_INVALID, "usefbcon needs the gradient pyramids of the second image");
+  std::shared_ptr<FlowCtx> c;
+  rc = flow_ctx_get(p, &c);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(c->busy);
+  rc = flow_with_ctx(*c, p, im_a, im_a_dx, im_a_dy, im_b, im_b_dx, im_b_dy, outflow, initflow);
+  if (rc) {
+    // a failed call may leave copy kernels reading the staging buffer and a context in an unknown state: drain its
+    // stream and drop it from the cache (the next call builds a fresh one)
+    (void)hipStreamSynchronize(c->s);
+    flow_ctx_evict(c);
+  }
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------ per-function

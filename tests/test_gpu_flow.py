@@ -553,3 +553,28 @@ def test_prep_kernel_row_bands(gpu, orc, band):
         assert_bits_equal(gpu.flow(p, pa[0], pa[1], pa[2], pb[0]), orc.flow(p, pa[0], pa[1], pa[2], pb[0]), f"band rows {band}")
     finally:
         gpu.restore_tuning(old)
+
+
+def test_dropin_from_several_threads(gpu, orc):
+    """ofdis_flow keeps one context per (parameters, device): calls with the same parameters take turns on it, calls with
+    different parameters run side by side (a per-context mutex; the global one only guards the cache).  Every call must
+    return its own pair's bits."""
+    import threading
+    cases = [synth_case(256, 128, 2400 + k, 1, 2, 1) for k in range(2)] + [synth_case(320, 240, 2410, 1, 2, 1)]
+    refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
+    errors = []
+
+    def worker(i):
+        try:
+            c = cases[i % len(cases)]
+            for _ in range(6):
+                got = gpu.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0])
+                assert_bits_equal(got, refs[i % len(cases)], f"thread {i}")
+        except Exception as e:  # noqa: BLE001 -- reported below
+            errors.append((i, repr(e)))
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -9,47 +9,61 @@ import pytest
 
 from of_dis_amd import build as B
 
-LLVM = "/opt/rocm/lib/llvm/bin"
+def _llvm_bin():
+    """The ROCm LLVM tools next to the hipcc that builds the library ($ROCM_PATH, hipcc's own tree, /opt/rocm)."""
+    import shutil
+    cands = []
+    if os.environ.get("ROCM_PATH"):
+        cands.append(os.path.join(os.environ["ROCM_PATH"], "lib", "llvm", "bin"))
+    try:
+        hipcc = os.path.realpath(B._hipcc())
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(hipcc)), "lib", "llvm", "bin"))
+    except RuntimeError:
+        pass
+    cands.append("/opt/rocm/lib/llvm/bin")
+    for c in cands:
+        if os.path.exists(os.path.join(c, "llvm-readelf")) and os.path.exists(os.path.join(c, "clang-offload-bundler")):
+            return c
+    return None
 
 
 def _kernel_notes():
+    """{mangled kernel name: metadata map} of every gfx950 kernel in the built library.  The metadata is the YAML document
+    of the code objects' NT_AMDGPU_METADATA notes, parsed as YAML (no assumptions about key order); every kernel descriptor
+    symbol (*.kd) of the code objects must have an entry."""
+    import yaml
+    llvm = _llvm_bin()
     so = B.lib_path()
     if not os.path.exists(so):
         B.build()
     tmp = tempfile.mkdtemp()
     fb = os.path.join(tmp, "fatbin")
-    subprocess.check_call([LLVM + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", so, fb])
+    subprocess.check_call([llvm + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", so, fb])
     blob = open(fb, "rb").read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
     starts = [m.start() for m in re.finditer(re.escape(magic), blob)]   # one bundle per translation unit
-    kernels = {}
+    kernels, descriptors = {}, set()
     for i, st in enumerate(starts):
         part, co = os.path.join(tmp, "bundle%d" % i), os.path.join(tmp, "gfx950_%d.co" % i)
         with open(part, "wb") as f:
             f.write(blob[st:starts[i + 1] if i + 1 < len(starts) else len(blob)])
-        subprocess.check_call([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + part,
+        subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + part,
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-        notes = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
-        cur = None
-        for line in notes.splitlines():
-            m = re.match(r"\s*-?\s*\.(\w+):\s+(\S+)", line)
-            if not m:
-                continue
-            k, v = m.group(1), m.group(2)
-            if k == "agpr_count":      # first key of a kernel's metadata map
-                cur = {}
-            if cur is not None:
-                cur[k] = v
-                if k == "wavefront_size":  # last key of the (alphabetically ordered) map
-                    sym = cur["symbol"]
-                    kernels[sym[:-3] if sym.endswith(".kd") else sym] = cur   # mangled name
-                    cur = None
+        notes = subprocess.run([llvm + "/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+        for doc in re.findall(r"^\s*---\n(.*?)^\s*\.\.\.\s*$", notes, flags=re.S | re.M):
+            meta = yaml.safe_load(doc)
+            for k in (meta or {}).get("amdhsa.kernels", []):
+                kernels[k[".name"]] = {key.lstrip("."): val for key, val in k.items()}
+        syms = subprocess.run([llvm + "/llvm-readelf", "--symbols", "--wide", co], capture_output=True, text=True, check=True).stdout
+        descriptors |= {m.group(1) for m in re.finditer(r"\s(\S+)\.kd\s*$", syms, flags=re.M)}
+    missing = descriptors - set(kernels)
+    assert not missing, f"kernel descriptors without metadata: {sorted(missing)[:5]}"
     return kernels
 
 
 @pytest.fixture(scope="module")
 def kernels():
-    if not os.path.exists(LLVM + "/llvm-readelf"):
+    if _llvm_bin() is None:
         pytest.skip("ROCm LLVM tools not found")
     k = _kernel_notes()
     assert len(k) > 40, len(k)
@@ -76,6 +90,9 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     ("patch_optimize_gray8_kernelILi0EE", 128, "gray 8x8 patch kernel: four wavefronts per SIMD"),
     ("patch_optimize_kernelILi7ELi64ELi432ELi1EE", 84, "RGB 12x12 patch kernel, L1 cost: six wavefronts per SIMD"),
     ("densify_kernelILb1EE", 64, "densify_kernel<true>: eight wavefronts per SIMD"),
+    ("densify_quad_kernel", 64, "densify_quad_kernel: eight wavefronts per SIMD"),
+    ("tv_prep_kernelILi2EE", 84, "tv_prep_kernel<2> (two wavefronts per 128-column row): six wavefronts per SIMD by registers"),
+    ("tv_prep_kernelILi1EE", 84, "tv_prep_kernel<1>: six wavefronts per SIMD by registers"),
 ])
 def test_register_budgets(kernels, pattern, max_vgprs, what):
     hits = [(n, m) for n, m in kernels.items() if pattern in n]
