@@ -743,9 +743,12 @@ def main():
         traffic, valu = {}, {}
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get("batch") == B and tj.get("tv") == args.tv:
-                traffic = tj["bytes_per_step"]
-                valu = tj.get("valu_insts_per_step", {})
+            if tj.get("batch") and tj.get("tv") == args.tv:
+                # (the PMC passes run on a 4096-pair batch -- rocprofv3 does not survive the 16384-pair one --; frames are
+                # independent and every kernel's work is per frame, so the counters scale with the frame count)
+                scale = B / float(tj["batch"])
+                traffic = {k: v * scale for k, v in tj["bytes_per_step"].items()}
+                valu = {k: v * scale for k, v in tj.get("valu_insts_per_step", {}).items()}
         except Exception:
             pass
         for name, k in kernels.items():

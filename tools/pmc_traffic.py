@@ -20,8 +20,9 @@ import os
 import sys
 from collections import defaultdict
 
-CLASS = {"warp": "warp", "derivatives": "derivatives", "tv_system": "tv_system", "sor_": "sor", "tv_fused": "tv_fused",
-         "patch_optimize": "patch_optimize", "densify": "densify", "tv_finish": "tv_finish"}
+# kernel-name prefix -> kernel class of bench.py (tv_prep = warp + derivatives of the fused path, reported as "derivatives")
+CLASS = {"warp": "warp", "derivatives": "derivatives", "tv_prep": "derivatives", "tv_system": "tv_system", "sor_": "sor",
+         "tv_fused": "tv_fused", "patch_optimize": "patch_optimize", "densify": "densify", "tv_finish": "tv_finish"}
 
 
 def collect(path, counter, scale):
