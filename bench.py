@@ -708,15 +708,16 @@ def main():
                             f"({n5} pairs on rank 0)", "value": round(total * k5 / e5, 1), "unit": "frames/s",
                 "ms_per_step": round(e5 / k5 * 1e3, 4), "ms_per_step_per_rank": per_rank, "steps": k5, "scaling": "strong"}
 
+    only_blocks = os.environ.get("OFDIS_BENCH_BLOCKS")  # developer switch: just these secondary blocks (comma separated)
     batch512, strong4096 = None, None
-    if not args.no_extras and not e2e and tv:
+    if not args.no_extras and not e2e and tv and not only_blocks:
         batch512 = strong_block(512)
         strong4096 = strong_block(4096)
 
     # ---- the headline loop again for >= 1 s of wall time (the K-step figure above is the contract's; this one shows
     #      that it is sustained)
     sustained = None
-    if not args.no_extras:
+    if not args.no_extras and not only_blocks:
         k_s = max(args.steps, int(1.05 / max(elapsed / args.steps, 1e-6)) + 1)
         while True:  # (every rank sees the same max-over-ranks time, so all take the same decision)
             barrier()
@@ -832,7 +833,7 @@ def main():
             except Exception as e:  # the checker is optional for the measurement
                 result["parity_check"] = f"not run ({type(e).__name__}: {e})"
         extras = world == 1 and tv and not e2e and not args.no_extras
-        if extras:
+        if extras and not only_blocks:
             # BASELINE.json also lists the same operating point with the refinement switched off (configs[1]); report it
             # next to the headline (configs[2], TV on -- what operating point 2 is in the reference, run_dense.cpp:259-265)
             try:
@@ -848,7 +849,7 @@ def main():
                 result["tv_off"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         if extras:
             args.batch_frames = B
-            only = os.environ.get("OFDIS_BENCH_BLOCKS")  # developer switch: comma-separated block names
+            only = only_blocks
             for name, fn in BLOCKS:
                 if only and name not in only.split(","):
                     continue
