@@ -761,8 +761,8 @@ def main():
                     "traffic": traffic.get(dom),
                     "note": "achieved = algorithmic bytes of all launches of this kernel class in one step / their "
                             "summed HIP-event time (bytes/s); traffic = PMC HBM bytes of the same launches per step "
-                            "(profiles/traffic.json). The two dominant kernels (tv_fused, patch_optimize) are VALU-issue "
-                            "bound, see roofline_valu and DESIGN.md section 4"}
+                            "(profiles/traffic.json, scaled from a 4096-pair PMC pass). The kernels of this path are "
+                            "instruction-issue bound, see roofline_valu and DESIGN.md section 4"}
         # VALU-side roofline of the same kernel: wave64 VALU instructions issued per step (PMC SQ_INSTS_VALU,
         # profiles/traffic.json) / its measured time, against SIMDs x clock / 2 (a wave64 VALU op occupies a
         # gfx950 SIMD for two clocks, MI355X_MICROARCH.md); the clock is the sustained one observed under this load
@@ -776,17 +776,18 @@ def main():
                              "unit": "G wave64 VALU instructions/s", "frac": round(ach / peak_nominal, 4),
                              "valu_instructions_per_step": valu[dom],
                              "note": "VALU instructions = rocprofv3 --pmc SQ_INSTS_VALU of this kernel class per step "
-                                     "(profiles/traffic.json; every instruction counts once: 366.5 per diagonal step of the fused "
-                                     "kernel), time from this run; peak = 1024 SIMDs x 2.4 GHz / 2 clocks per wave64 instruction "
-                                     "(MI355X_MICROARCH.md) -- a rate the SIMD reaches only by pairing plain VALU instructions of two "
-                                     "wavefronts; DPP and transcendental instructions force single issue (~4 clocks), "
-                                     "profiles/README.md snapshot r02_c"}
+                                     "(profiles/traffic.json, a 4096-pair PMC pass scaled by the frame count; every instruction "
+                                     "counts once), time from this run; peak = 1024 SIMDs x 2.4 GHz / 2 clocks per wave64 "
+                                     "instruction (MI355X_MICROARCH.md).  The kernels of this path never see that rate: with "
+                                     "memory, scalar and wait instructions in the stream a SIMD issues about one instruction of "
+                                     "any kind per 4 clocks (frac_of_single_issue_rate; DESIGN.md section 4, "
+                                     "profiles/README.md round 3)"}
             if clk:
                 roofline_valu["sustained_clock_ghz"] = clk
                 roofline_valu["frac_at_sustained_clock"] = round(ach / (simds * clk / 2.0), 4)
-                # the rate of a stream that cannot pair (this kernel's: DPP moves and transcendentals): one VALU
-                # instruction per ~4.2 clocks per SIMD (tools/probes/issue_probe.hip, profiles/README.md r02_c)
-                roofline_valu["frac_of_single_issue_rate"] = round(ach / (simds * clk / 4.2), 4)
+                # the rate real kernels get on this chip: one instruction per ~4 clocks per SIMD (VALU instructions alone
+                # here; the kernel's scalar / memory instructions take slots of the same budget)
+                roofline_valu["frac_of_single_issue_rate"] = round(ach / (simds * clk / 4.0), 4)
         result = {
             "metric": "frames/sec at 1024×436 op-point-2 (INT)", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

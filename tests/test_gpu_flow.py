@@ -330,6 +330,8 @@ def test_baseline_config4_rgb_1080p(gpu, orc):
     ref = orc.flow(p, pa[0], pa[1], pa[2], pb[0])
     got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
     assert_bits_equal(got, ref, "config 4")
+    if oracle.have_ref("rgb", True):  # ... and directly against the reference sources compiled in place (defined-order build)
+        assert_bits_equal(got, oracle.ref("rgb", True).flow(p, pa[0], pa[1], pa[2], pb[0]), "config 4 vs the reference build")
 
 
 def _random_config(rng):
