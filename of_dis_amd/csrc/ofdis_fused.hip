@@ -238,6 +238,7 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   float ru[NS], rv[NS], ru2[NS], rv2[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) { ru[s] = rv[s] = ru2[s] = rv2[s] = 0.0f; }
+  float ldx = 0.0f, ldy = 0.0f;  // wx, wy of the pixel row being assembled minus those of the row before (set below)
 
   auto wrap_row = [&](int r) { r %= rw; return r < 0 ? r + rw : r; };  // diag row of the strip
   auto wrap_col = [&](int c) { c %= w; return c < 0 ? c + w : c; };    // column within a frame
@@ -346,13 +347,14 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           if (x2_last) { ur = uc; vr = vc; }
           if (!has_top) { ut = uc; vt = vc; }
           if (!has_bot) { ub = uc; vb = vc; }
-          // the reference's middle tap is -0 * centre: adding a signed zero changes at most the sign of a zero
-          // result, and each derivative is only ever squared
-          const float ux = D3_C0 * ul + D3_C2 * ur;
-          const float vx = D3_C0 * vl + D3_C2 * vr;
-          const float uy = D3_C0 * ut + D3_C2 * ub;
-          const float vy = D3_C0 * vt + D3_C2 * vb;
-          sm[(u + 2) % 3] = fdiv_by_sqrt(qa, ux * ux + uy * uy + vx * vx + vy * vy + EPS_SMOOTH);
+          // The reference's derivative is ux = -0.5 ul + (-0 uc) + 0.5 ur.  The middle tap adds a signed zero (it changes at
+          // most the sign of a zero result, and each derivative is only ever squared); the outer taps are exact scalings,
+          // so ux = 0.5 (ur - ul) with the same single rounding, ux^2 = 0.25 (ur - ul)^2, and a sum of such squares is 0.25
+          // times the sum of the unscaled ones, rounding for rounding (powers of two commute with every rounding; a square
+          // small enough to underflow is 30 orders of magnitude below half an ulp of the 1e-6 added next).  Four
+          // subtractions, four squares, three additions and ONE scaling instead of eight scalings on top of them.
+          const float ex = ur - ul, fx = vr - vl, ey = ub - ut, fy = vb - vt;
+          sm[(u + 2) % 3] = fdiv_by_sqrt(qa, 0.25f * (ex * ex + ey * ey + fx * fx + fy * fy) + EPS_SMOOTH);
         }
         // ---- (4) system of pixel row tau = t+1 (opticalflow_aux.c:150-163, 172-199, 342-427)
         //      x of row tau is x2 of the previous step: "last column" was x2_last then
@@ -371,10 +373,13 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           const float wx_d = from_next(rp.wx), wy_d = from_next(rp.wy);
           const float sh_l = slot[u % 6].sh;         // (s_l + sc), 0 on column 0
           const float sv_t = from_prev(slot[u % 6].sv);  // (s_u + sc), 0 on row 0
-          b1 -= sh_l * (rc.wx - rm.wx);
-          b2 -= sh_l * (rc.wy - rm.wy);
-          b1 += sh_c * (rp.wx - rc.wx);
-          b2 += sh_c * (rp.wy - rc.wy);
+          // (the difference to the left neighbour is the previous step's difference to the right neighbour)
+          const float rdx = rp.wx - rc.wx, rdy = rp.wy - rc.wy;
+          b1 -= sh_l * ldx;
+          b2 -= sh_l * ldy;
+          b1 += sh_c * rdx;
+          b2 += sh_c * rdy;
+          ldx = rdx; ldy = rdy;
           b1 -= sv_t * (rc.wx - wx_u);
           b2 -= sv_t * (rc.wy - wy_u);
           b1 += sv_c * (wx_d - rc.wx);
@@ -447,6 +452,11 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
             const unsigned q0 = q[0], q1 = q[1];
             if (row_ok && ig >= 0 && ig < wtot)
               flow_row[ig] = make_float2(asf(q0) + nu[NS - 1], asf(q1) + nv[NS - 1]);
+          } else if (!MW) {
+            // (no branch: a lane outside its rows / columns stores at an offset beyond the resource, which the hardware drops)
+            const u32x2 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), __builtin_bit_cast(unsigned, nv[NS - 1])};
+            const bool on = row_ok & (ig >= 0) & (ig < wtot);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rsU, on ? vo2 : 0x7ffffff0, srow * h * 8, 0);
           } else if (row_ok && ig >= 0 && ig < wtot) {
             const u32x2 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), __builtin_bit_cast(unsigned, nv[NS - 1])};
             __builtin_amdgcn_raw_buffer_store_b64(v, rsU, vo2, srow * h * 8, 0);
