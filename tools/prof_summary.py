@@ -32,7 +32,8 @@ if rows and "Start_Timestamp" in rows[0]:  # kernel trace
         name = short(r)
         i = seen.get(name, 0)
         seen[name] = i + 1
-        per_pass = max(1, calls[name] // passes) if calls[name] % passes == 0 else 1
+        # (a single pass gives no cycle to find: the rows are then keyed on the geometry alone)
+        per_pass = max(1, calls[name] // passes) if (passes > 1 and calls[name] % passes == 0) else 1
         key = (name, i % per_pass, r.get("Grid_Size") or r.get("Grid_Size_X"), r.get("Workgroup_Size") or r.get("Workgroup_Size_X"))
         acc.setdefault(key, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     tot = sum(sum(v) for v in acc.values())
