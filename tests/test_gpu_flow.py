@@ -580,3 +580,25 @@ def test_dropin_from_several_threads(gpu, orc):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("size,channels,opp,seed", [((1024, 436), 1, 2, 11), ((640, 480), 1, 2, 12), ((333, 251), 1, 1, 13),
+                                                    ((320, 240), 3, 3, 14), ((256, 128), 1, 2, 15)])
+def test_block_world_inputs(gpu, orc, size, channels, opp, seed):
+    """A second input family (tools/gen_synth.py: make_pair_blocks): flat-shaded rectangles with hard edges, each with its own
+    sub-pixel velocity, occlusions, saturated regions, objects leaving the frame, per-frame noise -- outlier resets, warps
+    that leave the image (zero mask: the fused TV path stores an all-zero derivative record there) and flat regions with
+    near-singular Hessians in one picture.  Bit-exact against the restatement and the compiled reference."""
+    import gen_synth
+    from of_dis_amd.params import oppoint
+    w, h = size
+    ia, ib = gen_synth.make_pair_blocks(w, h, seed, channels)
+    p = oppoint(opp, w, h, noc=channels)
+    O = oracle.c_oracle()
+    pa, pb = O.build_pyramid(p, ia), O.build_pyramid(p, ib)
+    got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
+    assert_bits_equal(got, orc.flow(p, pa[0], pa[1], pa[2], pb[0]), "block world vs restatement")
+    mode = "int" if channels == 1 else "rgb"
+    if oracle.have_ref(mode, True):
+        assert_bits_equal(got, oracle.ref(mode, True).flow(p, pa[0], pa[1], pa[2], pb[0]), "block world vs the reference build")
+    assert np.isfinite(got).all()

@@ -138,3 +138,22 @@ def test_reduction_order_sensitivity_is_tiny():
     mean, mx, frac = oracle.epe_stats(a, b)
     s = 1 << p.sc_l
     assert mean * s < 1e-4 and mx * s < 1e-2, (mean * s, mx * s, frac)
+
+
+def test_block_world_inputs_cpu():
+    """The second input family (hard edges, occlusions, saturation): the C restatement against the reference sources
+    compiled in place, both reduction orders, bit for bit."""
+    import gen_synth
+    from of_dis_amd.params import oppoint
+    ia, ib = gen_synth.make_pair_blocks(320, 240, 21)
+    p = oppoint(2, 320, 240)
+    O = oracle.c_oracle()
+    pa, pb = O.build_pyramid(p, ia), O.build_pyramid(p, ib)
+    for wave64 in (False, True):
+        if not oracle.have_ref("int", wave64):
+            pytest.skip("oracle/_ref not built")
+        O.set_reduce_order(wave64)
+        a = O.flow(p, pa[0], pa[1], pa[2], pb[0])
+        b = oracle.ref("int", wave64).flow(p, pa[0], pa[1], pa[2], pb[0])
+        assert np.array_equal(a, b), ("reduce order", wave64)
+    O.set_reduce_order(False)

@@ -47,6 +47,42 @@ def make_pair(w, h, seed=1234, channels=1, flow_scale=1.0):
     return ia, ib, np.stack([u, v], -1).astype(np.float32)
 
 
+def make_pair_blocks(w, h, seed=1234, channels=1, nrect=40, max_shift=9.0):
+    """A second input family, as unlike the band-limited textures as possible: flat-shaded rectangles with hard edges on a
+    noisy gradient background, each moving with its own (fractional, up to `max_shift` px) velocity and drawn back to front,
+    so the pair has occlusions, disocclusions, motion discontinuities, saturated (0 / 255) regions and objects that leave the
+    frame.  Returns (img_a, img_b) uint8 arrays of shape (h,w) or (h,w,3); there is no dense ground truth."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    rects = []
+    for _ in range(nrect):
+        rw, rh = rng.integers(6, max(8, w // 3)), rng.integers(6, max(8, h // 3))
+        x0, y0 = rng.uniform(-rw / 2, w - rw / 2), rng.uniform(-rh / 2, h - rh / 2)
+        vel = rng.uniform(-max_shift, max_shift, 2)
+        col = rng.choice([0.0, 255.0, *rng.uniform(20, 235, 6)], size=channels)
+        rects.append((x0, y0, rw, rh, vel, col, rng.uniform(0.0, 0.5)))
+
+    def render(t):
+        out = []
+        for c in range(channels):
+            img = 128.0 + 60.0 * np.sin(0.037 * (xx + 3.0 * t) + c) * np.cos(0.051 * (yy - 2.0 * t))
+            for x0, y0, rw, rh, vel, col, tex in rects:
+                cx, cy = x0 + t * vel[0], y0 + t * vel[1]
+                # anti-aliased coverage of the (sub-pixel positioned) rectangle: hard edges, one blended pixel row / column
+                cov = np.clip(xx + 0.5 - cx, 0, 1) * np.clip(cx + rw - (xx - 0.5), 0, 1) * \
+                    np.clip(yy + 0.5 - cy, 0, 1) * np.clip(cy + rh - (yy - 0.5), 0, 1)
+                shade = col[c] * (1.0 - tex) + tex * 255.0 * (((xx - cx).astype(int) ^ (yy - cy).astype(int)) & 4 > 0)
+                img = img * (1 - cov) + shade * cov
+            img = img + rng_noise[c]
+            out.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+        return out[0] if channels == 1 else np.stack(out, -1)
+    rng_noise = [rng.normal(0, 2.0, (h, w)) for _ in range(channels)]
+    ia = render(0.0)
+    rng_noise = [rng.normal(0, 2.0, (h, w)) for _ in range(channels)]
+    ib = render(1.0)
+    return ia, ib
+
+
 def write_pgm(path, img):
     img = np.ascontiguousarray(img)
     with open(path, "wb") as f:
