@@ -602,3 +602,35 @@ def test_block_world_inputs(gpu, orc, size, channels, opp, seed):
     if oracle.have_ref(mode, True):
         assert_bits_equal(got, oracle.ref(mode, True).flow(p, pa[0], pa[1], pa[2], pb[0]), "block world vs the reference build")
     assert np.isfinite(got).all()
+
+
+@pytest.mark.parametrize("size,level,nfr,strip", [((256, 512), 3, 8, 2), ((256, 512), 3, 8, 4), ((128, 512), 3, 6, 2),
+                                                  ((128, 512), 3, 8, 8), ((536, 512), 3, 4, 2), ((712, 304), 3, 4, 2)])
+def test_fused_tv_strips_odd_geometries(gpu, orc, size, level, nfr, strip):
+    """Strips on levels that are taller than wide (32x64, 16x64: the diag rows of a strip wrap several times within one
+    frame's columns), of widths that leave lanes of the row-marching kernel idle (67, 89) and of even / odd band splits, as
+    ONE level of the path through the batch interface (sc_f = sc_l = level; sizes are multiples of 2^level)."""
+    import gen_synth
+    from of_dis_amd.params import oppoint
+    w, h = size
+    p = oppoint(2, w, h).copy(sc_f=level, sc_l=level, width=w, height=h)
+    O = oracle.c_oracle()
+    cases = []
+    for k in range(3):
+        ia, ib, _ = gen_synth.make_pair(w, h, 2500 + k)
+        cases.append((O.build_pyramid(p, ia), O.build_pyramid(p, ib)))
+    refs = [orc.flow(p, pa[0], pa[1], pa[2], pb[0]) for pa, pb in cases]
+    for variant in ({"fused_mw_max": 0, "fused_strip": strip}, {"fused_mw_max": 1 << 30, "fused_strip": 0}):
+        old = gpu.set_tuning(**variant)
+        try:
+            b = gpu.Batch(p, nfr)
+            for kind in range(4):
+                planes = [pa[kind][level] if kind < 3 else pb[0][level] for pa, pb in cases]
+                b.set_input(level, kind, np.stack([planes[(s * 2 + s // 3) % 3] for s in range(nfr)]))
+            b.run()
+            out = b.download_all()
+            for s in range(nfr):
+                assert_bits_equal(out[s], refs[(s * 2 + s // 3) % 3], f"{size} level {level}, {variant}, slot {s}")
+            b.close()
+        finally:
+            gpu.restore_tuning(old)
