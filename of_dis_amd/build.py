@@ -16,7 +16,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 ROOT = os.path.dirname(HERE)
 
-HIP_SOURCES = ["ofdis_dis.hip", "ofdis_tv.hip", "ofdis_prep.hip", "ofdis_sor.hip", "ofdis_fused.hip", "ofdis_de.hip",
+HIP_SOURCES = ["ofdis_dis.hip", "ofdis_tv.hip", "ofdis_prep.hip", "ofdis_sor.hip", "ofdis_fused.hip", "ofdis_fused_xcu.hip",
+               "ofdis_de.hip",
                "ofdis_pyr.hip", "ofdis_capi.hip"]
 # -ffp-contract=off: every fp32 operation separately rounded, like the reference's SSE path.
 # -fvisibility=hidden: the shared library exports the C ABI of include/ofdis.h (marked in ofdis_capi.hip) and nothing else.
@@ -29,6 +30,7 @@ HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "
 # moves that assemble register pairs are pure overhead; in ofdis_dis.hip it also splits the DPP reduction chains.
 _NO_SLP = ["-fno-slp-vectorize"]
 PER_FILE_FLAGS = {"ofdis_dis.hip": _NO_SLP, "ofdis_tv.hip": _NO_SLP, "ofdis_prep.hip": _NO_SLP, "ofdis_fused.hip": _NO_SLP,
+                  "ofdis_fused_xcu.hip": _NO_SLP,
                   "ofdis_sor.hip": _NO_SLP}
 
 

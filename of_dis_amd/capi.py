@@ -38,7 +38,8 @@ ABI_SYMBOLS = [
 class OfdisTuning(C.Structure):
     """include/ofdis.h: ofdis_tuning -- kernel-selection knobs, every setting bit-identical."""
     _fields_ = [(n, C.c_int) for n in ("gray8", "rgb12", "rgb12_lpp", "fused_tv", "fused_mw_max", "fused_split",
-                                       "finish_fusion", "fused_strip", "prep_band_rows", "graph", "flow_dma", "flow_whole")]
+                                       "finish_fusion", "fused_strip", "prep_band_rows", "graph", "flow_dma", "flow_whole",
+                                       "fused_xcu_max")]
 
 
 class OfdisError(RuntimeError):

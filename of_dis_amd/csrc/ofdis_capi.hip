@@ -46,6 +46,7 @@ void tuning_init_locked() {
   g_tuning.graph = !on("OFDIS_NO_GRAPH");
   g_tuning.flow_dma = on("OFDIS_FLOW_DMA");
   g_tuning.flow_whole = on("OFDIS_FLOW_WHOLE");
+  g_tuning.fused_xcu_max = std::max(0, num("OFDIS_FUSED_XCU_MAX", 256));
   g_tuning_init = true;
 }
 }  // namespace
@@ -175,6 +176,8 @@ struct ofdis_batch {
   float *w_im2 = nullptr, *derivs = nullptr, *sys = nullptr;
   float *wrec = nullptr, *uv = nullptr;  // fused TV path: the (wx, wy) and (du, dv) records; `derivs` holds the
                                          // derivative records there (ofdis_dev.h: sdiag_index)
+  float* xbuf = nullptr;                 // ... and the hand-over granules of its cross-CU variant (small contexts only)
+  size_t xbuf_per_frame = 0;             // floats
   std::vector<float*> pyr_tmp;       // unpadded level images (ofdis_batch_build_pyramids_u8), lazily allocated
   // device memory: requests are collected (dalloc) and served from ONE hipMalloc per commit (dcommit) -- a context is
   // one allocation (two with the u8 pyramid scratch), and the input planes form one contiguous region [in_base,
@@ -255,6 +258,37 @@ struct KTimer {  // brackets one launch with events when timing is on
   }
 };
 
+// Cross-CU variant of the fused TV kernel (ofdis_fused.hip, MODE 3): contexts up to this many frames own the hand-over
+// granule array; a wavefront whose hand-over row never arrives (bounded wait) sets a word in mapped host memory that the
+// synchronising entry points check -- the call then fails instead of returning a wrong flow, and the variant is switched
+// off for the rest of the process.
+constexpr int XCU_MAX_CONTEXT_FRAMES = 256;
+int* g_xcu_err_host = nullptr;
+int* g_xcu_err_dev = nullptr;
+std::once_flag g_xcu_err_once;
+int* xcu_err_word() {
+  std::call_once(g_xcu_err_once, [] {
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, sizeof(int), hipHostMallocMapped) != hipSuccess) return;
+    *(volatile int*)h = 0;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return; }
+    g_xcu_err_host = (int*)h;
+    g_xcu_err_dev = (int*)d;
+  });
+  return g_xcu_err_dev;
+}
+int xcu_check() {  // after a synchronisation
+  if (g_xcu_err_host && *(volatile int*)g_xcu_err_host) {
+    *(volatile int*)g_xcu_err_host = 0;
+    ofdis_tuning t = ofdis::tuning();
+    t.fused_xcu_max = 0;
+    (void)ofdis_set_tuning(&t);
+    return fail(OFDIS_ERR_DEVICE, "fused TV kernel (cross-CU variant): a hand-over row never arrived; the variant is now off");
+  }
+  return OFDIS_OK;
+}
+
 DisArgs dis_args(const ofdis_params& p, const LevelGeom& g, int nframes) {
   DisArgs a;
   memset(&a, 0, sizeof(a));
@@ -321,7 +355,8 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
     const ofdis_tuning tn = tuning();
     FusedArgs fa{t, b->derivs, b->wrec, b->uv, 1, c.quarter_alpha, c.half_delta_over3, c.half_gamma_over3, p.tv_solverit,
                  p.tv_sor, n_inner, b->total_frames, tn.finish_fusion ? flow_out : nullptr, tn.fused_mw_max, tn.fused_split};
-    if (tv_fused_mode(fa) == 0) fa.S = strip_length(b, g, tn);  // strips: throughput mapping only
+    const FusedXcu fx{b->xbuf, tn.fused_xcu_max, b->xbuf ? xcu_err_word() : nullptr};
+    if (tv_fused_mode(fa, &fx) == 0) fa.S = strip_length(b, g, tn);  // strips: throughput mapping only
     {  // image_warp + get_derivatives (refine_variational.cpp:189-190): one kernel, records out
       KTimer kt(b, OFDIS_K_DERIV, s);
       PrepArgs pa{t, im_a, im_b, g.pad, g.tmp_w, g.tmp_h, flow_out, b->derivs, b->wrec, fa.S, tn.prep_band_rows};
@@ -330,7 +365,7 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
     bool flow_written = false;  // the multi-wave variants of the fused kernel write the refined AoS flow themselves
     {  // every fixed-point iteration of this level in one launch (du = dv = 0 on its first pass: no memset)
       KTimer kt(b, OFDIS_K_FUSED, s);
-      HIPCHK(launch_tv_fused(fa, s, &flow_written));
+      HIPCHK(launch_tv_fused(fa, s, &flow_written, &fx));
     }
     if (!flow_written) {
       KTimer kt(b, OFDIS_K_UPDATE, s);
@@ -536,6 +571,13 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
     if (!rc && may_fuse) {
       rc = dalloc(b, &b->wrec, npx * 2);
       if (!rc) rc = dalloc(b, &b->uv, npx * 2);
+      if (!rc && nframes <= XCU_MAX_CONTEXT_FRAMES) {  // {du, tag, dv, tag} per pixel and iteration boundary (ofdis_fused.hip)
+        for (auto& g : b->geom) {
+          const size_t n_inner = (size_t)std::max(1, p->tv_innerit * (g.level + 1));
+          b->xbuf_per_frame = std::max(b->xbuf_per_frame, (n_inner - 1) * g.w * g.h * 4);
+        }
+        rc = dalloc(b, &b->xbuf, b->xbuf_per_frame * nframes);
+      }
     }
   }
   if (!rc) rc = dcommit(b);
@@ -681,7 +723,7 @@ ofdis_batch frame_view(const ofdis_batch& b, int f0, int n) {
   off(v.pvec_bw, nop_max * 2); off(v.pweight_bw, nop_max * g0.novals);
   off(v.wx, npx); off(v.wy, npx); off(v.du, npx); off(v.dv, npx); off(v.mask, npx); off(v.uu, npx);
   off(v.w_im2, npx * b.p.noc); off(v.derivs, npx * 8 * b.p.noc); off(v.sys, npx * 7);
-  off(v.wrec, npx * 2); off(v.uv, npx * 2);
+  off(v.wrec, npx * 2); off(v.uv, npx * 2); off(v.xbuf, b.xbuf_per_frame);
   return v;
 }
 
@@ -941,7 +983,7 @@ int ofdis_batch_download(ofdis_batch* b, int frame, float* outflow_host, void* s
   HIPCHK(hipMemcpyAsync(outflow_host, b->flow[0] + (size_t)frame * n, n * sizeof(float), hipMemcpyDeviceToHost,
                         (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-  return OFDIS_OK;
+  return xcu_check();
 }
 
 // Warm start (oflow.cpp:217-220): the coarsest level initialises its patches from this flow exactly as finer levels
@@ -1158,6 +1200,7 @@ int flow_with_ctx(FlowCtx& ctx, const ofdis_params* p, const float* const* im_a,
   if (use_dma || (c->flow_bytes & 15)) HIPCHK(hipMemcpyAsync(out_stage, b->flow[0], c->flow_bytes, hipMemcpyDeviceToHost, c->s));
   else HIPCHK(launch_copy16(out_stage, b->flow[0], c->flow_bytes, c->s));
   HIPCHK(hipStreamSynchronize(c->s));
+  if ((rc = xcu_check())) return rc;
   memcpy(outflow, out_stage, c->flow_bytes);
   return OFDIS_OK;
 }
@@ -1325,6 +1368,10 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   if (!rc && want_fused) {
     rc = dalloc(&b, &b.wrec, npx * 2);
     if (!rc) rc = dalloc(&b, &b.uv, npx * 2);
+    if (!rc && nframes <= XCU_MAX_CONTEXT_FRAMES) {
+      b.xbuf_per_frame = (size_t)std::max(0, p->tv_innerit * (level + 1) - 1) * g.w * g.h * 4;
+      rc = dalloc(&b, &b.xbuf, b.xbuf_per_frame * nframes);
+    }
   }
   if (!rc && p->selectmode == 2) rc = dalloc(&b, &b.uu, npx);
   if (!rc) rc = dcommit(&b);
@@ -1344,6 +1391,7 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   }
   hipError_t e = hipStreamSynchronize(s);
   if (!rc && e != hipSuccess) rc = hipfail(e, "sync");
+  if (!rc) rc = xcu_check();
   for (void* d : b.allocs) (void)hipFree(d);
   b.allocs.clear();
   return rc;
@@ -1358,7 +1406,8 @@ int ofdis_get_tuning(ofdis_tuning* out) {
 int ofdis_set_tuning(const ofdis_tuning* in) {
   if (!in) return fail(OFDIS_ERR_INVALID, "tuning is NULL");
   if (in->rgb12_lpp != 64 && in->rgb12_lpp != 32) return fail(OFDIS_ERR_INVALID, "rgb12_lpp must be 64 or 32");
-  if (in->fused_mw_max < 0 || in->fused_strip < 0 || in->prep_band_rows < 0) return fail(OFDIS_ERR_INVALID, "negative knob");
+  if (in->fused_mw_max < 0 || in->fused_strip < 0 || in->prep_band_rows < 0 || in->fused_xcu_max < 0)
+    return fail(OFDIS_ERR_INVALID, "negative knob");
   ofdis::tuning();  // initialise from the environment first
   std::lock_guard<std::mutex> lock(ofdis::g_tuning_mutex);
   ofdis::g_tuning = *in;

@@ -1,0 +1,87 @@
+// ofdis_fused.h -- what the variants of the fused TV kernel share (ofdis_fused.hip: throughput, multi-wave, split;
+// ofdis_fused_xcu.hip: cross-CU): the trimmed quotients, the per-pixel records and the gray data term.
+#pragma once
+#include "ofdis_kernels.h"
+#include "ofdis_tvmath.h"
+
+namespace ofdis {
+
+// Quotients of this kernel: denominators are normal and positive by construction (n >= 0.01, sqrt(.. + 1e-6) >= 1e-3,
+// det >= (sum of edge weights)^2 > 0) and numerators are finite for finite images, so v_div_fixup_f32 has nothing to
+// fix (ofdis_dev.h: div_by_finite).
+struct FDen {  // a denominator prepared once for all its quotients
+  float nb, r;
+};
+__device__ __forceinline__ FDen fden(float b) {
+  // 0 - b, not -b: a subtraction from +0 is not a negation for the compiler (signed zeros), so it stays one plain
+  // instruction and is not folded back into a source modifier (VOP3) of every fma that uses it
+  return FDen{0.0f - b, rcp_refined(b)};
+}
+__device__ __forceinline__ float fdiv_by(float a, const FDen& d) { return div_by_finite(a, d.nb, d.r); }
+__device__ __forceinline__ float fdiv_rn(float a, float b) { return fdiv_by(a, fden(b)); }
+__device__ __forceinline__ float fdiv_by_sqrt(float num, float x) { return fdiv_rn(num, sqrt_rn(x)); }  // num / sqrt(x)
+
+struct FSlot {
+  float a11, a12, a22, b1, b2, sh, sv;  // system of pixel (j, tau - j); a** become the block inverse at step tau
+  float dur, dvr;                       // old du,dv of the right neighbour (row tau+1)
+  float hl, vt;                         // left / top edge weights (= sh of the left, sv of the upper pixel)
+};
+struct FRow {
+  float wx, wy, du, dv;  // the pixel's (wx, wy) record and its du, dv of before this iteration
+};
+struct FDer {  // the pixel's derivative record, in the order ofdis_prep.hip stores it
+  float ix, iz, ixx, ixz, iy, ixy, iyz, iyy;
+};
+
+// Data term of one gray pixel: ofdis_tvmath.h data_term() with the divisions and square roots written out
+// (ofdis_dev.h: div_by / sqrt_rn; same bits for the operand ranges the launcher guarantees) and the refined
+// reciprocal of each normaliser shared by the two quotients that use it.
+// The warp's mask (opticalflow_aux.c:352,381: it multiplies both weights) is not an operand: ofdis_prep.hip stores an
+// all-zero record for a masked pixel, and zero derivatives give the same coefficients as zero weights -- every product
+// below is then +-0 * finite and every accumulator ends as +0 either way (sums of signed zeros starting from +0).
+template <bool BRIGHT>
+__device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, float hd3, float hg3, float& a11,
+                                               float& a12, float& a22, float& b1, float& b2) {
+  const float ix = D.ix, iy = D.iy, iz = D.iz, ixx = D.ixx, ixy = D.ixy, iyy = D.iyy, ixz = D.ixz, iyz = D.iyz;
+  a11 = 0.0f; a12 = 0.0f; a22 = 0.0f; b1 = 0.0f; b2 = 0.0f;
+  float tmp, tmp2, n1, n2;
+  if (BRIGHT) {  // hd3 != 0 (opticalflow_aux.c:352)
+    tmp = iz + ix * u + iy * v;
+    n1 = ix * ix + iy * iy + DATANORM;
+    const FDen d1 = fden(n1);
+    tmp = fdiv_by_sqrt(hd3, fdiv_by(3 * tmp * tmp, d1) + EPS_COLOR);
+    tmp = fdiv_by(tmp, d1);
+    a11 += tmp * ix * ix;
+    a12 += tmp * ix * iy;
+    a22 += tmp * iy * iy;
+    b1 -= tmp * iz * ix;
+    b2 -= tmp * iz * iy;
+  }
+  n1 = ixx * ixx + ixy * ixy + DATANORM;
+  n2 = iyy * iyy + ixy * ixy + DATANORM;
+  const FDen d1 = fden(n1), d2 = fden(n2);
+  tmp = ixz + ixx * u + ixy * v;
+  tmp2 = iyz + ixy * u + iyy * v;
+  tmp = fdiv_by_sqrt(hg3, fdiv_by(3 * tmp * tmp, d1) + fdiv_by(3 * tmp2 * tmp2, d2) + EPS_GRAD);
+  tmp2 = fdiv_by(tmp, d2);
+  tmp = fdiv_by(tmp, d1);
+  a11 += tmp * ixx * ixx + tmp2 * ixy * ixy;
+  a12 += tmp * ixx * ixy + tmp2 * ixy * iyy;
+  a22 += tmp2 * iyy * iyy + tmp * ixy * ixy;
+  b1 -= tmp * ixx * ixz + tmp2 * ixy * iyz;
+  b2 -= tmp2 * iyy * iyz + tmp * ixy * ixz;
+  a11 *= 3; a12 *= 3; a22 *= 3; b1 *= 3; b2 *= 3;
+}
+
+// Workgroup barrier of the multi-wave variant's step loop.  Only LDS traffic crosses wavefronts there (the du/dv ring), so
+// only the LDS counter is drained: __syncthreads() also waits for vmcnt(0), i.e. for the global row loads that are
+// deliberately kept 3-5 steps in flight, and would expose one memory latency per step.
+__device__ __forceinline__ void mw_step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int SLOT_FLOATS = 11;  // FSlot
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// Launch of the cross-CU variant (ofdis_fused_xcu.hip); waves = frame groups, R = lanes per frame of a group
+hipError_t launch_tv_fused_xcu(const FusedArgs& a, const FusedXcu& x, int waves, int R, hipStream_t s);
+
+}  // namespace ofdis

@@ -50,77 +50,9 @@
 // value as the reference's folded (c0+c1)*s0 + c2*s1 because c1 = -0 (image.c:376-399).
 #include <stdlib.h>
 
-#include "ofdis_kernels.h"
-#include "ofdis_tvmath.h"
+#include "ofdis_fused.h"
 
 namespace ofdis {
-
-// Quotients of this kernel: denominators are normal and positive by construction (n >= 0.01, sqrt(.. + 1e-6) >= 1e-3,
-// det >= (sum of edge weights)^2 > 0) and numerators are finite for finite images, so v_div_fixup_f32 has nothing to
-// fix (ofdis_dev.h: div_by_finite).
-struct FDen {  // a denominator prepared once for all its quotients
-  float nb, r;
-};
-__device__ __forceinline__ FDen fden(float b) {
-  // 0 - b, not -b: a subtraction from +0 is not a negation for the compiler (signed zeros), so it stays one plain
-  // instruction and is not folded back into a source modifier (VOP3) of every fma that uses it
-  return FDen{0.0f - b, rcp_refined(b)};
-}
-__device__ __forceinline__ float fdiv_by(float a, const FDen& d) { return div_by_finite(a, d.nb, d.r); }
-__device__ __forceinline__ float fdiv_rn(float a, float b) { return fdiv_by(a, fden(b)); }
-__device__ __forceinline__ float fdiv_by_sqrt(float num, float x) { return fdiv_rn(num, sqrt_rn(x)); }  // num / sqrt(x)
-
-struct FSlot {
-  float a11, a12, a22, b1, b2, sh, sv;  // system of pixel (j, tau - j); a** become the block inverse at step tau
-  float dur, dvr;                       // old du,dv of the right neighbour (row tau+1)
-  float hl, vt;                         // left / top edge weights (= sh of the left, sv of the upper pixel)
-};
-struct FRow {
-  float wx, wy, du, dv;  // the pixel's (wx, wy) record and its du, dv of before this iteration
-};
-struct FDer {  // the pixel's derivative record, in the order ofdis_prep.hip stores it
-  float ix, iz, ixx, ixz, iy, ixy, iyz, iyy;
-};
-
-// Data term of one gray pixel: ofdis_tvmath.h data_term() with the divisions and square roots written out
-// (ofdis_dev.h: div_by / sqrt_rn; same bits for the operand ranges the launcher guarantees) and the refined
-// reciprocal of each normaliser shared by the two quotients that use it.
-// The warp's mask (opticalflow_aux.c:352,381: it multiplies both weights) is not an operand: ofdis_prep.hip stores an
-// all-zero record for a masked pixel, and zero derivatives give the same coefficients as zero weights -- every product
-// below is then +-0 * finite and every accumulator ends as +0 either way (sums of signed zeros starting from +0).
-template <bool BRIGHT>
-__device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, float hd3, float hg3, float& a11,
-                                               float& a12, float& a22, float& b1, float& b2) {
-  const float ix = D.ix, iy = D.iy, iz = D.iz, ixx = D.ixx, ixy = D.ixy, iyy = D.iyy, ixz = D.ixz, iyz = D.iyz;
-  a11 = 0.0f; a12 = 0.0f; a22 = 0.0f; b1 = 0.0f; b2 = 0.0f;
-  float tmp, tmp2, n1, n2;
-  if (BRIGHT) {  // hd3 != 0 (opticalflow_aux.c:352)
-    tmp = iz + ix * u + iy * v;
-    n1 = ix * ix + iy * iy + DATANORM;
-    const FDen d1 = fden(n1);
-    tmp = fdiv_by_sqrt(hd3, fdiv_by(3 * tmp * tmp, d1) + EPS_COLOR);
-    tmp = fdiv_by(tmp, d1);
-    a11 += tmp * ix * ix;
-    a12 += tmp * ix * iy;
-    a22 += tmp * iy * iy;
-    b1 -= tmp * iz * ix;
-    b2 -= tmp * iz * iy;
-  }
-  n1 = ixx * ixx + ixy * ixy + DATANORM;
-  n2 = iyy * iyy + ixy * ixy + DATANORM;
-  const FDen d1 = fden(n1), d2 = fden(n2);
-  tmp = ixz + ixx * u + ixy * v;
-  tmp2 = iyz + ixy * u + iyy * v;
-  tmp = fdiv_by_sqrt(hg3, fdiv_by(3 * tmp * tmp, d1) + fdiv_by(3 * tmp2 * tmp2, d2) + EPS_GRAD);
-  tmp2 = fdiv_by(tmp, d2);
-  tmp = fdiv_by(tmp, d1);
-  a11 += tmp * ixx * ixx + tmp2 * ixy * ixy;
-  a12 += tmp * ixx * ixy + tmp2 * ixy * iyy;
-  a22 += tmp2 * iyy * iyy + tmp * ixy * ixy;
-  b1 -= tmp * ixx * ixz + tmp2 * ixy * iyz;
-  b2 -= tmp2 * iyy * iyz + tmp * ixy * ixz;
-  a11 *= 3; a12 *= 3; a22 *= 3; b1 *= 3; b2 *= 3;
-}
 
 // Border handling.  The reference special-cases every border (solver.c:77-421, opticalflow_aux.c:172-199).  Here
 // an edge weight that does not exist IS zero -- sh = 0 on the last column, sv = 0 on the last row (and in the
@@ -132,19 +64,12 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
 // every such system has at least one positive edge weight (quarter_alpha > 0 is a launch condition, a pixel is
 // never first and last column at once), so det >= (sum of weights)^2 > 0; the slot ring starts with a unit
 // diagonal and unit weights.
-// Workgroup barrier of the multi-wave variant's step loop.  Only LDS traffic crosses wavefronts there (the du/dv ring), so
-// only the LDS counter is drained: __syncthreads() also waits for vmcnt(0), i.e. for the global row loads that are
-// deliberately kept 3-5 steps in flight, and would expose one memory latency per step.
-__device__ __forceinline__ void mw_step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 constexpr int MW_LAG = 10;       // MODE 1: steps between consecutive iterations' wavefronts: PDW + 2*(NS-1) + 1 for NS = 3
 constexpr int MW_MAX_ITERS = 8;  // MODE 1: wavefronts per workgroup (= fixed-point iterations it handles)
 constexpr int MW_RING = 8;       // LDS rows of du/dv per iteration (a power of two)
 constexpr int SP_LAG = 9;        // MODE 2: du/dv are read 4 rows ahead instead of PDW = 5: 4 + 2*(NS-1) + 1
 constexpr int SP_MAX_ITERS = 6;  // MODE 2: 2 wavefronts per iteration, 12 per workgroup (3 per SIMD: 168 VGPRs each)
-constexpr int SLOT_FLOATS = 11;  // FSlot
 
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // MODE 0: one wavefront walks all fixed-point iterations of its strip(s) (the throughput kernel).
 // MODE 1: "multi-wave" -- one workgroup per frame group, wavefront k runs iteration k (header comment); S = 1.
@@ -499,17 +424,18 @@ bool tv_fused_params_ok(float qa, float hd3, float hg3) {
 // FusedArgs::mw_max_groups (default 512) frame groups in the launch AND at most 1024 frames in the whole batch.
 constexpr int MW_MAX_BATCH_FRAMES = 1024;
 
-int tv_fused_mode(const FusedArgs& a) {
+int tv_fused_mode(const FusedArgs& a, const FusedXcu* x) {
   const int h = a.t.h;
   const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
   const int groups = (a.t.nframes + 64 / R - 1) / (64 / R);
   const int total = a.total_frames > 0 ? a.total_frames : a.t.nframes;
+  if (x && x->xbuf && a.S == 1 && a.n_inner >= 2 && groups <= x->max_groups && total <= MW_MAX_BATCH_FRAMES) return 3;
   const bool mw = a.S == 1 && a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS && groups <= a.mw_max_groups &&
                   (total <= MW_MAX_BATCH_FRAMES || a.mw_max_groups >= (1 << 30));
   return mw ? ((a.split && a.n_inner <= SP_MAX_ITERS) ? 2 : 1) : 0;
 }
 
-hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow) {
+hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow, const FusedXcu* x) {
   if (wrote_flow) *wrote_flow = false;
   if (!tv_fused_supported(a.t, a.iterations) || a.n_inner < 1 || a.S < 1 || a.t.nframes % a.S != 0 ||
       !tv_fused_params_ok(a.quarter_alpha, a.half_delta_over3, a.half_gamma_over3))
@@ -522,8 +448,9 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow) 
   const int blocks = (waves + 3) / 4;
   const bool bright = a.half_delta_over3 != 0.0f;
   // small batches: one workgroup per frame group, one (MODE 1) or two (MODE 2) wavefronts per fixed-point iteration
-  const int mode = tv_fused_mode(a);
+  const int mode = tv_fused_mode(a, x);
   if (wrote_flow) *wrote_flow = mode != 0 && a.flow_out != nullptr;
+  if (mode == 3) return launch_tv_fused_xcu(a, *x, waves, R, s);
 #define OFDIS_FUSED_LAUNCH(NS)                                                                                         \
   if (mode == 2) {                                                                                                     \
     if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 2>), dim3(waves), dim3(128 * a.n_inner), 0, s, a, R);    \

@@ -1,0 +1,427 @@
+// ofdis_fused_xcu.hip -- the fused TV kernel of ofdis_fused.hip with every fixed-point iteration of a frame group on its
+// own compute unit (small batches).  Same arithmetic in the same order as the other variants: bit-identical results.
+#include "ofdis_fused.h"
+
+namespace ofdis {
+
+// ------------------------------------------------------------------------------------------- MODE 3: "xcu" (cross-CU)
+// The multi-wave variants of ofdis_fused.hip keep a frame group on ONE compute unit, and a CU issues about one wavefront
+// instruction per clock: a diagonal step of n fixed-point iterations costs n x ~400 instructions / 4 SIMDs x 4 clocks
+// whatever the number of wavefronts (0.79 us per step at level 3).  This variant gives every fixed-point iteration of a
+// frame group its OWN workgroup -- its own CU while the launch has no more workgroups than the chip has CUs -- and divides
+// the iteration's step between FOUR wavefronts, one per SIMD.  A lone wavefront issues one dependent instruction per ~6
+// clocks, so the longest of them sets the step (0.40 us measured):
+//   rows wave  (0): (wx, wy) row loads, flow sums, smoothness, Laplacian products -- then, one step later, the data term's
+//                   five sums from the data wave, the b1 / b2 updates in the reference's order and the block inverse
+//   data wave  (1): derivative record loads and the data term (opticalflow_aux.c:342-427)
+//   solve wave (2): the NS pipelined SOR sweeps, one step behind the other two; publishes the finished du/dv row
+//   fetch wave (3): brings the previous iteration's du/dv rows into an LDS ring, a few rows ahead of the rows wave
+// Hand-overs inside the workgroup go through small LDS arrays and one LDS-only barrier per step, as in MODE 2.
+// Between iterations -- between CUs -- a finished du/dv row travels through global memory as self-validating 16-byte
+// granules {du, tag, dv, tag} written by ONE write-through (sc1) store per lane and read by sc1 loads that bypass the
+// reader's L1 (cdna_hip_programming.md Guideline 16, form R2: the data is the flag; each 8-byte half carries its own tag,
+// so no ordering between stores is needed and nothing depends on dispatch order, timing or workgroup -> XCD placement).
+// Only the fetch wave touches granules: memory returns in order, so in a wavefront that also computes, every nearer load
+// (and the compiler's conservative wait counts around the re-read loop) exposed the 1.2 us hand-off latency at every
+// step.  The fetch wave works in batches: every XC_B steps it takes the XC_B rows it requested XC_B steps ago, checks the
+// tag of every existing pixel -- when one is missing it lets the predecessor gain XC_LEAD rows and re-reads (bounded) --
+// writes them to the ring and requests the next batch.  An iteration so trails its predecessor by ~13 steps + the latency
+// (6.8 us per iteration boundary) and never waits in steady state.
+// The launcher zeroes the granule array before every launch (tag 0 = not yet written).  Block index = iteration * G8 +
+// group with G8 a multiple of 8: an iteration only waits for a LOWER block index, and the iterations of a group share an
+// XCD under the observed round-robin placement (speed only).  A wait that exceeds XC_SPIN_LIMIT re-reads (seconds) sets
+// the caller's error word and the wavefront carries on without waiting: the call fails, nothing hangs.
+constexpr int XC_B = 3;      // rows per batch of the fetch wave (divides 6); requested XC_B steps before they are taken
+constexpr int XC_LEAD = 2;   // rows the fetch wave lets the predecessor gain, beyond its requests, before it (re)starts
+constexpr int XC_RING = 8;   // rows of the LDS du/dv ring (a power of two > XC_B + 1)
+constexpr unsigned XC_TAG = 1u;
+constexpr unsigned XC_SPIN_LIMIT = 1u << 22;  // re-reads of one row (~1 us each) before the wavefront gives up
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NS, bool BRIGHT>
+__global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, const int R, const int G8, float* const xbuf,
+                                                            int* const err) {
+  constexpr int U = 6;
+  constexpr int PDW = 5, PDD = 3, PDU = 4;
+  static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
+  __shared__ float uvl[2 * 2 * 64];              // rows wave -> data wave: du, dv of a pixel row     [row & 1][field][lane]
+  __shared__ float dtl[2 * 5 * 64];              // data wave -> rows wave: a11, a12, a22, b1, b2     [row & 1][field][lane]
+  __shared__ float sring[2 * SLOT_FLOATS * 64];  // rows wave -> solve wave: the finished FSlot       [row & 1][field][lane]
+  __shared__ float wring[16 * 2 * 64];           // rows wave -> solve wave (last iteration): wx, wy of a pixel row [row & 15][field][lane]
+  __shared__ float xring[XC_RING * 2 * 64];      // fetch wave -> rows wave: du, dv of the previous iteration [row & 7][field][lane]
+  const int w = a.t.w, h = a.t.h;
+  const int rw = w;  // S == 1: a strip is a frame
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int it = (int)blockIdx.x / G8, wid = (int)blockIdx.x - it * G8;
+  const int n_iters = a.n_inner;
+  const int G = 64 / R;
+  const int nstrips = a.t.nframes;
+  const int s0 = wid * G;
+  if (s0 >= nstrips) return;  // whole workgroup idle
+  int fl = lane / R;
+  const int jr = lane % R;
+  const bool row_ok = (s0 + fl < nstrips) && (jr < h);
+  if (s0 + fl >= nstrips) fl = nstrips - 1 - s0;
+  const int j = jr < h ? jr : h - 1;
+  const bool has_top = j > 0, has_bot = j < h - 1;
+  const float omega = a.omega, qa = a.quarter_alpha, hd3 = a.half_delta_over3, hg3 = a.half_gamma_over3;
+  auto from_prev = [&](float x) { return wave_from_prev(x); };
+  auto from_next = [&](float x) { return wave_from_next(x); };
+  const int nst = min(G, nstrips - s0);
+  const size_t strip_recs = (size_t)rw * h;
+  auto rsrc = [&](const float* base, int rec_floats) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)s0 * strip_recs * rec_floats), 0,
+                                             (int)(nst * strip_recs * rec_floats * 4), 0x00020000);
+  };
+  const int vrec = fl * (int)strip_recs + j;
+  const int vo8 = vrec * 32, vo2 = vrec * 8, vo4 = vrec * 16;
+  auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
+  auto wrap_row = [&](int r) { r %= rw; return r < 0 ? r + rw : r; };
+  auto wrap_col = [&](int c) { c %= w; return c < 0 ? c + w : c; };
+  auto next_row = [&](int r) { return (r + 1 == rw) ? 0 : r + 1; };
+  const int tend = (rw - 1) + (h - 1) + 2 * (NS - 1) + 1;  // (the solve wave runs one step behind)
+  const size_t it_floats = (size_t)a.t.nframes * strip_recs * 4;  // granules of one iteration boundary
+  int taut = -3;  // unwrapped step number
+  const bool wants_w = it == n_iters - 1 && a.flow_out;  // last iteration: the solve wave writes wx + du, wy + dv itself
+
+  if (role == 0) {
+    // ------------------------------------------------------------------------------------------------ rows wave
+    const __amdgpu_buffer_rsrc_t rsW = rsrc(a.wrec, 2);
+    // du, dv of the previous iteration for the row with unwrapped number tau: from the LDS ring the fetch wave fills; zero
+    // in the first iteration (image_erase, refine_variational.cpp:186-187)
+    auto ring_uv = [&](FRow& r, int tau) {
+      if (it == 0) {
+        r.du = 0.0f; r.dv = 0.0f;
+      } else {
+        const float* q = xring + ((tau & (XC_RING - 1)) * 2) * 64 + lane;
+        r.du = q[0 * 64]; r.dv = q[1 * 64];
+      }
+    };
+    auto load_w = [&](FRow& r, int drow) {
+      const auto t = __builtin_amdgcn_raw_buffer_load_b64(rsW, vo2, drow * h * 8, 0);
+      const unsigned t0 = t[0], t1 = t[1];
+      r.wx = asf(t0); r.wy = asf(t1);
+    };
+    FRow W[6];
+    float uu[3], vv[3], sm[3];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) W[r] = FRow{0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { uu[r] = vv[r] = 0.0f; sm[r] = 1.0f; }
+    float ldx = 0.0f, ldy = 0.0f;
+    float shp = 1.0f, svp = 1.0f;  // sh, sv of pixel row t (fill phase: unit weights, see "Border handling")
+    // the part of row t's system this wave produced one step ago
+    float p_sh = 1.0f, p_sv = 1.0f, p_hl = 0.0f, p_vt = 0.0f, p_dur = 0.0f, p_dvr = 0.0f;
+    float q1x = 0.0f, q1y = 0.0f, q2x = 0.0f, q2y = 0.0f, q3x = 0.0f, q3y = 0.0f, q4x = 0.0f, q4y = 0.0f;
+    // prologue: W rows -1, 0, 1 (indices 2, 3, 4); du/dv of row 0 (row -1 has no pixel)
+    load_w(W[2], wrap_row(-1));
+    load_w(W[3], wrap_row(0));
+    load_w(W[4], wrap_row(1));
+    uvl[(0 * 2 + 0) * 64 + lane] = 0.0f;  // du, dv of row -2 for the data wave's first step
+    uvl[(0 * 2 + 1) * 64 + lane] = 0.0f;
+    __syncthreads();  // (the fetch wave has put rows 0 and 1 into the ring)
+    ring_uv(W[3], 0);
+    int rowW = wrap_row(PDW - 3);
+    int x2 = wrap_col(-1 - j);
+    bool x1_last = (wrap_col(-2 - j) == w - 1);
+    for (int k0 = 0; k0 <= tend + 3; k0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // ---- (0) finish the system of pixel row t: data term of the data wave (written one step ago) + the Laplacian
+        //      products kept from the previous step, then the block inverse (solver.c:100-110)
+        if (taut > -3) {
+          const float* dr = dtl + ((taut & 1) * 5) * 64 + lane;
+          const float a11 = dr[0 * 64], a12 = dr[1 * 64], a22 = dr[2 * 64];
+          float b1 = dr[3 * 64], b2 = dr[4 * 64];
+          b1 -= q1x; b2 -= q1y;
+          b1 += q2x; b2 += q2y;
+          b1 -= q3x; b2 -= q3y;
+          b1 += q4x; b2 += q4y;
+          const float d = p_hl + p_sh + p_vt + p_sv;
+          const float A11 = a22 + d, A22 = a11 + d;
+          const float det = A11 * A22 - a12 * a12;
+          const FDen dd = fden(det);
+          float* sr = sring + ((taut & 1) * SLOT_FLOATS) * 64 + lane;
+          sr[0 * 64] = fdiv_by(A11, dd); sr[1 * 64] = -fdiv_by(a12, dd); sr[2 * 64] = fdiv_by(A22, dd);
+          sr[3 * 64] = b1; sr[4 * 64] = b2; sr[5 * 64] = p_sh; sr[6 * 64] = p_sv; sr[7 * 64] = p_dur; sr[8 * 64] = p_dvr;
+          sr[9 * 64] = p_hl; sr[10 * 64] = p_vt;
+        }
+        // ---- (1) W row t+5; du/dv of row t+4 from the ring
+        load_w(W[(u + PDW) % 6], rowW);
+        rowW = next_row(rowW);
+        ring_uv(W[(u + PDU) % 6], taut + PDU);
+        // ---- (2) uu, vv of row t+3
+        {
+          const FRow& r = W[(u + 3) % 6];
+          uu[u % 3] = r.wx + r.du;
+          vv[u % 3] = r.wy + r.dv;
+          if (wants_w) {  // the solve wave adds the final du, dv to these eight steps from now
+            float* q = wring + (((taut + 3) & 15) * 2) * 64 + lane;
+            q[0 * 64] = r.wx; q[1 * 64] = r.wy;
+          }
+        }
+        // ---- (3) smoothness of row t+2 (opticalflow_aux.c:128-140; see the throughput kernel for the scaling argument)
+        const bool x2_last = (x2 == w - 1);
+        {
+          const float uc = uu[(u + 2) % 3], vc = vv[(u + 2) % 3];
+          float ul = uu[(u + 1) % 3], vl = vv[(u + 1) % 3];
+          float ur = uu[u % 3], vr = vv[u % 3];
+          float ut = from_prev(uu[(u + 1) % 3]), vt = from_prev(vv[(u + 1) % 3]);
+          float ub = from_next(uu[u % 3]), vb = from_next(vv[u % 3]);
+          if (x2 == 0) { ul = uc; vl = vc; }
+          if (x2_last) { ur = uc; vr = vc; }
+          if (!has_top) { ut = uc; vt = vc; }
+          if (!has_bot) { ub = uc; vb = vc; }
+          const float ex = ur - ul, fx = vr - vl, ey = ub - ut, fy = vb - vt;
+          sm[(u + 2) % 3] = fdiv_by_sqrt(qa, 0.25f * (ex * ex + ey * ey + fx * fx + fy * fy) + EPS_SMOOTH);
+        }
+        // ---- (4) this wave's part of the system of pixel row t+1 (opticalflow_aux.c:150-163, 172-199)
+        {
+          const float sc = sm[(u + 1) % 3];
+          const float s_r = sm[(u + 2) % 3];
+          const float s_d = from_next(sm[(u + 2) % 3]);
+          const float sh_c = x1_last ? 0.0f : sc + s_r;
+          const float sv_c = has_bot ? sc + s_d : 0.0f;
+          const FRow& rc = W[(u + 1) % 6];
+          const FRow& rm = W[u % 6];
+          const FRow& rp = W[(u + 2) % 6];
+          const float wx_u = from_prev(rm.wx), wy_u = from_prev(rm.wy);
+          const float wx_d = from_next(rp.wx), wy_d = from_next(rp.wy);
+          const float sh_l = shp;
+          const float sv_t = from_prev(svp);
+          const float rdx = rp.wx - rc.wx, rdy = rp.wy - rc.wy;
+          q1x = sh_l * ldx; q1y = sh_l * ldy;
+          q2x = sh_c * rdx; q2y = sh_c * rdy;
+          ldx = rdx; ldy = rdy;
+          q3x = sv_t * (rc.wx - wx_u); q3y = sv_t * (rc.wy - wy_u);
+          q4x = sv_c * (wx_d - rc.wx); q4y = sv_c * (wy_d - rc.wy);
+          p_sh = sh_c; p_sv = sv_c; p_hl = sh_l; p_vt = sv_t; p_dur = rp.du; p_dvr = rp.dv;
+          shp = sh_c; svp = sv_c;
+          // du, dv of row t+2 for the data wave's next step
+          float* uw = uvl + ((taut & 1) * 2) * 64 + lane;  // (t + 2) & 1 == t & 1
+          uw[0 * 64] = rp.du; uw[1 * 64] = rp.dv;
+        }
+        x1_last = x2_last;
+        x2 = x2_last ? 0 : x2 + 1;
+        ++taut;
+        mw_step_barrier();
+      }
+    }
+  } else if (role == 1) {
+    // ------------------------------------------------------------------------------------------------ data wave
+    const __amdgpu_buffer_rsrc_t rsD = rsrc(a.d8, 8);
+    auto load_d = [&](FDer& r, int drow) {
+      const int o = drow * h * 32;
+      const auto lo = __builtin_amdgcn_raw_buffer_load_b128(rsD, vo8, o, 0);
+      const auto hi = __builtin_amdgcn_raw_buffer_load_b128(rsD, vo8 + 16, o, 0);
+      const unsigned l0 = lo[0], l1 = lo[1], l2 = lo[2], l3 = lo[3], h0 = hi[0], h1 = hi[1], h2 = hi[2], h3 = hi[3];
+      r.ix = asf(l0); r.iz = asf(l1); r.ixx = asf(l2); r.ixz = asf(l3);
+      r.iy = asf(h0); r.ixy = asf(h1); r.iyz = asf(h2); r.iyy = asf(h3);
+    };
+    FDer D[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) D[r] = FDer{0, 0, 0, 0, 0, 0, 0, 0};
+    int rowD = wrap_row(PDD - 3);
+    __syncthreads();
+    for (int k0 = 0; k0 <= tend + 3; k0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        load_d(D[(u + PDD) % 3], rowD);  // row t+3
+        rowD = next_row(rowD);
+        const float* ur = uvl + (((taut + 1) & 1) * 2) * 64 + lane;  // du, dv of row t+1
+        const float du = ur[0 * 64], dv = ur[1 * 64];
+        float a11, a12, a22, b1, b2;
+        data_term_gray<BRIGHT>(D[(u + 1) % 3], du, dv, hd3, hg3, a11, a12, a22, b1, b2);
+        float* dw = dtl + (((taut + 1) & 1) * 5) * 64 + lane;
+        dw[0 * 64] = a11; dw[1 * 64] = a12; dw[2 * 64] = a22; dw[3 * 64] = b1; dw[4 * 64] = b2;
+        ++taut;
+        mw_step_barrier();
+      }
+    }
+  } else if (role == 3) {
+    // ------------------------------------------------------------------------------------------------ fetch wave
+    // Brings the previous iteration's du/dv rows from global memory into the LDS ring, XC_B rows every XC_B steps: at a
+    // batch step t it takes the rows t+5 .. t+4+XC_B it requested XC_B steps ago (the rows wave reads them in the next XC_B
+    // steps), checks the tag of every existing pixel -- re-reading (bounded) until the predecessor has written them, after
+    // letting it gain XC_LEAD rows -- and requests the next XC_B rows.  All its memory waits are whole-queue waits on
+    // requests that are XC_B steps old, so the other wavefronts never see the hand-off latency.
+    if (it > 0) {
+      const __amdgpu_buffer_rsrc_t rsX = rsrc(xbuf + (size_t)(it - 1) * it_floats, 4);
+      bool dead = false;  // a row never arrived: stop waiting (the results are wrong, the err word says so)
+      auto request = [&](int drow) { return __builtin_amdgcn_raw_buffer_load_b128(rsX, vo4, drow * h * 16, 16 /* sc1 */); };
+      auto inrange = [&](int tau) { const int x = tau - j; return (x >= 0) & (x < rw); };  // this lane's pixel of row tau exists
+      auto ready = [&](const u32x4& q, bool inr) { return !inr | ((q[1] == XC_TAG) & (q[3] == XC_TAG)); };
+      // re-reads row tau until every existing pixel's granules carry their tag (bounded)
+      auto wait_row = [&](int tau) {
+        const int drow = wrap_row(tau);
+        const bool inr = inrange(tau);
+        u32x4 g = request(drow);
+        unsigned spins = 0;
+        while (!dead && __builtin_amdgcn_ballot_w64(!ready(g, inr)) != 0) {
+          if (++spins >= XC_SPIN_LIMIT) {
+            dead = true;
+            if (err && lane == 0) atomicExch(err, 1);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+          asm volatile("" ::: "memory");
+          g = request(drow);
+        }
+        return g;
+      };
+      const int last_tau = rw + h - 2;  // the last row with a pixel
+      auto deliver = [&](const u32x4& g, int tau) {  // (lanes outside their columns: zero -- finite, never read as a pixel)
+        const bool inr = inrange(tau);
+        const unsigned g0 = g[0], g2 = g[2];
+        float* q = xring + ((tau & (XC_RING - 1)) * 2) * 64 + lane;
+        q[0 * 64] = inr ? asf(g0) : 0.0f;
+        q[1 * 64] = inr ? asf(g2) : 0.0f;
+      };
+      // prologue: wait until the predecessor has passed the rows of the first batch by XC_LEAD, then take rows 0 .. 1 + XC_B
+      // in ONE round trip: rows 0 and 1 are delivered now, the others are the first batch
+      (void)wait_row(min(1 + XC_B + XC_LEAD, last_tau));
+      u32x4 XG[XC_B];
+      {
+        u32x4 g0 = request(wrap_row(0)), g1 = request(wrap_row(1));
+#pragma unroll
+        for (int r = 0; r < XC_B; ++r) XG[r] = request(wrap_row(2 + r));
+        if (!dead && (__builtin_amdgcn_ballot_w64(!ready(g0, inrange(0))) | __builtin_amdgcn_ballot_w64(!ready(g1, inrange(1)))) != 0) {
+          g0 = wait_row(0);
+          g1 = wait_row(1);
+        }
+        deliver(g0, 0);
+        deliver(g1, 1);
+      }
+      __syncthreads();
+      for (int k0 = 0; k0 <= tend + 3; k0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (u % XC_B == 0) {  // batch step: rows taut + 5 .. taut + 4 + XC_B
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < XC_B; ++r) ok &= __builtin_amdgcn_ballot_w64(!ready(XG[r], inrange(taut + 5 + r))) == 0;
+            if (!ok && !dead) {  // requested too early: fall back behind the predecessor, then take the rows one by one
+              (void)wait_row(min(taut + 4 + XC_B + XC_LEAD, last_tau));
+#pragma unroll
+              for (int r = 0; r < XC_B; ++r) XG[r] = wait_row(taut + 5 + r);
+            }
+#pragma unroll
+            for (int r = 0; r < XC_B; ++r) deliver(XG[r], taut + 5 + r);
+            int rr = wrap_row(taut + 5 + XC_B);
+#pragma unroll
+            for (int r = 0; r < XC_B; ++r) {
+              XG[r] = request(rr);
+              rr = next_row(rr);
+            }
+          }
+          ++taut;
+          mw_step_barrier();
+        }
+      }
+    } else {
+      __syncthreads();
+      for (int k0 = 0; k0 <= tend + 3; k0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) mw_step_barrier();
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------ solve wave
+    const __amdgpu_buffer_rsrc_t rsX = rsrc(xbuf + (size_t)(it < n_iters - 1 ? it : 0) * it_floats, 4);
+    const __amdgpu_buffer_rsrc_t rsU = rsrc(a.uv, 2);
+    const int npx = w * h;
+    float2* const flow_row = reinterpret_cast<float2*>(a.flow_out) + ((size_t)(s0 + fl) * npx + (size_t)j * w);
+    FSlot slot[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) slot[r] = FSlot{1, 0, 1, 0, 0, 1, 1, 0, 0, 0, 0};  // (block inverse included: any finite value)
+    float ru[NS], rv[NS], ru2[NS], rv2[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { ru[s] = rv[s] = ru2[s] = rv2[s] = 0.0f; }
+    int srow = wrap_row(-3 - 2 * (NS - 1));  // row finished by the last sweep at this wave's first step
+    int ig = -3 - j - 2 * (NS - 1);          // ... and its column in this lane
+    __syncthreads();
+    for (int k0 = 0; k0 <= tend + 3; k0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (taut > -3) {  // this wave's step number is taut - 1; its current pixel row sits at ring index us
+          const int us = (u + 5) % 6;
+          if (taut > -2) {  // the slot of row taut - 1, finished by the rows wave one step ago (the first one is row -2)
+            const float* sr = sring + (((taut - 1) & 1) * SLOT_FLOATS) * 64 + lane;
+            FSlot& c = slot[us];
+            c.a11 = sr[0 * 64]; c.a12 = sr[1 * 64]; c.a22 = sr[2 * 64]; c.b1 = sr[3 * 64]; c.b2 = sr[4 * 64]; c.sh = sr[5 * 64];
+            c.sv = sr[6 * 64]; c.dur = sr[7 * 64]; c.dvr = sr[8 * 64]; c.hl = sr[9 * 64]; c.vt = sr[10 * 64];
+          }
+          float nu[NS], nv[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            const FSlot& c = slot[(us - 2 * s + 12) % 6];
+            float ou, ov, rgu, rgv, bu, bv;
+            if (s == 0) {
+              const FSlot& p = slot[(us + 5) % 6];
+              ou = p.dur; ov = p.dvr;
+              rgu = c.dur; rgv = c.dvr;
+              bu = from_next(c.dur);
+              bv = from_next(c.dvr);
+            } else {
+              ou = ru2[s - 1]; ov = rv2[s - 1];
+              rgu = ru[s - 1]; rgv = rv[s - 1];
+              bu = from_next(ru[s - 1]);
+              bv = from_next(rv[s - 1]);
+            }
+            const float tu = from_prev(ru[s]), tv = from_prev(rv[s]);
+            const float lu = ru[s], lv = rv[s];
+            const float s1 = c.sh * rgu + c.vt * tu + c.sv * bu + c.b1;
+            const float s2 = c.sh * rgv + c.vt * tv + c.sv * bv + c.b2;
+            const float B1 = c.hl * lu + s1, B2 = c.hl * lv + s2;
+            nu[s] = ou + omega * (c.a11 * B1 + c.a12 * B2 - ou);
+            nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
+          }
+          const bool on = row_ok & (ig >= 0) & (ig < rw);
+          if (it < n_iters - 1) {  // hand the finished row to the next iteration's workgroup: one write-through granule pair
+            const u32x4 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), XC_TAG, __builtin_bit_cast(unsigned, nv[NS - 1]), XC_TAG};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsX, on ? vo4 : 0x7ffffff0, srow * h * 16, 16 /* sc1 */);
+          } else if (a.flow_out) {  // last iteration: the refined flow itself, AoS (refine_variational.cpp:209-221, 92-99)
+            const float* q = wring + (((taut - 1 - 2 * (NS - 1)) & 15) * 2) * 64 + lane;  // the row the last sweep finishes now
+            if (on) flow_row[ig] = make_float2(q[0 * 64] + nu[NS - 1], q[1 * 64] + nv[NS - 1]);
+          } else {  // ... or du, dv for tv_finish_records
+            const u32x2 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), __builtin_bit_cast(unsigned, nv[NS - 1])};
+            __builtin_amdgcn_raw_buffer_store_b64(v, rsU, on ? vo2 : 0x7ffffff0, srow * h * 8, 0);
+          }
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            ru2[s] = ru[s]; rv2[s] = rv[s];
+            ru[s] = nu[s]; rv[s] = nv[s];
+          }
+          srow = next_row(srow);
+          ++ig;
+        }
+        ++taut;
+        mw_step_barrier();
+      }
+    }
+  }
+}
+
+
+hipError_t launch_tv_fused_xcu(const FusedArgs& a, const FusedXcu& x, int waves, int R, hipStream_t s) {
+  const int G8 = (waves + 7) & ~7;  // workgroups per fixed-point iteration
+  // granule tags: 0 = not yet written (re-initialised before EVERY launch, also under graph replay)
+  const hipError_t e = hipMemsetAsync(x.xbuf, 0, (size_t)(a.n_inner - 1) * a.t.nframes * a.t.w * a.t.h * 16, s);
+  if (e != hipSuccess) return e;
+  const bool bright = a.half_delta_over3 != 0.0f;
+#define OFDIS_XCU_LAUNCH(NS)                                                                                           \
+  if (bright)                                                                                                          \
+    hipLaunchKernelGGL((tv_fused_xcu_kernel<NS, true>), dim3(a.n_inner * G8), dim3(256), 0, s, a, R, G8, x.xbuf, x.err); \
+  else                                                                                                                 \
+    hipLaunchKernelGGL((tv_fused_xcu_kernel<NS, false>), dim3(a.n_inner * G8), dim3(256), 0, s, a, R, G8, x.xbuf, x.err)
+  switch (a.iterations) {
+    case 1: OFDIS_XCU_LAUNCH(1); break;
+    case 2: OFDIS_XCU_LAUNCH(2); break;
+    default: OFDIS_XCU_LAUNCH(3); break;
+  }
+#undef OFDIS_XCU_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace ofdis

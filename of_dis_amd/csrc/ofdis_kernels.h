@@ -134,12 +134,20 @@ struct FusedArgs {
   int mw_max_groups;  // frame groups (workgroups) up to which the multi-wave variants are launched (0 = never)
   int split;          // 0 = never the split (producer / solver wavefronts) variant of the multi-wave kernel
 };
+// cross-CU variant (one workgroup per fixed-point iteration of a frame group), kept out of FusedArgs so that the other
+// variants' kernel arguments -- and register allocation -- stay what they were
+struct FusedXcu {
+  float* xbuf = nullptr;   // [n_inner - 1][nframes][w*h] granules of 4 floats {du, tag, dv, tag}; null: never
+  int max_groups = 0;      // frame groups up to which the variant is launched (0 = never)
+  int* err = nullptr;      // optional device-visible word, set to 1 when a hand-over row never arrived (results invalid)
+};
 bool tv_fused_supported(const TvGeom& t, int iterations);
 // the fused kernel's trimmed divisions (ofdis_dev.h) need the three weights to be 0 or of ordinary magnitude
 bool tv_fused_params_ok(float quarter_alpha, float half_delta_over3, float half_gamma_over3);
-// 0 = one wavefront per strip group (throughput), 1 = a wavefront per fixed-point iteration, 2 = producer + solver each
-int tv_fused_mode(const FusedArgs& a);
-hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow = nullptr);
+// 0 = one wavefront per strip group (throughput), 1 = a wavefront per fixed-point iteration, 2 = producer + solver each,
+// 3 = one workgroup (three wavefronts) per fixed-point iteration, the iterations of a frame group on different CUs
+int tv_fused_mode(const FusedArgs& a, const FusedXcu* x = nullptr);
+hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow = nullptr, const FusedXcu* x = nullptr);
 
 // uu = wx + du, vv = wy + dv (refine_variational.cpp:209-221, 92-99) in place: flow (AoS, row-major) holds wx, wy on entry
 // and the refined flow on return; uv = the fused kernel's du, dv records

@@ -529,7 +529,7 @@ def test_fused_tv_strips(gpu, orc, nfr, strip, size):
     cases = [synth_case(w, h, 2300 + k, 1, 2, 1) for k in range(3)]
     p = cases[0][0]
     refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
-    old = gpu.set_tuning(fused_mw_max=0, fused_strip=strip)
+    old = gpu.set_tuning(fused_mw_max=0, fused_xcu_max=0, fused_strip=strip)
     try:
         b = gpu.Batch(p, nfr)
         for l in range(p.sc_l, p.sc_f + 1):               # slot s holds frame (s * s + s // 3) % 3: neighbours vary
@@ -620,7 +620,9 @@ def test_fused_tv_strips_odd_geometries(gpu, orc, size, level, nfr, strip):
         ia, ib, _ = gen_synth.make_pair(w, h, 2500 + k)
         cases.append((O.build_pyramid(p, ia), O.build_pyramid(p, ib)))
     refs = [orc.flow(p, pa[0], pa[1], pa[2], pb[0]) for pa, pb in cases]
-    for variant in ({"fused_mw_max": 0, "fused_strip": strip}, {"fused_mw_max": 1 << 30, "fused_strip": 0}):
+    for variant in ({"fused_mw_max": 0, "fused_xcu_max": 0, "fused_strip": strip},
+                    {"fused_mw_max": 1 << 30, "fused_xcu_max": 0, "fused_strip": 0},
+                    {"fused_xcu_max": 1 << 30, "fused_strip": 0}):
         old = gpu.set_tuning(**variant)
         try:
             b = gpu.Batch(p, nfr)

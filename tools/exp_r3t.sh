@@ -1,0 +1,13 @@
+#!/bin/bash
+# cross-CU fused TV variant with pacing: parity, then request distance / lead A/B at small batches
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; OUT=$R/gpurun_out/r3t; mkdir -p $OUT
+timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_flow.py -x -q -k "varref or batch_matches or fallback or odd_geometries or dropin or strips" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest.log
+X=OFDIS_FUSED_XCU_MAX=1073741824
+( for b in 1 64 256; do
+  KB="--steps 50 --warmup 5 --no-extras --pipeline 1 --batch $b"
+  echo -n "b$b split: "; timeout 300 python tools/kbench.py OFDIS_FUSED_XCU_MAX=0 -- $KB
+  echo -n "b$b xcu pf3 lead5: "; timeout 300 python tools/kbench.py $X -- $KB
+  for v in pf6 pf2 pf3l8 pf3l3 pf6l6; do
+    echo -n "b$b xcu $v: "; timeout 300 python tools/kbench.py OFDIS_LIB=$R/of_dis_amd/lib/ab_$v/libofdis_hip.so $X -- $KB
+  done
+done ) 2>&1 | sed "s#$R/##g;s#OFDIS_LIB=[^ ]* ##;s#OFDIS_FUSED_XCU_MAX=[0-9]* ##" | tee $OUT/variants.txt
