@@ -582,6 +582,10 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
   }
   if (!rc) rc = dcommit(b);
   if (!rc) b->in_base = (char*)b->in[0][0];
+  if (!rc && b->xbuf) {  // granule tags: 0 = not yet written (the kernel restores the zeros itself)
+    hipError_t e = hipMemset(b->xbuf, 0, b->xbuf_per_frame * nframes * sizeof(float));
+    if (e != hipSuccess) rc = hipfail(e, "hipMemset");
+  }
   if (rc) {
     ofdis_batch_destroy(b);
     return rc == OFDIS_ERR_DEVICE ? OFDIS_ERR_NOMEM : rc;
@@ -1375,6 +1379,10 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   }
   if (!rc && p->selectmode == 2) rc = dalloc(&b, &b.uu, npx);
   if (!rc) rc = dcommit(&b);
+  if (!rc && b.xbuf) {
+    hipError_t e = hipMemsetAsync(b.xbuf, 0, b.xbuf_per_frame * nframes * sizeof(float), s);
+    if (e != hipSuccess) rc = hipfail(e, "hipMemsetAsync");
+  }
   if (!rc && p->selectmode == 2) {  // one channel: wx = flow, wy = 0
     b.nop = 1;
     hipError_t e = hipMemcpyAsync(b.wx, flow, npx * sizeof(float), hipMemcpyDeviceToDevice, s);

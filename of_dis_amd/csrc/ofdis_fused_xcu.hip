@@ -27,7 +27,8 @@ namespace ofdis {
 // tag of every existing pixel -- when one is missing it lets the predecessor gain XC_LEAD rows and re-reads (bounded) --
 // writes them to the ring and requests the next batch.  An iteration so trails its predecessor by ~13 steps + the latency
 // (6.8 us per iteration boundary) and never waits in steady state.
-// The launcher zeroes the granule array before every launch (tag 0 = not yet written).  Block index = iteration * G8 +
+// Tag 0 = not yet written: the array is zeroed when it is allocated, and the fetch wave puts every granule it has taken
+// back to zero, so a launch leaves the array as it found it (no memset per launch).  Block index = iteration * G8 +
 // group with G8 a multiple of 8: an iteration only waits for a LOWER block index, and the iterations of a group share an
 // XCD under the observed round-robin placement (speed only).  A wait that exceeds XC_SPIN_LIMIT re-reads (seconds) sets
 // the caller's error word and the wavefront carries on without waiting: the call fails, nothing hangs.
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
   __shared__ float dtl[2 * 5 * 64];              // data wave -> rows wave: a11, a12, a22, b1, b2     [row & 1][field][lane]
   __shared__ float sring[2 * SLOT_FLOATS * 64];  // rows wave -> solve wave: the finished FSlot       [row & 1][field][lane]
   __shared__ float wring[16 * 2 * 64];           // rows wave -> solve wave (last iteration): wx, wy of a pixel row [row & 15][field][lane]
+  __shared__ float2 oring[16 * 64];              // solve wave -> fetch wave (last iteration): wx + du, wy + dv of a finished row [row & 15][lane]
   __shared__ float xring[XC_RING * 2 * 64];      // fetch wave -> rows wave: du, dv of the previous iteration [row & 7][field][lane]
   const int w = a.t.w, h = a.t.h;
   const int rw = w;  // S == 1: a strip is a frame
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
   const int tend = (rw - 1) + (h - 1) + 2 * (NS - 1) + 1;  // (the solve wave runs one step behind)
   const size_t it_floats = (size_t)a.t.nframes * strip_recs * 4;  // granules of one iteration boundary
   int taut = -3;  // unwrapped step number
-  const bool wants_w = it == n_iters - 1 && a.flow_out;  // last iteration: the solve wave writes wx + du, wy + dv itself
+  const bool wants_w = it == n_iters - 1 && a.flow_out;  // last iteration: the workgroup writes wx + du, wy + dv itself
 
   if (role == 0) {
     // ------------------------------------------------------------------------------------------------ rows wave
@@ -271,12 +273,16 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
         return g;
       };
       const int last_tau = rw + h - 2;  // the last row with a pixel
-      auto deliver = [&](const u32x4& g, int tau) {  // (lanes outside their columns: zero -- finite, never read as a pixel)
+      // into the ring (lanes outside their columns: zero -- finite, never read as a pixel); the granules go back to "not
+      // written" for the next launch: every granule a launch writes is taken exactly once, so the array is all zero
+      // again when the launch ends and needs no memset between launches
+      auto deliver = [&](const u32x4& g, int tau, int drow) {
         const bool inr = inrange(tau);
         const unsigned g0 = g[0], g2 = g[2];
         float* q = xring + ((tau & (XC_RING - 1)) * 2) * 64 + lane;
         q[0 * 64] = inr ? asf(g0) : 0.0f;
         q[1 * 64] = inr ? asf(g2) : 0.0f;
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0, 0, 0, 0}, rsX, (inr & row_ok) ? vo4 : 0x7ffffff0, drow * h * 16, 16 /* sc1 */);
       };
       // prologue: wait until the predecessor has passed the rows of the first batch by XC_LEAD, then take rows 0 .. 1 + XC_B
       // in ONE round trip: rows 0 and 1 are delivered now, the others are the first batch
@@ -290,9 +296,32 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
           g0 = wait_row(0);
           g1 = wait_row(1);
         }
-        deliver(g0, 0);
-        deliver(g1, 1);
+        deliver(g0, 0, wrap_row(0));
+        deliver(g1, 1, wrap_row(1));
       }
+      int rowd = wrap_row(2);          // next row to deliver
+      int rowq = wrap_row(2 + XC_B);   // next row to request
+      // Last iteration: the refined flow itself, AoS (refine_variational.cpp:209-221, 92-99).  The solve wave leaves
+      // every finished row in an LDS ring; every six steps this wavefront writes the six rows finished since: in a lane's
+      // image row they are six consecutive pixels, 48 contiguous bytes instead of six scattered 8-byte stores.
+      float2* const flow_row = reinterpret_cast<float2*>(a.flow_out) + ((size_t)(s0 + fl) * (w * h) + (size_t)j * w);
+      auto flush = [&](int r0) {  // diag rows r0 .. r0 + 5 (unwrapped): pixels x0 .. x0 + 5 of this lane's image row
+        const int x0 = r0 - j;
+        float2 v[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) v[e] = oring[((r0 + e) & 15) * 64 + lane];
+        if (row_ok & (x0 >= 0) & (x0 + 5 < rw)) {
+          typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+          f4a8* d = reinterpret_cast<f4a8*>(flow_row + x0);
+          d[0] = f4a8{v[0].x, v[0].y, v[1].x, v[1].y};
+          d[1] = f4a8{v[2].x, v[2].y, v[3].x, v[3].y};
+          d[2] = f4a8{v[4].x, v[4].y, v[5].x, v[5].y};
+        } else if (row_ok) {
+#pragma unroll
+          for (int e = 0; e < 6; ++e)
+            if ((x0 + e >= 0) & (x0 + e < rw)) flow_row[x0 + e] = v[e];
+        }
+      };
       __syncthreads();
       for (int k0 = 0; k0 <= tend + 3; k0 += U) {
 #pragma unroll
@@ -307,18 +336,22 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
               for (int r = 0; r < XC_B; ++r) XG[r] = wait_row(taut + 5 + r);
             }
 #pragma unroll
-            for (int r = 0; r < XC_B; ++r) deliver(XG[r], taut + 5 + r);
-            int rr = wrap_row(taut + 5 + XC_B);
+            for (int r = 0; r < XC_B; ++r) {
+              deliver(XG[r], taut + 5 + r, rowd);
+              rowd = next_row(rowd);
+            }
 #pragma unroll
             for (int r = 0; r < XC_B; ++r) {
-              XG[r] = request(rr);
-              rr = next_row(rr);
+              XG[r] = request(rowq);
+              rowq = next_row(rowq);
             }
           }
+          if (u == U - 1 && wants_w) flush(taut - 6 - 1 - 2 * (NS - 1));  // the rows finished in steps taut-6 .. taut-1
           ++taut;
           mw_step_barrier();
         }
       }
+      if (wants_w) flush(taut - 6 - 1 - 2 * (NS - 1));  // (overlaps the last flush: same values)
     } else {
       __syncthreads();
       for (int k0 = 0; k0 <= tend + 3; k0 += U) {
@@ -330,8 +363,6 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
     // ------------------------------------------------------------------------------------------------ solve wave
     const __amdgpu_buffer_rsrc_t rsX = rsrc(xbuf + (size_t)(it < n_iters - 1 ? it : 0) * it_floats, 4);
     const __amdgpu_buffer_rsrc_t rsU = rsrc(a.uv, 2);
-    const int npx = w * h;
-    float2* const flow_row = reinterpret_cast<float2*>(a.flow_out) + ((size_t)(s0 + fl) * npx + (size_t)j * w);
     FSlot slot[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) slot[r] = FSlot{1, 0, 1, 0, 0, 1, 1, 0, 0, 0, 0};  // (block inverse included: any finite value)
@@ -382,8 +413,9 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
             const u32x4 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), XC_TAG, __builtin_bit_cast(unsigned, nv[NS - 1]), XC_TAG};
             __builtin_amdgcn_raw_buffer_store_b128(v, rsX, on ? vo4 : 0x7ffffff0, srow * h * 16, 16 /* sc1 */);
           } else if (a.flow_out) {  // last iteration: the refined flow itself, AoS (refine_variational.cpp:209-221, 92-99)
-            const float* q = wring + (((taut - 1 - 2 * (NS - 1)) & 15) * 2) * 64 + lane;  // the row the last sweep finishes now
-            if (on) flow_row[ig] = make_float2(q[0 * 64] + nu[NS - 1], q[1 * 64] + nv[NS - 1]);
+            const int frow = taut - 1 - 2 * (NS - 1);  // the row the last sweep finishes now
+            const float* q = wring + ((frow & 15) * 2) * 64 + lane;
+            oring[(frow & 15) * 64 + lane] = make_float2(q[0 * 64] + nu[NS - 1], q[1 * 64] + nv[NS - 1]);
           } else {  // ... or du, dv for tv_finish_records
             const u32x2 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), __builtin_bit_cast(unsigned, nv[NS - 1])};
             __builtin_amdgcn_raw_buffer_store_b64(v, rsU, on ? vo2 : 0x7ffffff0, srow * h * 8, 0);
@@ -406,9 +438,6 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
 
 hipError_t launch_tv_fused_xcu(const FusedArgs& a, const FusedXcu& x, int waves, int R, hipStream_t s) {
   const int G8 = (waves + 7) & ~7;  // workgroups per fixed-point iteration
-  // granule tags: 0 = not yet written (re-initialised before EVERY launch, also under graph replay)
-  const hipError_t e = hipMemsetAsync(x.xbuf, 0, (size_t)(a.n_inner - 1) * a.t.nframes * a.t.w * a.t.h * 16, s);
-  if (e != hipSuccess) return e;
   const bool bright = a.half_delta_over3 != 0.0f;
 #define OFDIS_XCU_LAUNCH(NS)                                                                                           \
   if (bright)                                                                                                          \
