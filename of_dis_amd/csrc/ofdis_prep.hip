@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
   int frame = fg * fpw + fl;
   const bool fok = frame < a.t.nframes;
   if (!fok) frame = a.t.nframes - 1;  // idle lane group: shadows the last frame, never flushed
-  const int yb0 = band * a.band_rows, yb1 = min(h, yb0 + a.band_rows);  // band_rows is a multiple of KW (launcher)
+  const int yb0 = band * a.band_rows, yb1 = min(h, yb0 + a.band_rows);  // (band_rows: even; a multiple of KW from 8 rows on)
   if (yb0 >= h) return;
   const int r_begin = max(yb0 - 4, 0), r_s0end = min(yb1 + 4, h);  // rows of stage 0
   const int y1lo = max(yb0 - 2, 0), y1hi = min(yb1 + 2, h);       // rows of stage 1
@@ -416,10 +416,16 @@ hipError_t launch_tv_prep(const PrepArgs& a_in, hipStream_t s) {
   const int lpf_shift = w > 64 ? 7 : (w > 32 ? 6 : (w > 16 ? 5 : 4));
   const int fpw = w > 64 ? 1 : (64 >> lpf_shift);
   const int fgroups = (a.t.nframes + fpw - 1) / fpw;
-  // bands: enough wavefronts for ~2 per SIMD (1024 SIMDs), at least 8 output rows each, a multiple of the staging blocks
-  int nbands = a.band_rows > 0 ? (h + a.band_rows - 1) / a.band_rows : (2048 + fgroups - 1) / fgroups;
-  nbands = std::max(1, std::min(nbands, (h + 7) / 8));
-  a.band_rows = (((h + nbands - 1) / nbands + PREP_KW - 1) / PREP_KW) * PREP_KW;
+  // bands: enough wavefronts for ~2 per SIMD (1024 SIMDs); from 8 output rows on a multiple of the staging blocks
+  int nbands;
+  if (a.band_rows > 0) {  // explicit (ofdis_tuning::prep_band_rows): any even number of rows
+    a.band_rows = std::max(2, (a.band_rows + 1) & ~1);
+  } else {  // (small batches: bands down to two rows -- a band re-computes 4 + 2 margin rows, but the kernel is then bound by
+    // the latency of one wavefront marching its rows: 55 -> 36 us per one-pair pass with 2 instead of 8 rows per band)
+    nbands = std::max(1, std::min((2048 + fgroups - 1) / fgroups, (h + 1) / 2));
+    a.band_rows = ((h + nbands - 1) / nbands + 1) & ~1;
+    if (a.band_rows > PREP_KW) a.band_rows = ((a.band_rows + PREP_KW - 1) / PREP_KW) * PREP_KW;
+  }
   nbands = (h + a.band_rows - 1) / a.band_rows;
   const long long units = (long long)fgroups * nbands;
   if (w > 64) hipLaunchKernelGGL(tv_prep_kernel<2>, dim3((unsigned)units), dim3(128), 0, s, a, lpf_shift, nbands);

@@ -545,7 +545,7 @@ def test_fused_tv_strips(gpu, orc, nfr, strip, size):
         gpu.restore_tuning(old)
 
 
-@pytest.mark.parametrize("band", [8, 11, 64])
+@pytest.mark.parametrize("band", [2, 4, 6, 8, 11, 64])
 def test_prep_kernel_row_bands(gpu, orc, band):
     """The warp + derivatives kernel cut into row bands (small batches: more wavefronts; each band recomputes its margins)
     gives the same records as one wavefront marching the whole frame."""
