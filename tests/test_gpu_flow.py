@@ -582,6 +582,63 @@ def test_dropin_from_several_threads(gpu, orc):
     assert not errors, errors
 
 
+def test_cross_cu_handover_under_uneven_load(gpu, orc):
+    """The cross-CU fused TV kernel hands du/dv rows from one workgroup to the next through global memory (granules that
+    carry their own tag, ofdis_fused_xcu.hip).  Such hand-overs must be tested on a busy chip and with warm caches: here two
+    threads push single pairs through ofdis_flow (one pair = 4-6 workgroups per level on different CUs, the same granule
+    addresses call after call) and a 24-pair context is run and re-run, while a third thread keeps every CU busy with
+    3000-pair passes of the throughput kernels.  Every result must carry its pair's bits, call after call."""
+    import threading
+    cases = [synth_case(1024, 436, 2600 + k, 1, 2, 1) for k in range(2)]
+    refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
+    p = cases[0][0]
+    big = gpu.Batch(p, 3000)
+    for l in range(p.sc_l, p.sc_f + 1):
+        for kind in range(4):
+            plane = cases[0][1][kind][l] if kind < 3 else cases[0][2][0][l]
+            big.set_input(l, kind, np.broadcast_to(plane, (3000,) + plane.shape))
+    big.set_pipeline(2)  # half of it on an internal stream: that half runs beside the other contexts' streams
+    small = gpu.Batch(p, 24)
+    for slot in range(24):
+        c = cases[slot % 2]
+        small.upload(slot, c[1][0], c[1][1], c[1][2], c[2][0])
+    stop = threading.Event()
+    errors = []
+
+    def load():
+        try:
+            while not stop.is_set():
+                big.run()
+                big.join()
+        except Exception as e:  # noqa: BLE001 -- reported below
+            errors.append(("load", repr(e)))
+
+    def single(i):
+        try:
+            c = cases[i]
+            for rep in range(40):
+                assert_bits_equal(gpu.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]), refs[i], f"ofdis_flow thread {i} call {rep}")
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+    threads = [threading.Thread(target=load)] + [threading.Thread(target=single, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    try:
+        for rep in range(12):
+            small.run()
+            out = small.download_all()
+            for slot in (0, 1, 11, 22, 23):
+                assert_bits_equal(out[slot], refs[slot % 2], f"24-pair context, pass {rep}, slot {slot}")
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+    assert not errors, errors
+    assert_bits_equal(big.download(2999), refs[0], "the load batch itself")  # (joins by itself)
+    big.close()
+    small.close()
+
+
 @pytest.mark.parametrize("size,channels,opp,seed", [((1024, 436), 1, 2, 11), ((640, 480), 1, 2, 12), ((333, 251), 1, 1, 13),
                                                     ((320, 240), 3, 3, 14), ((256, 128), 1, 2, 15)])
 def test_block_world_inputs(gpu, orc, size, channels, opp, seed):
