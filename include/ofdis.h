@@ -202,7 +202,7 @@ typedef struct ofdis_tuning {
   int flow_dma;       /* 1: ofdis_flow stages through hipMemcpyAsync instead of copy kernels               OFDIS_FLOW_DMA */
   int flow_whole;     /* 1: ofdis_flow uploads the whole pyramid before the first launch                OFDIS_FLOW_WHOLE */
   int fused_xcu_max;  /* frame groups up to which the fused TV kernel runs every fixed-point iteration of a group as its
-                       * own workgroup on its own CU (contexts of <= 256 frames; 0 = never)        OFDIS_FUSED_XCU_MAX */
+                       * own workgroup on its own CU (contexts of <= 768 frames; 0 = never)        OFDIS_FUSED_XCU_MAX */
 } ofdis_tuning;
 int ofdis_get_tuning(ofdis_tuning* out);
 int ofdis_set_tuning(const ofdis_tuning* in);

@@ -46,7 +46,7 @@ void tuning_init_locked() {
   g_tuning.graph = !on("OFDIS_NO_GRAPH");
   g_tuning.flow_dma = on("OFDIS_FLOW_DMA");
   g_tuning.flow_whole = on("OFDIS_FLOW_WHOLE");
-  g_tuning.fused_xcu_max = std::max(0, num("OFDIS_FUSED_XCU_MAX", 256));
+  g_tuning.fused_xcu_max = std::max(0, num("OFDIS_FUSED_XCU_MAX", 768));
   g_tuning_init = true;
 }
 }  // namespace
@@ -262,7 +262,7 @@ struct KTimer {  // brackets one launch with events when timing is on
 // granule array; a wavefront whose hand-over row never arrives (bounded wait) sets a word in mapped host memory that the
 // synchronising entry points check -- the call then fails instead of returning a wrong flow, and the variant is switched
 // off for the rest of the process.
-constexpr int XCU_MAX_CONTEXT_FRAMES = 256;
+constexpr int XCU_MAX_CONTEXT_FRAMES = 768;
 int* g_xcu_err_host = nullptr;
 int* g_xcu_err_dev = nullptr;
 std::once_flag g_xcu_err_once;

@@ -480,11 +480,12 @@ def test_streaming_pyramid_and_upsample_paths(gpu, orc, w, h, opp, lvl):
         assert_bits_equal(full[slot], orc.upsample_crop(p, ref, w, h), f"full-resolution flow slot {slot}")
 
 
-@pytest.mark.parametrize("nfr", [7, 8, 255, 257, 512, 513, 1024, 1025, 2049])
+@pytest.mark.parametrize("nfr", [7, 8, 255, 257, 512, 513, 767, 769, 1024, 1025, 2049])
 def test_kernel_selection_does_not_change_results(gpu, orc, nfr):
-    """Which kernels run depends on the batch size: image_warp inside the derivatives kernel up to 256 pairs, the
-    multi-wave TV kernels up to 512 frame groups per launch and 1024 frames per batch (split variant up to 6 fixed-point
-    iterations), the per-XCD frame map from 8 frames on, pipelined sub-batches.  A frame's bits must not."""
+    """Which kernels run depends on the batch size: the cross-CU fused TV kernel in contexts of up to 768 frames, the
+    one-CU multi-wave TV kernels up to 512 frame groups per launch and 1024 frames per batch (split variant up to 6
+    fixed-point iterations), row bands of the warp + derivatives kernel by the number of wavefront groups, the per-XCD
+    frame map from 8 frames on, pipelined sub-batches.  A frame's bits must not."""
     w, h = 256, 128                                   # levels 3..1: 32x16, 64x32, 128x64 -- all on the fused TV path
     cases = [synth_case(w, h, 2200 + k, 1, 2, 1) for k in range(3)]
     p = cases[0][0]
