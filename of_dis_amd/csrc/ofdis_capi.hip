@@ -270,7 +270,7 @@ int* xcu_err_word() {
   std::call_once(g_xcu_err_once, [] {
     void* h = nullptr;
     void* d = nullptr;
-    if (hipHostMalloc(&h, sizeof(int), hipHostMallocMapped) != hipSuccess) return;
+    if (hipHostMalloc(&h, sizeof(int), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return;
     *(volatile int*)h = 0;
     if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return; }
     g_xcu_err_host = (int*)h;
