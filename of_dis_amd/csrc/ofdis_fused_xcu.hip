@@ -23,18 +23,18 @@ namespace ofdis {
 // so no ordering between stores is needed and nothing depends on dispatch order, timing or workgroup -> XCD placement).
 // Only the fetch wave touches granules: memory returns in order, so in a wavefront that also computes, every nearer load
 // (and the compiler's conservative wait counts around the re-read loop) exposed the 1.2 us hand-off latency at every
-// step.  The fetch wave works in batches: every XC_B steps it takes the XC_B rows it requested XC_B steps ago, checks the
-// tag of every existing pixel -- when one is missing it lets the predecessor gain XC_LEAD rows and re-reads (bounded) --
-// writes them to the ring and requests the next batch.  An iteration so trails its predecessor by ~13 steps + the latency
-// (6.8 us per iteration boundary) and never waits in steady state.
+// step.  The fetch wave takes one row per step, requested XC_AHEAD steps earlier, checks the tag of every existing pixel -- when
+// one is missing it lets the predecessor gain XC_LEAD rows and re-reads (bounded) -- and writes it to the ring.  An iteration
+// so trails its predecessor by ~9 steps of software pipeline + the latency (every row of lag costs 12 boundaries x 0.4 us
+// per one-pair pass) and never waits in steady state.
 // Tag 0 = not yet written: the array is zeroed when it is allocated, and the fetch wave puts every granule it has taken
 // back to zero, so a launch leaves the array as it found it (no memset per launch).  Block index = iteration * G8 +
 // group with G8 a multiple of 8: an iteration only waits for a LOWER block index, and the iterations of a group share an
 // XCD under the observed round-robin placement (speed only).  A wait that exceeds XC_SPIN_LIMIT re-reads (seconds) sets
 // the caller's error word and the wavefront carries on without waiting: the call fails, nothing hangs.
-constexpr int XC_B = 3;      // rows per batch of the fetch wave (divides 6); requested XC_B steps before they are taken
-constexpr int XC_LEAD = 2;   // rows the fetch wave lets the predecessor gain, beyond its requests, before it (re)starts
-constexpr int XC_RING = 8;   // rows of the LDS du/dv ring (a power of two > XC_B + 1)
+constexpr int XC_AHEAD = 3;  // steps a row is requested before the fetch wave takes it (= requests in flight; 3 x 0.4 us = the latency)
+constexpr int XC_LEAD = 1;   // rows the fetch wave lets the predecessor gain, beyond its requests, before it (re)starts
+constexpr int XC_RING = 4;   // rows of the LDS du/dv ring (a power of two > 2)
 constexpr unsigned XC_TAG = 1u;
 constexpr unsigned XC_SPIN_LIMIT = 1u << 22;  // re-reads of one row (~1 us each) before the wavefront gives up
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -43,7 +43,7 @@ template <int NS, bool BRIGHT>
 __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, const int R, const int G8, float* const xbuf,
                                                             int* const err) {
   constexpr int U = 6;
-  constexpr int PDW = 5, PDD = 3, PDU = 4;
+  constexpr int PDW = 5, PDD = 3, PDU = 3;  // (du/dv of row t+3 are read from the ring in the step that first uses them)
   static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
   __shared__ float uvl[2 * 2 * 64];              // rows wave -> data wave: du, dv of a pixel row     [row & 1][field][lane]
   __shared__ float dtl[2 * 5 * 64];              // data wave -> rows wave: a11, a12, a22, b1, b2     [row & 1][field][lane]
@@ -122,8 +122,7 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
     load_w(W[4], wrap_row(1));
     uvl[(0 * 2 + 0) * 64 + lane] = 0.0f;  // du, dv of row -2 for the data wave's first step
     uvl[(0 * 2 + 1) * 64 + lane] = 0.0f;
-    __syncthreads();  // (the fetch wave has put rows 0 and 1 into the ring)
-    ring_uv(W[3], 0);
+    __syncthreads();  // (the fetch wave has put row 0 into the ring)
     int rowW = wrap_row(PDW - 3);
     int x2 = wrap_col(-1 - j);
     bool x1_last = (wrap_col(-2 - j) == w - 1);
@@ -149,7 +148,7 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
           sr[3 * 64] = b1; sr[4 * 64] = b2; sr[5 * 64] = p_sh; sr[6 * 64] = p_sv; sr[7 * 64] = p_dur; sr[8 * 64] = p_dvr;
           sr[9 * 64] = p_hl; sr[10 * 64] = p_vt;
         }
-        // ---- (1) W row t+5; du/dv of row t+4 from the ring
+        // ---- (1) W row t+5; du/dv of row t+3 from the ring
         load_w(W[(u + PDW) % 6], rowW);
         rowW = next_row(rowW);
         ring_uv(W[(u + PDU) % 6], taut + PDU);
@@ -243,11 +242,10 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
     }
   } else if (role == 3) {
     // ------------------------------------------------------------------------------------------------ fetch wave
-    // Brings the previous iteration's du/dv rows from global memory into the LDS ring, XC_B rows every XC_B steps: at a
-    // batch step t it takes the rows t+5 .. t+4+XC_B it requested XC_B steps ago (the rows wave reads them in the next XC_B
-    // steps), checks the tag of every existing pixel -- re-reading (bounded) until the predecessor has written them, after
-    // letting it gain XC_LEAD rows -- and requests the next XC_B rows.  All its memory waits are whole-queue waits on
-    // requests that are XC_B steps old, so the other wavefronts never see the hand-off latency.
+    // Brings the previous iteration's du/dv rows from global memory into the LDS ring: at step t it takes row t+4, which it
+    // requested XC_AHEAD steps ago (the rows wave reads it in step t+1), checks the tag of every existing pixel -- when one is
+    // missing it lets the predecessor gain XC_LEAD rows and re-reads, bounded --, puts the granules back to zero and requests
+    // row t+4+XC_AHEAD.  Nothing else in this wavefront's loop waits for memory, so nobody sees the hand-off latency.
     if (it > 0) {
       const __amdgpu_buffer_rsrc_t rsX = rsrc(xbuf + (size_t)(it - 1) * it_floats, 4);
       bool dead = false;  // a row never arrived: stop waiting (the results are wrong, the err word says so)
@@ -284,23 +282,19 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
         q[1 * 64] = inr ? asf(g2) : 0.0f;
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{0, 0, 0, 0}, rsX, (inr & row_ok) ? vo4 : 0x7ffffff0, drow * h * 16, 16 /* sc1 */);
       };
-      // prologue: wait until the predecessor has passed the rows of the first batch by XC_LEAD, then take rows 0 .. 1 + XC_B
-      // in ONE round trip: rows 0 and 1 are delivered now, the others are the first batch
-      (void)wait_row(min(1 + XC_B + XC_LEAD, last_tau));
-      u32x4 XG[XC_B];
+      // prologue: wait until the predecessor has passed the first requests by XC_LEAD rows, then take rows 0 .. XC_AHEAD in
+      // ONE round trip: row 0 is delivered now, the others are the requests in flight (row r <-> XG[(r - 1) % XC_AHEAD])
+      (void)wait_row(min(XC_AHEAD + XC_LEAD, last_tau));
+      u32x4 XG[XC_AHEAD];
       {
-        u32x4 g0 = request(wrap_row(0)), g1 = request(wrap_row(1));
+        u32x4 g0 = request(wrap_row(0));
 #pragma unroll
-        for (int r = 0; r < XC_B; ++r) XG[r] = request(wrap_row(2 + r));
-        if (!dead && (__builtin_amdgcn_ballot_w64(!ready(g0, inrange(0))) | __builtin_amdgcn_ballot_w64(!ready(g1, inrange(1)))) != 0) {
-          g0 = wait_row(0);
-          g1 = wait_row(1);
-        }
+        for (int r = 0; r < XC_AHEAD; ++r) XG[r] = request(wrap_row(1 + r));
+        if (!dead && __builtin_amdgcn_ballot_w64(!ready(g0, inrange(0))) != 0) g0 = wait_row(0);
         deliver(g0, 0, wrap_row(0));
-        deliver(g1, 1, wrap_row(1));
       }
-      int rowd = wrap_row(2);          // next row to deliver
-      int rowq = wrap_row(2 + XC_B);   // next row to request
+      int rowd = wrap_row(1);             // next row to deliver
+      int rowq = wrap_row(1 + XC_AHEAD);  // next row to request
       // Last iteration: the refined flow itself, AoS (refine_variational.cpp:209-221, 92-99).  The solve wave leaves
       // every finished row in an LDS ring; every six steps this wavefront writes the six rows finished since: in a lane's
       // image row they are six consecutive pixels, 48 contiguous bytes instead of six scattered 8-byte stores.
@@ -326,25 +320,26 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
       for (int k0 = 0; k0 <= tend + 3; k0 += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          if (u % XC_B == 0) {  // batch step: rows taut + 5 .. taut + 4 + XC_B
-            bool ok = true;
-#pragma unroll
-            for (int r = 0; r < XC_B; ++r) ok &= __builtin_amdgcn_ballot_w64(!ready(XG[r], inrange(taut + 5 + r))) == 0;
-            if (!ok && !dead) {  // requested too early: fall back behind the predecessor, then take the rows one by one
-              (void)wait_row(min(taut + 4 + XC_B + XC_LEAD, last_tau));
-#pragma unroll
-              for (int r = 0; r < XC_B; ++r) XG[r] = wait_row(taut + 5 + r);
+          {  // row taut + 4, requested XC_AHEAD steps ago; the rows wave reads it in the next step
+            u32x4 g = XG[u % XC_AHEAD];
+            if (!dead && __builtin_amdgcn_ballot_w64(!ready(g, inrange(taut + 4))) != 0) {
+              // requested too early: fall back behind the predecessor, then take this row and the requests in flight (as early
+              // as this one) again, in one round trip; everything this branch loads is waited for inside it, and the ring is
+              // refilled from plain registers -- the wait counts of the fast path stay exact
+              (void)wait_row(min(taut + 4 + XC_AHEAD + XC_LEAD, last_tau));
+              const int r1 = next_row(rowd), r2 = next_row(r1);
+              u32x4 t0 = request(rowd), t1 = request(r1), t2 = request(r2);
+              if (__builtin_amdgcn_ballot_w64(!ready(t0, inrange(taut + 4))) != 0) t0 = wait_row(taut + 4);
+              if (__builtin_amdgcn_ballot_w64(!ready(t1, inrange(taut + 5))) != 0) t1 = wait_row(taut + 5);
+              if (__builtin_amdgcn_ballot_w64(!ready(t2, inrange(taut + 6))) != 0) t2 = wait_row(taut + 6);
+              g = t0;
+              XG[(u + 1) % XC_AHEAD] = t1;
+              XG[(u + 2) % XC_AHEAD] = t2;
             }
-#pragma unroll
-            for (int r = 0; r < XC_B; ++r) {
-              deliver(XG[r], taut + 5 + r, rowd);
-              rowd = next_row(rowd);
-            }
-#pragma unroll
-            for (int r = 0; r < XC_B; ++r) {
-              XG[r] = request(rowq);
-              rowq = next_row(rowq);
-            }
+            deliver(g, taut + 4, rowd);
+            rowd = next_row(rowd);
+            XG[u % XC_AHEAD] = request(rowq);
+            rowq = next_row(rowq);
           }
           if (u == U - 1 && wants_w) flush(taut - 6 - 1 - 2 * (NS - 1));  // the rows finished in steps taut-6 .. taut-1
           ++taut;
