@@ -34,6 +34,7 @@ namespace ofdis {
 // the caller's error word and the wavefront carries on without waiting: the call fails, nothing hangs.
 constexpr int XC_AHEAD = 3;  // steps a row is requested before the fetch wave takes it (= requests in flight; 3 x 0.4 us = the latency)
 constexpr int XC_LEAD = 1;   // rows the fetch wave lets the predecessor gain, beyond its requests, before it (re)starts
+constexpr int XC_SD = 1;     // rows between consecutive SOR sweeps in the solve wave
 constexpr int XC_RING = 4;   // rows of the LDS du/dv ring (a power of two > 2)
 constexpr unsigned XC_TAG = 1u;
 constexpr unsigned XC_SPIN_LIMIT = 1u << 22;  // re-reads of one row (~1 us each) before the wavefront gives up
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
                                                             int* const err) {
   constexpr int U = 6;
   constexpr int PDW = 5, PDD = 3, PDU = 3;  // (du/dv of row t+3 are read from the ring in the step that first uses them)
-  static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
+  static_assert(XC_SD * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
   __shared__ float uvl[2 * 2 * 64];              // rows wave -> data wave: du, dv of a pixel row     [row & 1][field][lane]
   __shared__ float dtl[2 * 5 * 64];              // data wave -> rows wave: a11, a12, a22, b1, b2     [row & 1][field][lane]
   __shared__ float sring[2 * SLOT_FLOATS * 64];  // rows wave -> solve wave: the finished FSlot       [row & 1][field][lane]
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
   auto wrap_row = [&](int r) { r %= rw; return r < 0 ? r + rw : r; };
   auto wrap_col = [&](int c) { c %= w; return c < 0 ? c + w : c; };
   auto next_row = [&](int r) { return (r + 1 == rw) ? 0 : r + 1; };
-  const int tend = (rw - 1) + (h - 1) + 2 * (NS - 1) + 1;  // (the solve wave runs one step behind)
+  const int tend = (rw - 1) + (h - 1) + XC_SD * (NS - 1) + 1;  // (the solve wave runs one step behind)
   const size_t it_floats = (size_t)a.t.nframes * strip_recs * 4;  // granules of one iteration boundary
   int taut = -3;  // unwrapped step number
   const bool wants_w = it == n_iters - 1 && a.flow_out;  // last iteration: the workgroup writes wx + du, wy + dv itself
@@ -341,12 +342,12 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
             XG[u % XC_AHEAD] = request(rowq);
             rowq = next_row(rowq);
           }
-          if (u == U - 1 && wants_w) flush(taut - 6 - 1 - 2 * (NS - 1));  // the rows finished in steps taut-6 .. taut-1
+          if (u == U - 1 && wants_w) flush(taut - 6 - 1 - XC_SD * (NS - 1));  // the rows finished in steps taut-6 .. taut-1
           ++taut;
           mw_step_barrier();
         }
       }
-      if (wants_w) flush(taut - 6 - 1 - 2 * (NS - 1));  // (overlaps the last flush: same values)
+      if (wants_w) flush(taut - 6 - 1 - XC_SD * (NS - 1));  // (overlaps the last flush: same values)
     } else {
       __syncthreads();
       for (int k0 = 0; k0 <= tend + 3; k0 += U) {
@@ -361,11 +362,11 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
     FSlot slot[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) slot[r] = FSlot{1, 0, 1, 0, 0, 1, 1, 0, 0, 0, 0};  // (block inverse included: any finite value)
-    float ru[NS], rv[NS], ru2[NS], rv2[NS];
+    float ru[NS], rv[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { ru[s] = rv[s] = ru2[s] = rv2[s] = 0.0f; }
-    int srow = wrap_row(-3 - 2 * (NS - 1));  // row finished by the last sweep at this wave's first step
-    int ig = -3 - j - 2 * (NS - 1);          // ... and its column in this lane
+    for (int s = 0; s < NS; ++s) ru[s] = rv[s] = 0.0f;
+    int srow = wrap_row(-3 - XC_SD * (NS - 1));  // row finished by the last sweep at this wave's first step
+    int ig = -3 - j - XC_SD * (NS - 1);          // ... and its column in this lane
     __syncthreads();
     for (int k0 = 0; k0 <= tend + 3; k0 += U) {
 #pragma unroll
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
           float nu[NS], nv[NS];
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
-            const FSlot& c = slot[(us - 2 * s + 12) % 6];
+            const FSlot& c = slot[(us - XC_SD * s + 12) % 6];
             float ou, ov, rgu, rgv, bu, bv;
             if (s == 0) {
               const FSlot& p = slot[(us + 5) % 6];
@@ -390,10 +391,13 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
               bu = from_next(c.dur);
               bv = from_next(c.dvr);
             } else {
-              ou = ru2[s - 1]; ov = rv2[s - 1];
-              rgu = ru[s - 1]; rgv = rv[s - 1];
-              bu = from_next(ru[s - 1]);
-              bv = from_next(rv[s - 1]);
+              // sweep s trails sweep s-1 by ONE row: its right / lower neighbours are what sweep s-1 produced earlier in this
+              // very step, its own old value what sweep s-1 produced one step ago (the throughput kernel keeps two rows between
+              // sweeps so that the three are independent instructions streams; here every row of lag costs more than that)
+              ou = ru[s - 1]; ov = rv[s - 1];
+              rgu = nu[s - 1]; rgv = nv[s - 1];
+              bu = from_next(nu[s - 1]);
+              bv = from_next(nv[s - 1]);
             }
             const float tu = from_prev(ru[s]), tv = from_prev(rv[s]);
             const float lu = ru[s], lv = rv[s];
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
             const u32x4 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), XC_TAG, __builtin_bit_cast(unsigned, nv[NS - 1]), XC_TAG};
             __builtin_amdgcn_raw_buffer_store_b128(v, rsX, on ? vo4 : 0x7ffffff0, srow * h * 16, 16 /* sc1 */);
           } else if (a.flow_out) {  // last iteration: the refined flow itself, AoS (refine_variational.cpp:209-221, 92-99)
-            const int frow = taut - 1 - 2 * (NS - 1);  // the row the last sweep finishes now
+            const int frow = taut - 1 - XC_SD * (NS - 1);  // the row the last sweep finishes now
             const float* q = wring + ((frow & 15) * 2) * 64 + lane;
             oring[(frow & 15) * 64 + lane] = make_float2(q[0 * 64] + nu[NS - 1], q[1 * 64] + nv[NS - 1]);
           } else {  // ... or du, dv for tv_finish_records
@@ -416,10 +420,7 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
             __builtin_amdgcn_raw_buffer_store_b64(v, rsU, on ? vo2 : 0x7ffffff0, srow * h * 8, 0);
           }
 #pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            ru2[s] = ru[s]; rv2[s] = rv[s];
-            ru[s] = nu[s]; rv[s] = nv[s];
-          }
+          for (int s = 0; s < NS; ++s) { ru[s] = nu[s]; rv[s] = nv[s]; }
           srow = next_row(srow);
           ++ig;
         }
