@@ -15,7 +15,8 @@ namespace ofdis {
 //                   five sums from the data wave, the b1 / b2 updates in the reference's order and the block inverse
 //   data wave  (1): derivative record loads and the data term (opticalflow_aux.c:342-427)
 //   solve wave (2): the NS pipelined SOR sweeps, one step behind the other two; publishes the finished du/dv row
-//   fetch wave (3): brings the previous iteration's du/dv rows into an LDS ring, a few rows ahead of the rows wave
+//   fetch wave (3): brings the previous iteration's du/dv rows into an LDS ring, one row ahead of the rows wave; in the last
+//                   iteration it also writes the refined flow, which the solve wave leaves in another LDS ring
 // Hand-overs inside the workgroup go through small LDS arrays and one LDS-only barrier per step, as in MODE 2.
 // Between iterations -- between CUs -- a finished du/dv row travels through global memory as self-validating 16-byte
 // granules {du, tag, dv, tag} written by ONE write-through (sc1) store per lane and read by sc1 loads that bypass the
