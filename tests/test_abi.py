@@ -51,6 +51,25 @@ def test_tuning_struct_layout_matches_header():
     assert (t.gray8, t.fused_tv, t.rgb12_lpp) == (1, 1, 64)
 
 
+def test_tuning_environment_variables_match_header():
+    """Every knob of ofdis_tuning names the environment variable that initialises it; the library must read exactly those
+    (and only in its one-time initialisation: no getenv on a launch path)."""
+    src = open(os.path.join(ROOT, "include", "ofdis.h")).read()
+    body = re.search(r"typedef struct ofdis_tuning \{(.*?)\} ofdis_tuning;", src, re.S).group(1)
+    documented = set(re.findall(r"OFDIS_[A-Z0-9_]+", body))
+    csrc = os.path.join(ROOT, "of_dis_amd", "csrc")
+    capi_src = open(os.path.join(csrc, "ofdis_capi.hip")).read()
+    init = capi_src[capi_src.index("void tuning_init_locked()"):capi_src.index("ofdis_tuning tuning(unsigned* epoch)")]
+    assert set(re.findall(r'"(OFDIS_[A-Z0-9_]+)"', init)) == documented
+    for name in os.listdir(csrc):
+        if name.endswith((".hip", ".h")):
+            text = open(os.path.join(csrc, name)).read()
+            if name == "ofdis_capi.hip":
+                text = text.replace(init, "")
+            code = re.sub(r"//[^\n]*", "", text)  # (comments may mention it)
+            assert "getenv(" not in code, f"{name} reads the environment outside the tuning initialisation"
+
+
 def test_params_struct_layout_matches_header():
     src = open(os.path.join(ROOT, "include", "ofdis.h")).read()
     body = re.search(r"typedef struct ofdis_params \{(.*?)\} ofdis_params;", src, re.S).group(1)
