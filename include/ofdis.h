@@ -179,11 +179,11 @@ int ofdis_batch_kernel_time(ofdis_batch* b, int kernel_class, double* ms_sum, lo
 int ofdis_batch_kernel_times(ofdis_batch* b, int kernel_class, double* ms_out, int capacity, int* launches);
 
 /* ---------------------------------------------------------------------------------------------
- * Kernel-selection knobs.  Several stages exist in more than one mapping of the SAME arithmetic (every setting gives
- * bit-identical results); the library picks by geometry and batch size.  The knobs are process-wide, are initialised
+ * Kernel-selection knobs.  Several stages exist in more than one mapping of the SAME arithmetic (every setting but
+ * `contract` gives bit-identical results); the library picks by geometry and batch size.  The knobs are process-wide, are initialised
  * ONCE from the environment variables named below at the first call into the library and can be changed at run time
  * (the parity tests run every mapping; a maintainer can pin one).  A change takes effect at the next ofdis_batch_run /
- * ofdis_flow, except fused_tv, which a context fixes at creation (it allocates the scratch of the path it will take:
+ * ofdis_flow, except fused_tv and contract, which a context fixes at creation (it allocates the scratch of the path it will take:
  * ofdis_flow_cache_clear() before ofdis_flow picks up a change).  A captured launch graph (ofdis_batch_set_graph) is
  * re-captured after a change.
  * ------------------------------------------------------------------------------------------- */
@@ -203,6 +203,12 @@ typedef struct ofdis_tuning {
   int flow_whole;     /* 1: ofdis_flow uploads the whole pyramid before the first launch                OFDIS_FLOW_WHOLE */
   int fused_xcu_max;  /* frame groups up to which the fused TV kernel runs every fixed-point iteration of a group as its
                        * own workgroup on its own CU (contexts of <= 768 frames; 0 = never)        OFDIS_FUSED_XCU_MAX */
+  int contract;       /* ARITHMETIC CONTRACT -- the one knob that changes bits.  0 = exact (default): the contract at the
+                       * top of this file, bit-identical to the reference build.  1 = fused: the tolerance contract of the
+                       * north star (flow within 1e-3 px of the reference): every kernel compiled a second time with
+                       * multiply-adds contracted to v_fma_f32 and the hardware's 1-ulp reciprocal / square root in place
+                       * of the correctly rounded ones -- same algorithm, same control flow, fewer instructions.  A context
+                       * fixes it at creation, like fused_tv.                                OFDIS_CONTRACT=fused -> 1 */
 } ofdis_tuning;
 int ofdis_get_tuning(ofdis_tuning* out);
 int ofdis_set_tuning(const ofdis_tuning* in);

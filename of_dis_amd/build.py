@@ -16,13 +16,20 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 ROOT = os.path.dirname(HERE)
 
-HIP_SOURCES = ["ofdis_dis.hip", "ofdis_tv.hip", "ofdis_prep.hip", "ofdis_sor.hip", "ofdis_fused.hip", "ofdis_fused_xcu.hip",
-               "ofdis_de.hip",
-               "ofdis_pyr.hip", "ofdis_capi.hip"]
-# -ffp-contract=off: every fp32 operation separately rounded, like the reference's SSE path.
+# Kernel files: compiled once per ARITHMETIC CONTRACT (csrc/ofdis_dev.h) from the same source, into ofdis::exact and
+# ofdis::fused; the pyramid (exact by construction for 8-bit input) and the C ABI are compiled once.
+KERNEL_SOURCES = ["ofdis_dis.hip", "ofdis_tv.hip", "ofdis_prep.hip", "ofdis_sor.hip", "ofdis_fused.hip", "ofdis_fused_xcu.hip",
+                  "ofdis_de.hip"]
+COMMON_SOURCES = ["ofdis_pyr.hip", "ofdis_capi.hip"]
+HIP_SOURCES = KERNEL_SOURCES + COMMON_SOURCES
 # -fvisibility=hidden: the shared library exports the C ABI of include/ofdis.h (marked in ofdis_capi.hip) and nothing else.
-HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
-            "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
+BASEFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+             "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
+# exact: -ffp-contract=off, every fp32 operation separately rounded, like the reference's SSE path (bit-identical results).
+# fused: the tolerance contract (EPE < 1e-3 px): a * b + c contracts into one v_fma_f32, also across statements.
+CONTRACT_FLAGS = {"exact": ["-DOFDIS_CONTRACT=0", "-ffp-contract=off"],
+                  "fused": ["-DOFDIS_CONTRACT=1", "-ffp-contract=fast"]}
+HIPFLAGS = BASEFLAGS + CONTRACT_FLAGS["exact"]
 
 
 # No SLP vectorisation: gfx950's SIMDs are 32 lanes wide, so a packed v_pk_*_f32 occupies the issue port about as
@@ -92,15 +99,20 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(ROOT, "include", "ofdis.h"))
     headers.append(os.path.abspath(__file__))  # the flags live here
-    objs = []
-    for src in HIP_SOURCES:
+    headers += [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".inc")]
+    objs, jobs = [], []
+    units = [(src, c) for c in ("exact", "fused") for src in KERNEL_SOURCES] + [(src, "exact") for src in COMMON_SOURCES]
+    for src, contract in units:
         sp = os.path.join(CSRC, src)
-        if not os.path.exists(sp):
-            continue
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        suffix = ".o" if contract == "exact" else "." + contract + ".o"
+        obj = os.path.join(LIBDIR, src.replace(".hip", suffix))
         if force or _newer(obj, [sp] + headers):
-            _run([hipcc] + HIPFLAGS + PER_FILE_FLAGS.get(src, []) + ["-c", sp, "-o", obj], verbose)
+            jobs.append([hipcc] + BASEFLAGS + CONTRACT_FLAGS[contract] + PER_FILE_FLAGS.get(src, []) + ["-c", sp, "-o", obj])
         objs.append(obj)
+    if jobs:  # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(lambda cmd: _run(cmd, verbose), jobs))
     so = lib_path()
     vs = _version_script()
     if force or _newer(so, objs + [vs]):

@@ -36,10 +36,11 @@ ABI_SYMBOLS = [
 
 
 class OfdisTuning(C.Structure):
-    """include/ofdis.h: ofdis_tuning -- kernel-selection knobs, every setting bit-identical."""
+    """include/ofdis.h: ofdis_tuning -- kernel-selection knobs, every setting bit-identical except `contract`
+    (0 = exact arithmetic, 1 = the FMA / fast-reciprocal tolerance contract)."""
     _fields_ = [(n, C.c_int) for n in ("gray8", "rgb12", "rgb12_lpp", "fused_tv", "fused_mw_max", "fused_split",
                                        "finish_fusion", "fused_strip", "prep_band_rows", "graph", "flow_dma", "flow_whole",
-                                       "fused_xcu_max")]
+                                       "fused_xcu_max", "contract")]
 
 
 class OfdisError(RuntimeError):

@@ -21,6 +21,45 @@
 
 using namespace ofdis;
 
+namespace {
+
+// The launchers of one arithmetic contract (ofdis_kernels.h / ofdis_launchers.inc): every kernel file is compiled once per
+// contract into ofdis::exact and ofdis::fused; a context fixes its contract at creation (ofdis_tuning::contract) and
+// launches through its table.
+struct Launchers {
+  decltype(&exact::launch_patch_optimize) patch_optimize;
+  decltype(&exact::launch_densify) densify;
+  decltype(&exact::launch_warp) warp;
+  decltype(&exact::launch_derivatives) derivatives;
+  decltype(&exact::tv_prep_supported) tv_prep_supported;
+  decltype(&exact::launch_tv_prep) tv_prep;
+  decltype(&exact::launch_tv_system) tv_system;
+  decltype(&exact::launch_sor) sor;
+  decltype(&exact::tv_fused_supported) tv_fused_supported;
+  decltype(&exact::tv_fused_params_ok) tv_fused_params_ok;
+  decltype(&exact::tv_fused_mode) tv_fused_mode;
+  decltype(&exact::launch_tv_fused) tv_fused;
+  decltype(&exact::launch_tv_finish_records) tv_finish_records;
+  decltype(&exact::launch_to_diag) to_diag;
+  decltype(&exact::launch_from_diag) from_diag;
+  decltype(&exact::launch_tv_finish) tv_finish;
+  decltype(&exact::launch_flow_split) flow_split;
+  decltype(&exact::launch_de_system) de_system;
+  decltype(&exact::launch_de_sor) de_sor;
+  decltype(&exact::launch_de_update) de_update;
+};
+#define OFDIS_LAUNCHER_TABLE(ns)                                                                                        \
+  {ns::launch_patch_optimize, ns::launch_densify, ns::launch_warp, ns::launch_derivatives, ns::tv_prep_supported,       \
+   ns::launch_tv_prep, ns::launch_tv_system, ns::launch_sor, ns::tv_fused_supported, ns::tv_fused_params_ok,            \
+   ns::tv_fused_mode, ns::launch_tv_fused, ns::launch_tv_finish_records, ns::launch_to_diag, ns::launch_from_diag,      \
+   ns::launch_tv_finish, ns::launch_flow_split, ns::launch_de_system, ns::launch_de_sor, ns::launch_de_update}
+const Launchers kExactLaunchers = OFDIS_LAUNCHER_TABLE(exact);
+const Launchers kFusedLaunchers = OFDIS_LAUNCHER_TABLE(fused);
+#undef OFDIS_LAUNCHER_TABLE
+const Launchers& launchers(int contract) { return contract ? kFusedLaunchers : kExactLaunchers; }
+
+}  // namespace
+
 namespace ofdis {
 
 // Kernel-selection knobs (include/ofdis.h: ofdis_tuning): read ONCE from the environment, changed only through
@@ -47,6 +86,10 @@ void tuning_init_locked() {
   g_tuning.flow_dma = on("OFDIS_FLOW_DMA");
   g_tuning.flow_whole = on("OFDIS_FLOW_WHOLE");
   g_tuning.fused_xcu_max = std::max(0, num("OFDIS_FUSED_XCU_MAX", 768));
+  {  // arithmetic contract: "fused" / "1" = the tolerance contract, anything else (or unset) = exact
+    const char* e = getenv("OFDIS_CONTRACT");
+    g_tuning.contract = (e && (!strcmp(e, "fused") || !strcmp(e, "1"))) ? 1 : 0;
+  }
   g_tuning_init = true;
 }
 }  // namespace
@@ -157,6 +200,8 @@ hipError_t launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t s
 
 struct ofdis_batch {
   ofdis_params p;
+  int contract = 0;                  // arithmetic contract, fixed at creation (ofdis_tuning::contract)
+  const Launchers* k = &kExactLaunchers;  // ... and its launchers
   int nframes = 0;
   int total_frames = 0;              // nframes of the owning context (a frame_view keeps it)
   int nlevels = 0;
@@ -339,13 +384,14 @@ bool use_fused(const ofdis_batch* b, const LevelGeom& g) {
   const TvConsts c = tv_consts(b->p.tv_alpha, b->p.tv_gamma, b->p.tv_delta);
   const TvGeom t{g.w, g.h, g.noc, b->nframes};
   // (a context created with every level on the fused path owns no unfused scratch: b->wx == nullptr keeps it there)
-  return b->wrec && (tuning().fused_tv || !b->wx) && tv_fused_supported(t, b->p.tv_solverit) && tv_prep_supported(t) &&
-         tv_fused_params_ok(c.quarter_alpha, c.half_delta_over3, c.half_gamma_over3);
+  return b->wrec && (tuning().fused_tv || !b->wx) && b->k->tv_fused_supported(t, b->p.tv_solverit) &&
+         b->k->tv_prep_supported(t) && b->k->tv_fused_params_ok(c.quarter_alpha, c.half_delta_over3, c.half_gamma_over3);
 }
 
 int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow_out,
                hipStream_t s) {
   const ofdis_params& p = b->p;
+  const Launchers& K = *b->k;
   TvGeom t{g.w, g.h, g.noc, b->nframes};
   const size_t npx = (size_t)g.w * g.h;
   const int n_inner = p.tv_innerit * (g.level + 1);  // :36
@@ -356,32 +402,32 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
     FusedArgs fa{t, b->derivs, b->wrec, b->uv, 1, c.quarter_alpha, c.half_delta_over3, c.half_gamma_over3, p.tv_solverit,
                  p.tv_sor, n_inner, b->total_frames, tn.finish_fusion ? flow_out : nullptr, tn.fused_mw_max, tn.fused_split};
     const FusedXcu fx{b->xbuf, tn.fused_xcu_max, b->xbuf ? xcu_err_word() : nullptr};
-    if (tv_fused_mode(fa, &fx) == 0) fa.S = strip_length(b, g, tn);  // strips: throughput mapping only
+    if (K.tv_fused_mode(fa, &fx) == 0) fa.S = strip_length(b, g, tn);  // strips: throughput mapping only
     {  // image_warp + get_derivatives (refine_variational.cpp:189-190): one kernel, records out
       KTimer kt(b, OFDIS_K_DERIV, s);
       PrepArgs pa{t, im_a, im_b, g.pad, g.tmp_w, g.tmp_h, flow_out, b->derivs, b->wrec, fa.S, tn.prep_band_rows};
-      HIPCHK(launch_tv_prep(pa, s));
+      HIPCHK(K.tv_prep(pa, s));
     }
     bool flow_written = false;  // the multi-wave variants of the fused kernel write the refined AoS flow themselves
     {  // every fixed-point iteration of this level in one launch (du = dv = 0 on its first pass: no memset)
       KTimer kt(b, OFDIS_K_FUSED, s);
-      HIPCHK(launch_tv_fused(fa, s, &flow_written, &fx));
+      HIPCHK(K.tv_fused(fa, s, &flow_written, &fx));
     }
     if (!flow_written) {
       KTimer kt(b, OFDIS_K_UPDATE, s);
-      HIPCHK(launch_tv_finish_records(t, flow_out, b->uv, fa.S, s));
+      HIPCHK(K.tv_finish_records(t, flow_out, b->uv, fa.S, s));
     }
     return OFDIS_OK;
   }
   {
     KTimer kt(b, OFDIS_K_WARP, s);
     WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx, b->wy, b->w_im2, b->mask};
-    HIPCHK(launch_warp(wa, s));
+    HIPCHK(K.warp(wa, s));
   }
   {
     KTimer kt(b, OFDIS_K_DERIV, s);
     DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs};
-    HIPCHK(launch_derivatives(da, s));
+    HIPCHK(K.derivatives(da, s));
   }
   HIPCHK(hipMemsetAsync(b->du, 0, npx * b->nframes * sizeof(float), s));  // image_erase :186-187
   HIPCHK(hipMemsetAsync(b->dv, 0, npx * b->nframes * sizeof(float), s));
@@ -390,17 +436,17 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
       KTimer kt(b, OFDIS_K_SYSTEM, s);
       SystemArgs sa{t, b->mask, b->wx, b->wy, b->du, b->dv, b->derivs, c.quarter_alpha, c.half_delta_over3,
                     c.half_gamma_over3, b->sys};
-      HIPCHK(launch_tv_system(sa, s));
+      HIPCHK(K.tv_system(sa, s));
     }
     {
       KTimer kt(b, OFDIS_K_SOR, s);
       SorArgs so{t, b->sys, b->du, b->dv, p.tv_solverit, p.tv_sor};
-      HIPCHK(launch_sor(so, s));
+      HIPCHK(K.sor(so, s));
     }
   }
   {
     KTimer kt(b, OFDIS_K_UPDATE, s);
-    HIPCHK(launch_tv_finish(t, b->wx, b->wy, b->du, b->dv, flow_out, s));
+    HIPCHK(K.tv_finish(t, b->wx, b->wy, b->du, b->dv, flow_out, s));
   }
   return OFDIS_OK;
 }
@@ -410,6 +456,7 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
 int run_varref_de(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow_out,
                   hipStream_t s, int camlr = 0) {
   const ofdis_params& p = b->p;
+  const Launchers& K = *b->k;
   TvGeom t{g.w, g.h, g.noc, b->nframes};
   const size_t n = (size_t)g.w * g.h * b->nframes;
   const int n_inner = p.tv_innerit * (g.level + 1);
@@ -417,12 +464,12 @@ int run_varref_de(ofdis_batch* b, const LevelGeom& g, const float* im_a, const f
   {
     KTimer kt(b, OFDIS_K_WARP, s);
     WarpArgs wa{t, im_b, 1, g.pad, g.tmp_w, g.tmp_h, b->wx, b->wy, b->w_im2, b->mask};
-    HIPCHK(launch_warp(wa, s));
+    HIPCHK(K.warp(wa, s));
   }
   {
     KTimer kt(b, OFDIS_K_DERIV, s);
     DerivArgs da{t, im_a, 1, g.pad, g.tmp_w, g.tmp_h, b->w_im2, b->derivs};
-    HIPCHK(launch_derivatives(da, s));
+    HIPCHK(K.derivatives(da, s));
   }
   HIPCHK(hipMemsetAsync(b->du, 0, n * sizeof(float), s));                                    // image_erase(du)
   HIPCHK(hipMemcpyAsync(b->uu, b->wx, n * sizeof(float), hipMemcpyDeviceToDevice, s));      // uu = wx (:283)
@@ -431,16 +478,16 @@ int run_varref_de(ofdis_batch* b, const LevelGeom& g, const float* im_a, const f
       KTimer kt(b, OFDIS_K_SYSTEM, s);
       DeSystemArgs sa{t, b->mask, b->wx, b->uu, b->du, b->derivs, c.quarter_alpha, c.half_delta_over3,
                       c.half_gamma_over3, b->sys};
-      HIPCHK(launch_de_system(sa, s));
+      HIPCHK(K.de_system(sa, s));
     }
     {
       KTimer kt(b, OFDIS_K_SOR, s);
       DeSorArgs so{t, b->sys, b->du, p.tv_solverit, p.tv_sor};
-      HIPCHK(launch_de_sor(so, s));
+      HIPCHK(K.de_sor(so, s));
     }
     {
       KTimer kt(b, OFDIS_K_UPDATE, s);
-      HIPCHK(launch_de_update(t, b->wx, b->du, b->uu, nullptr, camlr, s));  // min / max with 0 by camera side
+      HIPCHK(K.de_update(t, b->wx, b->du, b->uu, nullptr, camlr, s));  // min / max with 0 by camera side
     }
   }
   HIPCHK(hipMemcpyAsync(flow_out, b->uu, n * sizeof(float), hipMemcpyDeviceToDevice, s));   // wx = uu (:318)
@@ -451,7 +498,7 @@ int run_varref_de(ofdis_batch* b, const LevelGeom& g, const float* im_a, const f
 int run_varref_from_aos(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow,
                         hipStream_t s) {
   TvGeom t{g.w, g.h, g.noc, b->nframes};
-  if (!use_fused(b, g)) HIPCHK(launch_flow_split(t, flow, b->wx, b->wy, s));  // (the fused path starts from the AoS flow)
+  if (!use_fused(b, g)) HIPCHK(b->k->flow_split(t, flow, b->wx, b->wy, s));  // (the fused path starts from the AoS flow)
   return run_varref(b, g, im_a, im_b, flow, s);
 }
 
@@ -517,6 +564,8 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
   if (nframes < 1) return fail(OFDIS_ERR_INVALID, "nframes must be >= 1");
   ofdis_batch* b = new ofdis_batch();
   b->p = *p;
+  b->contract = tuning().contract ? 1 : 0;
+  b->k = &launchers(b->contract);
   b->nframes = nframes;
   b->total_frames = nframes;
   b->nlevels = p->sc_f - p->sc_l + 1;
@@ -551,11 +600,11 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
     // per pixel otherwise: a third of the context)
     const TvConsts tc = tv_consts(p->tv_alpha, p->tv_gamma, p->tv_delta);
     const bool may_fuse = p->noc == 1 && p->selectmode != 2 && tuning().fused_tv &&
-                          tv_fused_params_ok(tc.quarter_alpha, tc.half_delta_over3, tc.half_gamma_over3);
+                          b->k->tv_fused_params_ok(tc.quarter_alpha, tc.half_delta_over3, tc.half_gamma_over3);
     bool all_fused = may_fuse;
     for (auto& g : b->geom) {
       const TvGeom t{g.w, g.h, g.noc, nframes};
-      all_fused = all_fused && tv_fused_supported(t, p->tv_solverit) && tv_prep_supported(t);
+      all_fused = all_fused && b->k->tv_fused_supported(t, p->tv_solverit) && b->k->tv_prep_supported(t);
     }
     if (!all_fused) {
       if (!rc) rc = dalloc(b, &b->wx, npx);
@@ -855,7 +904,7 @@ int run_one_level(ofdis_batch* b, int sl, hipStream_t s) {
       a.flow_prev = (sl < p.sc_f) ? b->flow[ii + 1] : b->initflow;  // oflow.cpp:209-220
       a.p_out = b->pvec;
       a.pweight = b->pweight;
-      HIPCHK(launch_patch_optimize(a, s));
+      HIPCHK(b->k->patch_optimize(a, s));
       if (fb) {  // the backward grid: images swapped (oflow.cpp:193-197,214-215,234-235)
         a.im_a = b->in[3][ii];
         a.im_a_dx = b->in[4][ii];
@@ -865,7 +914,7 @@ int run_one_level(ofdis_batch* b, int sl, hipStream_t s) {
         a.p_out = b->pvec_bw;
         a.pweight = b->pweight_bw;
         a.camlr = 1;  // the backward grid is the right camera: displacement >= 0 (oflow.cpp:155-156, patch.cpp:191-192)
-        HIPCHK(launch_patch_optimize(a, s));
+        HIPCHK(b->k->patch_optimize(a, s));
       }
     }
     if (verbose > 1) { (void)hipStreamSynchronize(s); tt[2] = now_ms() - t0; t0 = now_ms(); }
@@ -894,7 +943,7 @@ int run_one_level(ofdis_batch* b, int sl, hipStream_t s) {
         d.flow_aos = dir ? b->flow_bw[ii] : b->flow[ii];
       }
       KTimer kt(b, OFDIS_K_DENSIFY, s);
-      HIPCHK(launch_densify(d, s));
+      HIPCHK(b->k->densify(d, s));
     }
     if (verbose > 1) { (void)hipStreamSynchronize(s); tt[3] = now_ms() - t0; t0 = now_ms(); }
     // step 5: variational refinement
@@ -1245,7 +1294,7 @@ int ofdis_image_warp(float* dst, float* mask, const float* src, const float* wx,
                      int noc, int nframes, void* stream) {
   if (!dst || !mask || !src || !wx || !wy || w < 1 || h < 1 || nframes < 1) return fail(OFDIS_ERR_INVALID, "bad arguments");
   WarpArgs a{TvGeom{w, h, noc, nframes}, src, 0, 0, 0, 0, wx, wy, dst, mask};
-  HIPCHK(launch_warp(a, (hipStream_t)stream));
+  HIPCHK(launchers(tuning().contract).warp(a, (hipStream_t)stream));
   return OFDIS_OK;
 }
 
@@ -1253,7 +1302,7 @@ int ofdis_get_derivatives(float* out, const float* im1, const float* im2w, int w
                           void* stream) {
   if (!out || !im1 || !im2w || w < 1 || h < 4 || nframes < 1) return fail(OFDIS_ERR_INVALID, "bad arguments (need h >= 4)");
   DerivArgs a{TvGeom{w, h, noc, nframes}, im1, 0, 0, 0, 0, im2w, out};
-  HIPCHK(launch_derivatives(a, (hipStream_t)stream));
+  HIPCHK(launchers(tuning().contract).derivatives(a, (hipStream_t)stream));
   return OFDIS_OK;
 }
 
@@ -1270,14 +1319,15 @@ int ofdis_tv_system(float* out, const float* mask, const float* wx, const float*
   HIPCHK(hipMalloc((void**)&tmp, npx * 9 * sizeof(float)));
   float *du_d = tmp, *dv_d = tmp + npx, *sys_d = tmp + 2 * npx;
   const TvConsts c = tv_consts(tv_alpha, tv_gamma, tv_delta);
-  hipError_t e = launch_to_diag(du, du_d, w, h, nframes, s);
-  if (e == hipSuccess) e = launch_to_diag(dv, dv_d, w, h, nframes, s);
+  const Launchers& K = launchers(tuning().contract);
+  hipError_t e = K.to_diag(du, du_d, w, h, nframes, s);
+  if (e == hipSuccess) e = K.to_diag(dv, dv_d, w, h, nframes, s);
   if (e == hipSuccess) {
     SystemArgs a{TvGeom{w, h, noc, nframes}, mask, wx, wy, du_d, dv_d, derivs, c.quarter_alpha, c.half_delta_over3,
                  c.half_gamma_over3, sys_d};
-    e = launch_tv_system(a, s);
+    e = K.tv_system(a, s);
   }
-  if (e == hipSuccess) e = launch_from_diag(sys_d, out, w, h, (long long)nframes * 7, s);
+  if (e == hipSuccess) e = K.from_diag(sys_d, out, w, h, (long long)nframes * 7, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)hipFree(tmp);
   if (e != hipSuccess) return hipfail(e, "ofdis_tv_system");
@@ -1292,15 +1342,16 @@ int ofdis_sor_coupled(float* du, float* dv, const float* sys, int iterations, fl
   float* tmp = nullptr;
   HIPCHK(hipMalloc((void**)&tmp, npx * 9 * sizeof(float)));
   float *du_d = tmp, *dv_d = tmp + npx, *sys_d = tmp + 2 * npx;
-  hipError_t e = launch_to_diag(du, du_d, w, h, nframes, s);
-  if (e == hipSuccess) e = launch_to_diag(dv, dv_d, w, h, nframes, s);
-  if (e == hipSuccess) e = launch_to_diag(sys, sys_d, w, h, (long long)nframes * 7, s);
+  const Launchers& K = launchers(tuning().contract);
+  hipError_t e = K.to_diag(du, du_d, w, h, nframes, s);
+  if (e == hipSuccess) e = K.to_diag(dv, dv_d, w, h, nframes, s);
+  if (e == hipSuccess) e = K.to_diag(sys, sys_d, w, h, (long long)nframes * 7, s);
   if (e == hipSuccess) {
     SorArgs a{TvGeom{w, h, 1, nframes}, sys_d, du_d, dv_d, iterations, omega};
-    e = launch_sor(a, s);
+    e = K.sor(a, s);
   }
-  if (e == hipSuccess) e = launch_from_diag(du_d, du, w, h, nframes, s);
-  if (e == hipSuccess) e = launch_from_diag(dv_d, dv, w, h, nframes, s);
+  if (e == hipSuccess) e = K.from_diag(du_d, du, w, h, nframes, s);
+  if (e == hipSuccess) e = K.from_diag(dv_d, dv, w, h, nframes, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)hipFree(tmp);
   if (e != hipSuccess) return hipfail(e, "ofdis_sor_coupled");
@@ -1325,13 +1376,14 @@ int ofdis_patchgrid_level(const ofdis_params* p, int level, const float* im_a, c
   a.flow_prev = flow_prev;
   a.p_out = pv;
   a.pweight = pw;
-  e = launch_patch_optimize(a, s);
+  const Launchers& K = launchers(tuning().contract);
+  e = K.patch_optimize(a, s);
   if (e == hipSuccess && flow_out) {
     DensifyArgs d;
     memset(&d, 0, sizeof(d));
     d.g = g; d.nframes = nframes; d.p = pv; d.pweight = pw; d.flow_aos = flow_out;
     d.stereo = p->selectmode == 2;
-    e = launch_densify(d, s);
+    e = K.densify(d, s);
   }
   if (e == hipSuccess && p_out)
     e = hipMemcpyAsync(p_out, pv, (size_t)g.nop * 2 * nframes * sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -1352,6 +1404,8 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   ofdis_batch b;
   b.p = *p;
   b.p.verbosity = 0;
+  b.contract = tuning().contract ? 1 : 0;
+  b.k = &launchers(b.contract);
   b.nframes = nframes;
   const LevelGeom g = make_geom(*p, level);
   if (g.h < 4) return fail(OFDIS_ERR_INVALID, "level must have >= 4 rows");
@@ -1366,9 +1420,9 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   if (!rc) rc = dalloc(&b, &b.sys, npx * 7);
   const TvConsts tc = tv_consts(p->tv_alpha, p->tv_gamma, p->tv_delta);
   const bool want_fused = p->noc == 1 && p->selectmode != 2 && tuning().fused_tv &&
-                          tv_fused_supported(TvGeom{g.w, g.h, g.noc, nframes}, p->tv_solverit) &&
-                          tv_prep_supported(TvGeom{g.w, g.h, g.noc, nframes}) &&
-                          tv_fused_params_ok(tc.quarter_alpha, tc.half_delta_over3, tc.half_gamma_over3);
+                          b.k->tv_fused_supported(TvGeom{g.w, g.h, g.noc, nframes}, p->tv_solverit) &&
+                          b.k->tv_prep_supported(TvGeom{g.w, g.h, g.noc, nframes}) &&
+                          b.k->tv_fused_params_ok(tc.quarter_alpha, tc.half_delta_over3, tc.half_gamma_over3);
   if (!rc && want_fused) {
     rc = dalloc(&b, &b.wrec, npx * 2);
     if (!rc) rc = dalloc(&b, &b.uv, npx * 2);
@@ -1392,7 +1446,7 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   } else {
     if (!rc && !want_fused) {  // (the fused path starts from the AoS flow)
       TvGeom t{g.w, g.h, g.noc, nframes};
-      hipError_t e = launch_flow_split(t, flow, b.wx, b.wy, s);
+      hipError_t e = b.k->flow_split(t, flow, b.wx, b.wy, s);
       if (e != hipSuccess) rc = hipfail(e, "flow_split");
     }
     if (!rc) rc = run_varref(&b, g, im_a, im_b, flow, s);
@@ -1416,6 +1470,9 @@ int ofdis_set_tuning(const ofdis_tuning* in) {
   if (in->rgb12_lpp != 64 && in->rgb12_lpp != 32) return fail(OFDIS_ERR_INVALID, "rgb12_lpp must be 64 or 32");
   if (in->fused_mw_max < 0 || in->fused_strip < 0 || in->prep_band_rows < 0 || in->fused_xcu_max < 0)
     return fail(OFDIS_ERR_INVALID, "negative knob");
+  if (in->fused_strip > 64 || in->prep_band_rows > 64)  // (strips index their records with 32-bit byte offsets)
+    return fail(OFDIS_ERR_INVALID, "fused_strip / prep_band_rows must be <= 64");
+  if (in->contract != 0 && in->contract != 1) return fail(OFDIS_ERR_INVALID, "contract must be 0 (exact) or 1 (fused)");
   ofdis::tuning();  // initialise from the environment first
   std::lock_guard<std::mutex> lock(ofdis::g_tuning_mutex);
   ofdis::g_tuning = *in;

@@ -11,6 +11,7 @@
 #include "ofdis_tvmath.h"
 
 namespace ofdis {
+namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
 
 // compute_smoothness at one pixel with vv == 0 (its derivative terms are exact zeros): replicate borders
 // horizontally (image.c:436-464), folded coefficients on the first / last row (image.c:376-399)
@@ -246,4 +247,5 @@ hipError_t launch_de_update(const TvGeom& t, const float* wx, const float* du, f
   return hipGetLastError();
 }
 
+}  // namespace OFDIS_KNS
 }  // namespace ofdis

@@ -4,6 +4,7 @@
 #include "ofdis_dev.h"
 
 namespace ofdis {
+namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
 
 // Reference: for ip ascending, for every pixel of the patch inside the image:
 //   absw = 1/max(2,|r|)  (RGB: 1/sum_c max(2,|r_c|));  we += absw;  flow += p*absw;
@@ -109,4 +110,5 @@ __device__ __forceinline__ void densify_accumulate_gray(const LevelGeom& g, cons
   }
 }
 
+}  // namespace OFDIS_KNS
 }  // namespace ofdis

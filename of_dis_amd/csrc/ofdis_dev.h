@@ -1,7 +1,14 @@
 // ofdis_dev.h -- shared host/device definitions for the gfx950 kernels.
 //
-// Arithmetic contract (see include/ofdis.h): fp32, no contraction (the library is compiled with
-// -ffp-contract=off), IEEE divide/sqrt (hipcc default), reference operation order.
+// Arithmetic contracts (see include/ofdis.h).  Every kernel file is compiled TWICE from the same source
+// (of_dis_amd/build.py), once per contract, into its own object set and namespace:
+//   ofdis::exact  (-DOFDIS_CONTRACT=0 -ffp-contract=off): fp32, every operation separately rounded, correctly rounded
+//                 divide / sqrt, the reference's operation order -- bit-identical to the reference build;
+//   ofdis::fused  (-DOFDIS_CONTRACT=1 -ffp-contract=fast): the tolerance contract of BASELINE.json's north star (EPE <
+//                 1e-3 px against the reference): multiply-adds contract into v_fma_f32, quotients and roots are the
+//                 hardware's 1-ulp v_rcp_f32 / v_rsq_f32 / v_sqrt_f32, sums may be re-associated where `kFusedContract`
+//                 selects a shorter form.  Same algorithm, same reduction shapes, same control flow.
+// ofdis_capi.hip picks the launcher set per context (ofdis_tuning::contract).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -9,8 +16,18 @@
 
 #include "../../include/ofdis.h"
 
+#ifndef OFDIS_CONTRACT
+#define OFDIS_CONTRACT 0
+#endif
+#if OFDIS_CONTRACT
+#define OFDIS_KNS fused
+#else
+#define OFDIS_KNS exact
+#endif
+
 namespace ofdis {
 
+constexpr bool kFusedContract = OFDIS_CONTRACT != 0;  // the contract of THIS translation unit
 constexpr int kWave = 64;  // CDNA wavefront
 
 // Per-level geometry, derived exactly as the reference does (oflow.cpp:138-157, patchgrid.cpp:42-48).
@@ -26,6 +43,8 @@ struct LevelGeom {
   unsigned steps_magic;  // ceil(2^32 / steps) for steps > 1 (0 for steps == 1): n / steps == umulhi(n, magic), 0 <= n < 65536
   size_t plane_elems;  // tmp_w*tmp_h*noc
 };
+
+namespace OFDIS_KNS {  // device helpers: one copy per contract (same source, different rounding of a * b + c)
 
 // ----------------------------------------------------------------------------- wave primitives
 template <int CTRL>
@@ -84,9 +103,9 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-// ----------------------------------------------------------------------------- IEEE divide / sqrt, trimmed
-// hipcc expands a correctly rounded fp32 `a / b` to  v_div_scale x2, v_rcp, 6 fma/mul, v_div_fmas, v_div_fixup
-// and `sqrtf` to a range scale, v_sqrt, a +-1 ulp residual test, an unscale and a class test.  The scale steps
+// ----------------------------------------------------------------------------- divide / sqrt
+// EXACT contract.  hipcc expands a correctly rounded fp32 `a / b` to  v_div_scale x2, v_rcp, 6 fma/mul, v_div_fmas,
+// v_div_fixup and `sqrtf` to a range scale, v_sqrt, a +-1 ulp residual test, an unscale and a class test.  The scale steps
 // only act on operands outside the ranges below, so the kernels whose operands provably stay inside them use
 // the same sequences without them -- same bits, 8 instead of 11 and 9 instead of 15 instructions, and the refined
 // reciprocal is shared by every quotient with the same denominator:
@@ -95,13 +114,18 @@ __device__ __forceinline__ float wave_sum(float x) {
 //                                           and NaN operands give the IEEE result through v_div_fixup.
 //   sqrt_rn(x) == sqrtf(x)                  for x >= 2^-96 (incl. +inf, NaN)
 // tests/test_gpu_kernels.py::test_trimmed_div_sqrt checks both against the compiler's expansion on the device.
+// FUSED contract.  The same names are the hardware approximations (v_rcp_f32 / v_sqrt_f32 / v_rsq_f32: 1 ulp): a quotient
+// is ONE multiply by the shared reciprocal, a root one instruction.  The operand ranges above are the same, so no
+// denormal / overflow handling is needed either (a zero denominator gives inf / NaN like the division would).
 __device__ __forceinline__ float rcp_refined(float b) {
   const float r0 = __builtin_amdgcn_rcpf(b);
+  if constexpr (kFusedContract) return r0;
   const float e = __builtin_fmaf(-b, r0, 1.0f);
   return __builtin_fmaf(e, r0, r0);
 }
 __device__ __forceinline__ float div_by(float a, float b, float r) {
   float q = a * r;
+  if constexpr (kFusedContract) return q;
   float e = __builtin_fmaf(-b, q, a);
   q = __builtin_fmaf(e, r, q);
   e = __builtin_fmaf(-b, q, a);
@@ -118,6 +142,7 @@ __device__ __forceinline__ float div_rn(float a, float b) { return div_by(a, b, 
 // modifier (8-byte encoding = two issue slots on gfx950, profiles/README.md).
 __device__ __forceinline__ float div_by_finite(float a, float nb, float r) {
   float q = a * r;
+  if constexpr (kFusedContract) return q;
   float e = __builtin_fmaf(nb, q, a);
   q = __builtin_fmaf(e, r, q);
   e = __builtin_fmaf(nb, q, a);
@@ -125,6 +150,7 @@ __device__ __forceinline__ float div_by_finite(float a, float nb, float r) {
 }
 __device__ __forceinline__ float sqrt_rn(float x) {
   const float s = __builtin_amdgcn_sqrtf(x);
+  if constexpr (kFusedContract) return s;
   const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
   const float su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
   const float ed = __builtin_fmaf(-sd, s, x);
@@ -133,6 +159,13 @@ __device__ __forceinline__ float sqrt_rn(float x) {
   r = (eu > 0.0f) ? su : r;
   return r;
 }
+// a / sqrt(x): exact contract = the two correctly rounded operations of the reference; fused = a * v_rsq_f32(x)
+__device__ __forceinline__ float div_by_sqrt(float a, float x) {
+  if constexpr (kFusedContract) return a * __builtin_amdgcn_rsqf(x);
+  return div_rn(a, sqrt_rn(x));
+}
+
+}  // namespace OFDIS_KNS
 
 // norm > outlierthresh (patch.cpp:199) is tested on the SQUARED norm: sqrt is monotonic and correctly rounded, so
 // sqrtf(x) > t  <=>  x > X with X = the largest float whose square root rounds to <= t (host sqrtf is correctly rounded)

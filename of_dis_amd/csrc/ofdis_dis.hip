@@ -24,6 +24,7 @@
 #include "ofdis_densify.h"
 
 namespace ofdis {
+namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
 
 // Sum over one patch vector in the documented reduction order (DESIGN.md "reduction order"; mirrored by
 // oracle/eigen_shim -DOFDIS_SHIM_WAVE64 and oracle_set_reduce_order(1)).
@@ -413,20 +414,25 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
   if ((blk * wpb + wave) * Q >= g.nop) return;   // wave-uniform: no patch for this wavefront
   const int sub = lane / LPP;
   const int pl = lane % LPP;
-  int ip = (blk * wpb + wave) * Q + sub;
-  const bool live = ip < g.nop;
-  if (!live) ip = g.nop - 1;  // idle lane group: shadows the last patch, never stores
+  // Which 16 patches a wavefront takes is a free choice (a patch's results go to its own index ip = gx*noph + gy): it takes
+  // 16 patches that are NEIGHBOURS ALONG A GRID ROW (row-major counter jp), not 16 consecutive indices (= a grid column).
+  // Patches of one grid row read the same image rows, `steps` pixels apart, so one load instruction of the wavefront -- 16
+  // patches x one 36-byte span -- touches 2-4 cache lines instead of 16 different ones: the kernel's memory time is the
+  // texture-address path's time per distinct line, not bytes (profiles/README.md round 4).
+  int jp = (blk * wpb + wave) * Q + sub;
+  const bool live = jp < g.nop;
+  if (!live) jp = g.nop - 1;  // idle lane group: shadows the last patch, never stores
+  const int gy = jp / g.nopw, gx = jp - gy * g.nopw;
+  const int ip = gx * g.noph + gy;
 
   const int tw = g.tmp_w;
   const size_t plane = g.plane_elems;
-  const float* __restrict__ imA = a.im_a + (size_t)frame * plane;
-  const float* __restrict__ imAx = a.im_a_dx + (size_t)frame * plane;
-  const float* __restrict__ imAy = a.im_a_dy + (size_t)frame * plane;
-  const __amdgpu_buffer_rsrc_t rsB =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(a.im_b + (size_t)frame * plane), 0, (int)(plane * sizeof(float)), 0x00020000);
+  auto plane_rsrc = [&](const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)frame * plane), 0, (int)(plane * sizeof(float)), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsB = plane_rsrc(a.im_b);
   const int row_bytes = tw * 4;
 
-  const int gx = ip / g.noph, gy = ip - gx * g.noph;
   const float rx = (float)(gx * g.steps + g.offw), ry = (float)(gy * g.steps + g.offh);
   const float inv_nv = 1.0f / 64.0f;  // x/64 == x*(1/64): both round the same real number
 
@@ -434,13 +440,20 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
   f2 T[R], Tx[R], Ty[R];
   {
     const int px = (int)roundf(rx) + g.pad, py = (int)roundf(ry) + g.pad;
-    const unsigned base = (unsigned)((py - 4) * tw + px - 4 + 2 * pl);
+    // one 8-byte buffer load per plane and patch row: per-lane byte offset of the lane's first column in the patch's first
+    // row, the row as a scalar offset
+    const __amdgpu_buffer_rsrc_t rsA = plane_rsrc(a.im_a), rsAx = plane_rsrc(a.im_a_dx), rsAy = plane_rsrc(a.im_a_dy);
+    const int vbase = ((py - 4) * tw + px - 4 + 2 * pl) * 4;
+    auto ld2 = [&](const __amdgpu_buffer_rsrc_t& rs, int r) {
+      const auto t = __builtin_amdgcn_raw_buffer_load_b64(rs, vbase, r * row_bytes, 0);
+      const unsigned u0 = t[0], u1 = t[1];  // (through scalars, see compute_err)
+      return f2{__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1)};
+    };
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const unsigned o = base + (unsigned)(r * tw);
-      T[r] = f2{imA[o], imA[o + 1]};
-      Tx[r] = f2{imAx[o], imAx[o + 1]};
-      Ty[r] = f2{imAy[o], imAy[o + 1]};
+      T[r] = ld2(rsA, r);
+      Tx[r] = ld2(rsAx, r);
+      Ty[r] = ld2(rsAy, r);
     }
     if (a.patnorm > 0) {
       const float mean = gray8_sum(T) * inv_nv;
@@ -864,4 +877,5 @@ hipError_t launch_densify(const DensifyArgs& a_in, hipStream_t s) {
   return hipGetLastError();
 }
 
+}  // namespace OFDIS_KNS
 }  // namespace ofdis

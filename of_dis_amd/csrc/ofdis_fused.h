@@ -5,6 +5,7 @@
 #include "ofdis_tvmath.h"
 
 namespace ofdis {
+namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
 
 // Quotients of this kernel: denominators are normal and positive by construction (n >= 0.01, sqrt(.. + 1e-6) >= 1e-3,
 // det >= (sum of edge weights)^2 > 0) and numerators are finite for finite images, so v_div_fixup_f32 has nothing to
@@ -84,4 +85,5 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // Launch of the cross-CU variant (ofdis_fused_xcu.hip); waves = frame groups, R = lanes per frame of a group
 hipError_t launch_tv_fused_xcu(const FusedArgs& a, const FusedXcu& x, int waves, int R, hipStream_t s);
 
+}  // namespace OFDIS_KNS
 }  // namespace ofdis

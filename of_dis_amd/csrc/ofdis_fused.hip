@@ -53,6 +53,7 @@
 #include "ofdis_fused.h"
 
 namespace ofdis {
+namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
 
 // Border handling.  The reference special-cases every border (solver.c:77-421, opticalflow_aux.c:172-199).  Here
 // an edge weight that does not exist IS zero -- sh = 0 on the last column, sv = 0 on the last row (and in the
@@ -469,4 +470,5 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow, 
   return hipGetLastError();
 }
 
+}  // namespace OFDIS_KNS
 }  // namespace ofdis

@@ -3,6 +3,7 @@
 #include "ofdis_fused.h"
 
 namespace ofdis {
+namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
 
 // ------------------------------------------------------------------------------------------- MODE 3: "xcu" (cross-CU)
 // The multi-wave variants of ofdis_fused.hip keep a frame group on ONE compute unit, and a CU issues about one wavefront
@@ -450,4 +451,5 @@ hipError_t launch_tv_fused_xcu(const FusedArgs& a, const FusedXcu& x, int waves,
   return hipGetLastError();
 }
 
+}  // namespace OFDIS_KNS
 }  // namespace ofdis

@@ -1,4 +1,7 @@
-// ofdis_kernels.h -- launchers of the gfx950 kernels (internal C++ API; the public ABI is include/ofdis.h).
+// ofdis_kernels.h -- argument blocks and launchers of the gfx950 kernels (internal C++ API; the public ABI is
+// include/ofdis.h).  The argument blocks are shared; the launchers exist once per arithmetic contract (ofdis_dev.h):
+// ofdis_launchers.inc is included into ofdis::exact and ofdis::fused, every kernel file defines its launchers in the
+// namespace of the contract it is being compiled for (OFDIS_KNS), and ofdis_capi.hip picks a set per context.
 #pragma once
 #include "ofdis_dev.h"
 
@@ -25,8 +28,6 @@ struct DisArgs {
 };
 // snapshot of the kernel-selection knobs (include/ofdis.h: ofdis_tuning; ofdis_capi.hip); *epoch counts the changes
 ofdis_tuning tuning(unsigned* epoch = nullptr);
-// PatGridClass::{InitializeGrid, SetTargetImage, InitializeFromCoarserOF, Optimize}
-hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s);
 
 struct DensifyArgs {
   LevelGeom g;
@@ -42,8 +43,6 @@ struct DensifyArgs {
   const float* cg_p;        // [B][nop][2]
   const float* cg_pweight;  // [B][nop][novals]
 };
-// PatGridClass::AggregateFlowDense as an order-preserving gather
-hipError_t launch_densify(const DensifyArgs& a, hipStream_t s);
 
 struct TvGeom {
   int w, h, noc, nframes;
@@ -60,7 +59,6 @@ struct WarpArgs {
   float* dst;
   float* mask;
 };
-hipError_t launch_warp(const WarpArgs& a, hipStream_t s);
 // get_derivatives.  im1 as for WarpArgs.src; im2w packed planar [B][noc][h][w].
 // out [B][8][noc][h][w]
 struct DerivArgs {
@@ -70,7 +68,6 @@ struct DerivArgs {
   const float* im2w;
   float* out;  // [B][8][noc][h][w] row-major
 };
-hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s);
 
 // image_warp + get_derivatives of the fused TV path in one row-marching kernel (ofdis_prep.hip): densified AoS flow and the
 // two padded gray planes in, the sdiag records of the fused TV kernel out (ofdis_dev.h: sdiag_index)
@@ -85,8 +82,6 @@ struct PrepArgs {
   int S;              // frames per strip
   int band_rows;      // output rows per wavefront (0 = chosen by the launcher from the batch size)
 };
-bool tv_prep_supported(const TvGeom& t);
-hipError_t launch_tv_prep(const PrepArgs& a, hipStream_t s);
 
 // compute_smoothness + compute_data + sub_laplacian x2 -> sys [B][7][w*h] in DIAG layout (ofdis_dev.h)
 struct SystemArgs {
@@ -100,7 +95,6 @@ struct SystemArgs {
   float quarter_alpha, half_delta_over3, half_gamma_over3;
   float* sys;
 };
-hipError_t launch_tv_system(const SystemArgs& a, hipStream_t s);
 
 // sor_coupled; every operand in DIAG layout
 struct SorArgs {
@@ -111,7 +105,6 @@ struct SorArgs {
   int iterations;
   float omega;
 };
-hipError_t launch_sor(const SorArgs& a, hipStream_t s);
 
 // All fixed-point iterations of a level fused: compute_smoothness + compute_data + 2x sub_laplacian produce each
 // anti-diagonal's system coefficients in registers, immediately consumed by the wavefront SOR of
@@ -141,28 +134,9 @@ struct FusedXcu {
   int max_groups = 0;      // frame groups up to which the variant is launched (0 = never)
   int* err = nullptr;      // optional device-visible word, set to 1 when a hand-over row never arrived (results invalid)
 };
-bool tv_fused_supported(const TvGeom& t, int iterations);
-// the fused kernel's trimmed divisions (ofdis_dev.h) need the three weights to be 0 or of ordinary magnitude
-bool tv_fused_params_ok(float quarter_alpha, float half_delta_over3, float half_gamma_over3);
-// 0 = one wavefront per strip group (throughput), 1 = a wavefront per fixed-point iteration, 2 = producer + solver each,
-// 3 = one workgroup (three wavefronts) per fixed-point iteration, the iterations of a frame group on different CUs
-int tv_fused_mode(const FusedArgs& a, const FusedXcu* x = nullptr);
-hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow = nullptr, const FusedXcu* x = nullptr);
 
-// uu = wx + du, vv = wy + dv (refine_variational.cpp:209-221, 92-99) in place: flow (AoS, row-major) holds wx, wy on entry
-// and the refined flow on return; uv = the fused kernel's du, dv records
-hipError_t launch_tv_finish_records(const TvGeom& t, float* flow_aos, const float* uv, int S, hipStream_t s);
 
-// layout conversion of `nplanes` planes of w x h (row-major <-> diag); used by the per-function entry
-// points, whose public interface is row-major
-hipError_t launch_to_diag(const float* src_rm, float* dst_diag, int w, int h, long long nplanes, hipStream_t s);
-hipError_t launch_from_diag(const float* src_diag, float* dst_rm, int w, int h, long long nplanes, hipStream_t s);
 
-// uu=wx+du, vv=wy+dv -> AoS flow (refine_variational.cpp:209-221, 92-99); wx,wy row-major, du,dv DIAG
-hipError_t launch_tv_finish(const TvGeom& t, const float* wx, const float* wy, const float* du, const float* dv,
-                            float* flow_aos, hipStream_t s);
-// AoS flow -> planar wx, wy (refine_variational.cpp:56-68)
-hipError_t launch_flow_split(const TvGeom& t, const float* flow_aos, float* wx, float* wy, hipStream_t s);
 
 // on-device pyramid (ofdis_pyr.hip; run_dense.cpp:130-178,298-311 restated)
 hipError_t launch_pyr_base(const uint8_t* src, float* dst, int nframes, int wo, int ho, int W, int H, int noc, int l,
@@ -186,7 +160,6 @@ struct DeSystemArgs {
   float quarter_alpha, half_delta_over3, half_gamma_over3;
   float* sys;          // [B][4][w*h] diag: a11, b1, smooth_horiz, smooth_vert
 };
-hipError_t launch_de_system(const DeSystemArgs& a, hipStream_t s);
 struct DeSorArgs {
   TvGeom t;
   const float* sys;
@@ -194,8 +167,12 @@ struct DeSorArgs {
   int iterations;
   float omega;
 };
-hipError_t launch_de_sor(const DeSorArgs& a, hipStream_t s);
-hipError_t launch_de_update(const TvGeom& t, const float* wx, const float* du, float* uu, float* out, int camlr,
-                            hipStream_t s);
+
+namespace exact {
+#include "ofdis_launchers.inc"
+}  // namespace exact
+namespace fused {
+#include "ofdis_launchers.inc"
+}  // namespace fused
 
 }  // namespace ofdis

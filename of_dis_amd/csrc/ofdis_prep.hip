@@ -37,6 +37,7 @@
 #include "ofdis_tvmath.h"
 
 namespace ofdis {
+namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -433,4 +434,5 @@ hipError_t launch_tv_prep(const PrepArgs& a_in, hipStream_t s) {
   return hipGetLastError();
 }
 
+}  // namespace OFDIS_KNS
 }  // namespace ofdis

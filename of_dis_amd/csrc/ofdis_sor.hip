@@ -27,6 +27,7 @@
 #include "ofdis_kernels.h"
 
 namespace ofdis {
+namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
 
 // One ring slot = everything the sweeps need about pixel (j, tau - j), tau = the step at which
 // sweep 0 reaches it.  a11/a12/a22 are overwritten by the block inverse when sweep 0 gets there.
@@ -444,4 +445,5 @@ hipError_t launch_sor(const SorArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+}  // namespace OFDIS_KNS
 }  // namespace ofdis

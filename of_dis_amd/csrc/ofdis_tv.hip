@@ -17,6 +17,7 @@
 #include "ofdis_tvmath.h"
 
 namespace ofdis {
+namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
 
 // ------------------------------------------------------------------------------------------ warp
 // image_warp (opticalflow_aux.c:18-60).  HBM-streaming kernel: per pixel it reads wx, wy, writes the
@@ -508,4 +509,5 @@ hipError_t launch_flow_split(const TvGeom& t, const float* flow_aos, float* wx, 
   return hipGetLastError();
 }
 
+}  // namespace OFDIS_KNS
 }  // namespace ofdis

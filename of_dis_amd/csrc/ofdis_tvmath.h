@@ -4,6 +4,7 @@
 #include "ofdis_dev.h"
 
 namespace ofdis {
+namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
 
 // 3-tap flow derivative of refine_variational.cpp:47-48: coeffs = { -0.5, -0, 0.5 }
 #define D3_C0 (-0.5f)
@@ -102,4 +103,5 @@ __device__ __forceinline__ void data_term(DF D, int noc, float m, float u, float
   }
 }
 
+}  // namespace OFDIS_KNS
 }  // namespace ofdis

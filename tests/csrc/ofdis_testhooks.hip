@@ -7,6 +7,7 @@
 #include "../../of_dis_amd/csrc/ofdis_dev.h"
 
 using namespace ofdis;
+using namespace ofdis::exact;  // (the helpers under test are the exact contract's)
 
 __global__ void wave_sum_test_kernel(const float* in, float* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
