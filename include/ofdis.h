@@ -159,6 +159,14 @@ int ofdis_batch_set_graph(ofdis_batch* b, int mode);
 /* device pointer to the result, [nframes][h>>sc_l][w>>sc_l][2] ([..][1] in stereo-depth mode); in pipelined mode valid on
  * a stream after ofdis_batch_join(b, stream) */
 const float* ofdis_batch_flow(const ofdis_batch* b);
+/* After the caller has synchronised the stream(s) of the context's last pass by its own means: OFDIS_OK, or
+ * OFDIS_ERR_DEVICE when that pass's results are invalid.  The one kernel that can report this is the cross-CU variant of the
+ * fused TV kernel (contexts of <= 768 frames; ofdis_tuning::fused_xcu_max): its workgroups hand rows to each other through
+ * memory and wait, bounded, for workgroups the dispatcher started earlier; a wait that expires marks the pass as failed.
+ * The failure stays with the context until its next ofdis_batch_run, which no longer uses the variant: run again.
+ * ofdis_batch_download, ofdis_flow (which repeats the pass itself) and ofdis_sync on the stream of the pass report the same
+ * condition; callers that synchronise through HIP directly call this. */
+int ofdis_batch_status(ofdis_batch* b);
 /* device pointer to the dense flow of an intermediate level (for per-level parity tests) */
 const float* ofdis_batch_level_flow(const ofdis_batch* b, int level);
 int ofdis_batch_download(ofdis_batch* b, int frame, float* outflow_host, void* stream);
@@ -203,6 +211,11 @@ typedef struct ofdis_tuning {
   int flow_whole;     /* 1: ofdis_flow uploads the whole pyramid before the first launch                OFDIS_FLOW_WHOLE */
   int fused_xcu_max;  /* frame groups up to which the fused TV kernel runs every fixed-point iteration of a group as its
                        * own workgroup on its own CU (contexts of <= 768 frames; 0 = never)        OFDIS_FUSED_XCU_MAX */
+  int fused_tp_pipe;  /* 1: large batches run the fused TV kernel with one wavefront per fixed-point iteration and strip (the
+                       * iterations of a strip on one compute unit share the derivative records through the L2); 0: one
+                       * wavefront per strip walks all iterations                              OFDIS_FUSED_NO_TP_PIPE -> 0 */
+  int fused_xcu_spin; /* re-reads (~1 us each) a workgroup of that variant waits for a hand-over row before it reports the
+                       * pass as failed; 0 = the default, 2^22 (seconds)                          OFDIS_FUSED_XCU_SPIN */
   int contract;       /* ARITHMETIC CONTRACT -- the one knob that changes bits.  0 = exact (default): the contract at the
                        * top of this file, bit-identical to the reference build.  1 = fused: the tolerance contract of the
                        * north star (flow within 1e-3 px of the reference): every kernel compiled a second time with

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "ofdis_batch_level_flow", "ofdis_batch_download", "ofdis_batch_upsample", "ofdis_batch_timing", "ofdis_batch_kernel_time",
     "ofdis_image_warp", "ofdis_get_derivatives", "ofdis_tv_system", "ofdis_sor_coupled", "ofdis_patchgrid_level",
     "ofdis_varref_level", "ofdis_dev_alloc", "ofdis_dev_free", "ofdis_memcpy_h2d", "ofdis_memcpy_d2h", "ofdis_memcpy_d2d", "ofdis_sync",
-    "ofdis_batch_set_graph", "ofdis_flow_cache_clear", "ofdis_get_tuning", "ofdis_set_tuning", "ofdis_batch_kernel_times", "ofdis_device_pci_bus_id",
+    "ofdis_batch_set_graph", "ofdis_batch_status", "ofdis_flow_cache_clear", "ofdis_get_tuning", "ofdis_set_tuning", "ofdis_batch_kernel_times", "ofdis_device_pci_bus_id",
 ]
 
 
@@ -40,7 +40,7 @@ class OfdisTuning(C.Structure):
     (0 = exact arithmetic, 1 = the FMA / fast-reciprocal tolerance contract)."""
     _fields_ = [(n, C.c_int) for n in ("gray8", "rgb12", "rgb12_lpp", "fused_tv", "fused_mw_max", "fused_split",
                                        "finish_fusion", "fused_strip", "prep_band_rows", "graph", "flow_dma", "flow_whole",
-                                       "fused_xcu_max", "contract")]
+                                       "fused_xcu_max", "fused_tp_pipe", "fused_xcu_spin", "contract")]
 
 
 class OfdisError(RuntimeError):
@@ -74,6 +74,7 @@ def lib():
         L.ofdis_batch_upload.argtypes = [VP, C.c_int, C.POINTER(FP), C.POINTER(FP), C.POINTER(FP), C.POINTER(FP), VP]
         L.ofdis_batch_build_pyramids_u8.argtypes = [VP, VP, VP, C.c_int, C.c_int, VP]
         L.ofdis_batch_run.argtypes = [VP, VP]
+        L.ofdis_batch_status.argtypes = [VP]
         L.ofdis_batch_flow.restype = VP
         L.ofdis_batch_flow.argtypes = [VP]
         L.ofdis_batch_level_flow.restype = VP
@@ -337,6 +338,10 @@ class Batch:
 
     def join(self, stream=None):
         check(lib().ofdis_batch_join(self.h, stream))
+
+    def status(self):
+        """ofdis_batch_status: 0, or OFDIS_ERR_DEVICE (-3) when the last pass's results are invalid (call after a sync)."""
+        return lib().ofdis_batch_status(self.h)
 
     def flow_ptr(self):
         return lib().ofdis_batch_flow(self.h)

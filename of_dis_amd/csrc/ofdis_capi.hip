@@ -86,6 +86,8 @@ void tuning_init_locked() {
   g_tuning.flow_dma = on("OFDIS_FLOW_DMA");
   g_tuning.flow_whole = on("OFDIS_FLOW_WHOLE");
   g_tuning.fused_xcu_max = std::max(0, num("OFDIS_FUSED_XCU_MAX", 768));
+  g_tuning.fused_tp_pipe = !on("OFDIS_FUSED_NO_TP_PIPE");
+  g_tuning.fused_xcu_spin = std::max(0, num("OFDIS_FUSED_XCU_SPIN", 0));
   {  // arithmetic contract: "fused" / "1" = the tolerance contract, anything else (or unset) = exact
     const char* e = getenv("OFDIS_CONTRACT");
     g_tuning.contract = (e && (!strcmp(e, "fused") || !strcmp(e, "1"))) ? 1 : 0;
@@ -198,6 +200,21 @@ hipError_t launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t s
 
 }  // namespace
 
+// Cross-CU variant of the fused TV kernel (ofdis_fused_xcu.hip): a workgroup whose hand-over row never arrives (bounded
+// wait) sets a word in mapped host memory.  The word belongs to the CONTEXT that launched the kernel: it is allocated with
+// the context (never on a launch path), polled by every synchronising entry point on behalf of that context only, and a
+// context that has seen it once never launches the variant again (its granule array is re-zeroed before the next pass).
+struct XcuState {
+  int* host = nullptr;             // mapped, device-visible
+  int* dev = nullptr;
+  bool off = false;                // the variant is off for this context
+  bool failed = false;             // the results of the last pass are invalid (until the next pass starts)
+  bool told_sync = false;          // ofdis_sync has reported the failure (it does so once; status / download keep saying it)
+  bool rezero = false;             // the granule array may hold stale tags
+  hipStream_t last_stream = nullptr;  // where the last pass was enqueued (ofdis_sync polls the contexts of its stream)
+  bool ran = false;
+};
+
 struct ofdis_batch {
   ofdis_params p;
   int contract = 0;                  // arithmetic contract, fixed at creation (ofdis_tuning::contract)
@@ -223,6 +240,7 @@ struct ofdis_batch {
                                          // derivative records there (ofdis_dev.h: sdiag_index)
   float* xbuf = nullptr;                 // ... and the hand-over granules of its cross-CU variant (small contexts only)
   size_t xbuf_per_frame = 0;             // floats
+  struct XcuState* xcu = nullptr;        // ... with the variant's error word (owned by the context; frame views share it)
   std::vector<float*> pyr_tmp;       // unpadded level images (ofdis_batch_build_pyramids_u8), lazily allocated
   // device memory: requests are collected (dalloc) and served from ONE hipMalloc per commit (dcommit) -- a context is
   // one allocation (two with the u8 pyramid scratch), and the input planes form one contiguous region [in_base,
@@ -303,33 +321,61 @@ struct KTimer {  // brackets one launch with events when timing is on
   }
 };
 
-// Cross-CU variant of the fused TV kernel (ofdis_fused.hip, MODE 3): contexts up to this many frames own the hand-over
-// granule array; a wavefront whose hand-over row never arrives (bounded wait) sets a word in mapped host memory that the
-// synchronising entry points check -- the call then fails instead of returning a wrong flow, and the variant is switched
-// off for the rest of the process.
+// Contexts of up to this many frames own the hand-over granule array of the cross-CU fused TV variant
 constexpr int XCU_MAX_CONTEXT_FRAMES = 768;
-int* g_xcu_err_host = nullptr;
-int* g_xcu_err_dev = nullptr;
-std::once_flag g_xcu_err_once;
-int* xcu_err_word() {
-  std::call_once(g_xcu_err_once, [] {
-    void* h = nullptr;
-    void* d = nullptr;
-    if (hipHostMalloc(&h, sizeof(int), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return;
-    *(volatile int*)h = 0;
-    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return; }
-    g_xcu_err_host = (int*)h;
-    g_xcu_err_dev = (int*)d;
-  });
-  return g_xcu_err_dev;
+// live contexts that own a cross-CU error word (ofdis_sync has only a stream to go by)
+std::mutex g_xcu_mutex;
+std::vector<ofdis_batch*> g_xcu_contexts;
+
+int xcu_state_create(ofdis_batch* b) {  // in ofdis_batch_create / ofdis_varref_level, never on a launch path
+  void* h = nullptr;
+  void* d = nullptr;
+  HIPCHK(hipHostMalloc(&h, sizeof(int), hipHostMallocMapped | hipHostMallocPortable));
+  *(volatile int*)h = 0;
+  hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+  if (e != hipSuccess) { (void)hipHostFree(h); return hipfail(e, "hipHostGetDevicePointer"); }
+  b->xcu = new XcuState();
+  b->xcu->host = (int*)h;
+  b->xcu->dev = (int*)d;
+  return OFDIS_OK;
 }
-int xcu_check() {  // after a synchronisation
-  if (g_xcu_err_host && *(volatile int*)g_xcu_err_host) {
-    *(volatile int*)g_xcu_err_host = 0;
-    ofdis_tuning t = ofdis::tuning();
-    t.fused_xcu_max = 0;
-    (void)ofdis_set_tuning(&t);
-    return fail(OFDIS_ERR_DEVICE, "fused TV kernel (cross-CU variant): a hand-over row never arrived; the variant is now off");
+void xcu_state_destroy(ofdis_batch* b) {
+  if (!b->xcu) return;
+  {
+    std::lock_guard<std::mutex> lock(g_xcu_mutex);
+    g_xcu_contexts.erase(std::remove(g_xcu_contexts.begin(), g_xcu_contexts.end(), b), g_xcu_contexts.end());
+  }
+  (void)hipHostFree(b->xcu->host);
+  delete b->xcu;
+  b->xcu = nullptr;
+}
+// After a synchronisation that covers the context's last pass: OFDIS_ERR_DEVICE when that pass's results are invalid.
+// The failure stays attached to the context until its next pass starts (xcu_begin_pass), which runs without the variant.
+int xcu_poll(ofdis_batch* b) {
+  XcuState* x = b ? b->xcu : nullptr;
+  if (!x) return OFDIS_OK;
+  if (*(volatile int*)x->host) {
+    *(volatile int*)x->host = 0;
+    x->failed = true;
+    x->off = true;
+    x->rezero = true;
+  }
+  if (x->failed)
+    return fail(OFDIS_ERR_DEVICE, "fused TV kernel (cross-CU variant): a hand-over row never arrived; the results of this pass are "
+                                  "invalid -- run the context again (it no longer uses the variant)");
+  return OFDIS_OK;
+}
+int xcu_begin_pass(ofdis_batch* b, hipStream_t s) {
+  XcuState* x = b->xcu;
+  if (!x) return OFDIS_OK;
+  if (*(volatile int*)x->host) (void)xcu_poll(b);  // a failure nobody has polled yet: the variant goes off all the same
+  x->failed = false;
+  x->told_sync = false;
+  x->last_stream = s;
+  x->ran = true;
+  if (x->rezero && b->xbuf) {  // stale tags of the pass that failed
+    HIPCHK(hipMemsetAsync(b->xbuf, 0, b->xbuf_per_frame * b->total_frames * sizeof(float), s));
+    x->rezero = false;
   }
   return OFDIS_OK;
 }
@@ -368,12 +414,15 @@ TvConsts tv_consts(float alpha, float gamma, float delta) {  // refine_variation
 // SIMDs: measured at 16384 pairs (level 3, ms per 4096 pairs): S = 1 / 2 / 4 / 8 -> 2.30 / 2.18 / 2.21 / 2.24
 // (profiles/README.md r03_b).  Rule: the largest S in {4, 2} that divides the frame count and leaves >= 4096 wavefronts in
 // the launch, else 1; ofdis_tuning::fused_strip overrides.
-int strip_length(const ofdis_batch* b, const LevelGeom& g, const ofdis_tuning& tn) {
+// `pipe`: the iteration-pipelined mapping (a workgroup of n_inner wavefronts per strip group): every wavefront pays the
+// fill / drain and the lag behind its predecessor per strip, so longer strips pay off more -- the largest S in {8, 4, 2}
+// that leaves >= 1024 workgroups (two rounds of what the chip holds).
+int strip_length(const ofdis_batch* b, const LevelGeom& g, const ofdis_tuning& tn, bool pipe) {
   const int n = b->nframes;
   if (tn.fused_strip > 0) return (n % tn.fused_strip == 0) ? tn.fused_strip : 1;
   const int R = g.h <= 16 ? 16 : (g.h <= 32 ? 32 : 64);
-  for (int S = 4; S > 1; S >>= 1)
-    if (n % S == 0 && (n / S) / (64 / R) >= 4096) return S;
+  for (int S = pipe ? 8 : 4; S > 1; S >>= 1)
+    if (n % S == 0 && (n / S) / (64 / R) >= (pipe ? 1024 : 4096)) return S;
   return 1;
 }
 
@@ -388,21 +437,28 @@ bool use_fused(const ofdis_batch* b, const LevelGeom& g) {
          b->k->tv_prep_supported(t) && b->k->tv_fused_params_ok(c.quarter_alpha, c.half_delta_over3, c.half_gamma_over3);
 }
 
+// `fused`: use_fused(b, g), decided ONCE per level by the caller (the densification before this call has to agree with it)
 int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow_out,
-               hipStream_t s) {
+               hipStream_t s, bool fused) {
   const ofdis_params& p = b->p;
   const Launchers& K = *b->k;
   TvGeom t{g.w, g.h, g.noc, b->nframes};
   const size_t npx = (size_t)g.w * g.h;
   const int n_inner = p.tv_innerit * (g.level + 1);  // :36
   const TvConsts c = tv_consts(p.tv_alpha, p.tv_gamma, p.tv_delta);
-  if (use_fused(b, g)) {
+  if (fused) {
     if (n_inner <= 0) return OFDIS_OK;  // du = dv = 0: the flow stays what it is
     const ofdis_tuning tn = tuning();
     FusedArgs fa{t, b->derivs, b->wrec, b->uv, 1, c.quarter_alpha, c.half_delta_over3, c.half_gamma_over3, p.tv_solverit,
-                 p.tv_sor, n_inner, b->total_frames, tn.finish_fusion ? flow_out : nullptr, tn.fused_mw_max, tn.fused_split};
-    const FusedXcu fx{b->xbuf, tn.fused_xcu_max, b->xbuf ? xcu_err_word() : nullptr};
-    if (K.tv_fused_mode(fa, &fx) == 0) fa.S = strip_length(b, g, tn);  // strips: throughput mapping only
+                 p.tv_sor, n_inner, b->total_frames, tn.finish_fusion ? flow_out : nullptr, tn.fused_mw_max, tn.fused_split, 0};
+    // (no error word, or a context that has seen a lost hand-over: never the cross-CU variant)
+    const bool xcu_ok = b->xbuf && b->xcu && !b->xcu->off;
+    const FusedXcu fx{xcu_ok ? b->xbuf : nullptr, xcu_ok ? tn.fused_xcu_max : 0, xcu_ok ? b->xcu->dev : nullptr,
+                      tn.fused_xcu_spin > 0 ? (unsigned)tn.fused_xcu_spin : 0u};
+    if (K.tv_fused_mode(fa, &fx) == 0) {  // not the small-batch regime: strips, on one of the two throughput mappings
+      fa.tp_pipe = tn.fused_tp_pipe;
+      fa.S = strip_length(b, g, tn, K.tv_fused_mode(fa, &fx) == 1);
+    }
     {  // image_warp + get_derivatives (refine_variational.cpp:189-190): one kernel, records out
       KTimer kt(b, OFDIS_K_DERIV, s);
       PrepArgs pa{t, im_a, im_b, g.pad, g.tmp_w, g.tmp_h, flow_out, b->derivs, b->wrec, fa.S, tn.prep_band_rows};
@@ -496,10 +552,10 @@ int run_varref_de(ofdis_batch* b, const LevelGeom& g, const float* im_a, const f
 
 // same, starting from an AoS flow (the backward direction of usefbcon, whose densified flow waits in AoS form)
 int run_varref_from_aos(ofdis_batch* b, const LevelGeom& g, const float* im_a, const float* im_b, float* flow,
-                        hipStream_t s) {
+                        hipStream_t s, bool fused) {
   TvGeom t{g.w, g.h, g.noc, b->nframes};
-  if (!use_fused(b, g)) HIPCHK(b->k->flow_split(t, flow, b->wx, b->wy, s));  // (the fused path starts from the AoS flow)
-  return run_varref(b, g, im_a, im_b, flow, s);
+  if (!fused) HIPCHK(b->k->flow_split(t, flow, b->wx, b->wy, s));  // (the fused path starts from the AoS flow)
+  return run_varref(b, g, im_a, im_b, flow, s, fused);
 }
 
 }  // namespace
@@ -620,12 +676,17 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
     if (!rc && may_fuse) {
       rc = dalloc(b, &b->wrec, npx * 2);
       if (!rc) rc = dalloc(b, &b->uv, npx * 2);
-      if (!rc && nframes <= XCU_MAX_CONTEXT_FRAMES) {  // {du, tag, dv, tag} per pixel and iteration boundary (ofdis_fused.hip)
+      // cross-CU variant: {du, tag, dv, tag} per pixel and iteration boundary (ofdis_fused_xcu.hip), sized over the levels
+      // that can take it (fused path, >= 2 fixed-point iterations) and only while the knob is on: 16 B x (n_inner - 1) per
+      // pixel of the largest such level, 344 KB per frame at operating point 2
+      if (!rc && nframes <= XCU_MAX_CONTEXT_FRAMES && tuning().fused_xcu_max > 0) {
         for (auto& g : b->geom) {
+          const TvGeom t{g.w, g.h, g.noc, nframes};
           const size_t n_inner = (size_t)std::max(1, p->tv_innerit * (g.level + 1));
-          b->xbuf_per_frame = std::max(b->xbuf_per_frame, (n_inner - 1) * g.w * g.h * 4);
+          if (n_inner >= 2 && b->k->tv_fused_supported(t, p->tv_solverit) && b->k->tv_prep_supported(t))
+            b->xbuf_per_frame = std::max(b->xbuf_per_frame, (n_inner - 1) * g.w * g.h * 4);
         }
-        rc = dalloc(b, &b->xbuf, b->xbuf_per_frame * nframes);
+        if (b->xbuf_per_frame) rc = dalloc(b, &b->xbuf, b->xbuf_per_frame * nframes);
       }
     }
   }
@@ -634,6 +695,11 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
   if (!rc && b->xbuf) {  // granule tags: 0 = not yet written (the kernel restores the zeros itself)
     hipError_t e = hipMemset(b->xbuf, 0, b->xbuf_per_frame * nframes * sizeof(float));
     if (e != hipSuccess) rc = hipfail(e, "hipMemset");
+    if (!rc) rc = xcu_state_create(b);
+    if (!rc) {
+      std::lock_guard<std::mutex> lock(g_xcu_mutex);
+      g_xcu_contexts.push_back(b);
+    }
   }
   if (rc) {
     ofdis_batch_destroy(b);
@@ -645,6 +711,7 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
 
 void ofdis_batch_destroy(ofdis_batch* b) {
   if (!b) return;
+  xcu_state_destroy(b);
   for (hipStream_t st : b->sub_streams) {
     (void)hipStreamSynchronize(st);
     (void)hipStreamDestroy(st);
@@ -820,6 +887,7 @@ int ofdis_batch_set_graph(ofdis_batch* b, int mode) {
 int ofdis_batch_run(ofdis_batch* b, void* stream) {
   if (!b) return fail(OFDIS_ERR_INVALID, "batch is NULL");
   hipStream_t s = (hipStream_t)stream;
+  if (int rc = xcu_begin_pass(b, s)) return rc;
   int S = (b->timing || b->p.verbosity != 0) ? 1 : b->pipeline;
   if (b->nframes < 2 * S) S = 1;
   if (S == 1) {
@@ -894,6 +962,9 @@ int run_one_level(ofdis_batch* b, int sl, hipStream_t s) {
     // search run as ONE kernel (pconst/pinit are reported as 0, poptim carries the time)
     const bool fb = p.usefbcon != 0;
     const bool bw_flow = fb && sl > p.sc_l;  // the backward flow is not needed at the last scale (oflow.cpp:269,291)
+    // one snapshot of the TV path per level: densification and refinement must take the same one even if another thread
+    // changes the knobs in between
+    const bool fused = p.usetvref && p.selectmode != 2 && use_fused(b, g);
     {
       KTimer kt(b, OFDIS_K_PATCH, s);
       DisArgs a = dis_args(p, g, b->nframes);
@@ -935,7 +1006,7 @@ int run_one_level(ofdis_batch* b, int sl, hipStream_t s) {
         d.cg_pweight = dir ? b->pweight : b->pweight_bw;
       }
       if (p.usetvref && dir == 0) {
-        if (use_fused(b, g)) d.flow_aos = b->flow[ii];  // the fused TV path refines the AoS flow in place
+        if (fused) d.flow_aos = b->flow[ii];  // the fused TV path refines the AoS flow in place
         else { d.wx = b->wx; d.wy = b->wy; }
       } else if (p.usetvref) {  // backward flow: parked as AoS until the forward refinement has used the planes
         d.flow_aos = b->flow_bw[ii];
@@ -958,10 +1029,10 @@ int run_one_level(ofdis_batch* b, int sl, hipStream_t s) {
         if (rc) return rc;
       }
     } else if (p.usetvref) {
-      int rc = run_varref(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s);
+      int rc = run_varref(b, g, b->in[0][ii], b->in[3][ii], b->flow[ii], s, fused);
       if (rc) return rc;
       if (bw_flow) {  // VarRefClass on the swapped pair (oflow.cpp:291-294)
-        rc = run_varref_from_aos(b, g, b->in[3][ii], b->in[0][ii], b->flow_bw[ii], s);
+        rc = run_varref_from_aos(b, g, b->in[3][ii], b->in[0][ii], b->flow_bw[ii], s, fused);
         if (rc) return rc;
       }
     }
@@ -1036,7 +1107,7 @@ int ofdis_batch_download(ofdis_batch* b, int frame, float* outflow_host, void* s
   HIPCHK(hipMemcpyAsync(outflow_host, b->flow[0] + (size_t)frame * n, n * sizeof(float), hipMemcpyDeviceToHost,
                         (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-  return xcu_check();
+  return xcu_poll(b);
 }
 
 // Warm start (oflow.cpp:217-220): the coarsest level initialises its patches from this flow exactly as finer levels
@@ -1239,6 +1310,7 @@ int flow_with_ctx(FlowCtx& ctx, const ofdis_params* p, const float* const* im_a,
     else HIPCHK(launch_copy16(lo, c->stage + (lo - b->in_base), bytes, c->s));
     return OFDIS_OK;
   };
+  if ((rc = xcu_begin_pass(b, c->s))) return rc;
   if (p->verbosity == 0 && !tn.flow_whole) {
     for (int l = p->sc_f; l >= p->sc_l && !rc; --l) {
       rc = stage_level(l);
@@ -1253,7 +1325,15 @@ int flow_with_ctx(FlowCtx& ctx, const ofdis_params* p, const float* const* im_a,
   if (use_dma || (c->flow_bytes & 15)) HIPCHK(hipMemcpyAsync(out_stage, b->flow[0], c->flow_bytes, hipMemcpyDeviceToHost, c->s));
   else HIPCHK(launch_copy16(out_stage, b->flow[0], c->flow_bytes, c->s));
   HIPCHK(hipStreamSynchronize(c->s));
-  if ((rc = xcu_check())) return rc;
+  if (xcu_poll(b) != OFDIS_OK) {
+    // a hand-over of the cross-CU fused TV variant was lost (bounded wait): the pyramid is still resident, so the pass is
+    // simply repeated -- this context no longer launches the variant -- and the caller gets the right flow, only later
+    if ((rc = ofdis_batch_run(b, c->s))) return rc;
+    if (use_dma || (c->flow_bytes & 15)) HIPCHK(hipMemcpyAsync(out_stage, b->flow[0], c->flow_bytes, hipMemcpyDeviceToHost, c->s));
+    else HIPCHK(launch_copy16(out_stage, b->flow[0], c->flow_bytes, c->s));
+    HIPCHK(hipStreamSynchronize(c->s));
+    if ((rc = xcu_poll(b))) return rc;
+  }
   memcpy(outflow, out_stage, c->flow_bytes);
   return OFDIS_OK;
 }
@@ -1426,16 +1506,18 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
   if (!rc && want_fused) {
     rc = dalloc(&b, &b.wrec, npx * 2);
     if (!rc) rc = dalloc(&b, &b.uv, npx * 2);
-    if (!rc && nframes <= XCU_MAX_CONTEXT_FRAMES) {
-      b.xbuf_per_frame = (size_t)std::max(0, p->tv_innerit * (level + 1) - 1) * g.w * g.h * 4;
+    if (!rc && nframes <= XCU_MAX_CONTEXT_FRAMES && tuning().fused_xcu_max > 0 && p->tv_innerit * (level + 1) >= 2) {
+      b.xbuf_per_frame = (size_t)(p->tv_innerit * (level + 1) - 1) * g.w * g.h * 4;
       rc = dalloc(&b, &b.xbuf, b.xbuf_per_frame * nframes);
     }
   }
   if (!rc && p->selectmode == 2) rc = dalloc(&b, &b.uu, npx);
   if (!rc) rc = dcommit(&b);
+  b.total_frames = nframes;
   if (!rc && b.xbuf) {
     hipError_t e = hipMemsetAsync(b.xbuf, 0, b.xbuf_per_frame * nframes * sizeof(float), s);
     if (e != hipSuccess) rc = hipfail(e, "hipMemsetAsync");
+    if (!rc) rc = xcu_state_create(&b);
   }
   if (!rc && p->selectmode == 2) {  // one channel: wx = flow, wy = 0
     b.nop = 1;
@@ -1444,16 +1526,19 @@ int ofdis_varref_level(const ofdis_params* p, int level, const float* im_a, cons
     if (e != hipSuccess) rc = hipfail(e, "stereo flow copy");
     if (!rc) rc = run_varref_de(&b, g, im_a, im_b, flow, s);
   } else {
+    // (this context owns both scratch sets, so the path is whatever want_fused decided above, whatever the knobs say now)
     if (!rc && !want_fused) {  // (the fused path starts from the AoS flow)
       TvGeom t{g.w, g.h, g.noc, nframes};
       hipError_t e = b.k->flow_split(t, flow, b.wx, b.wy, s);
       if (e != hipSuccess) rc = hipfail(e, "flow_split");
     }
-    if (!rc) rc = run_varref(&b, g, im_a, im_b, flow, s);
+    if (!rc) rc = run_varref(&b, g, im_a, im_b, flow, s, want_fused);
   }
   hipError_t e = hipStreamSynchronize(s);
   if (!rc && e != hipSuccess) rc = hipfail(e, "sync");
-  if (!rc) rc = xcu_check();
+  // (a lost hand-over of the cross-CU variant: the flow array was refined in place by a kernel that gave up waiting)
+  if (!rc && xcu_poll(&b) != OFDIS_OK) rc = OFDIS_ERR_DEVICE;
+  xcu_state_destroy(&b);
   for (void* d : b.allocs) (void)hipFree(d);
   b.allocs.clear();
   return rc;
@@ -1468,7 +1553,7 @@ int ofdis_get_tuning(ofdis_tuning* out) {
 int ofdis_set_tuning(const ofdis_tuning* in) {
   if (!in) return fail(OFDIS_ERR_INVALID, "tuning is NULL");
   if (in->rgb12_lpp != 64 && in->rgb12_lpp != 32) return fail(OFDIS_ERR_INVALID, "rgb12_lpp must be 64 or 32");
-  if (in->fused_mw_max < 0 || in->fused_strip < 0 || in->prep_band_rows < 0 || in->fused_xcu_max < 0)
+  if (in->fused_mw_max < 0 || in->fused_strip < 0 || in->prep_band_rows < 0 || in->fused_xcu_max < 0 || in->fused_xcu_spin < 0)
     return fail(OFDIS_ERR_INVALID, "negative knob");
   if (in->fused_strip > 64 || in->prep_band_rows > 64)  // (strips index their records with 32-bit byte offsets)
     return fail(OFDIS_ERR_INVALID, "fused_strip / prep_band_rows must be <= 64");
@@ -1501,7 +1586,24 @@ int ofdis_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
 }
 int ofdis_sync(void* stream) {
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-  return OFDIS_OK;
+  // a lost hand-over of the cross-CU fused TV variant belongs to the context that launched it: report it to whoever
+  // synchronises the stream that context's last pass went to (ofdis_batch_status asks one context directly)
+  int rc = OFDIS_OK;
+  std::lock_guard<std::mutex> lock(g_xcu_mutex);
+  for (ofdis_batch* b : g_xcu_contexts) {
+    XcuState* x = b->xcu;
+    if (!x || !x->ran || x->last_stream != (hipStream_t)stream || x->told_sync) continue;
+    if (xcu_poll(b) != OFDIS_OK) {  // (reported here once; ofdis_batch_status / _download keep reporting it until the next pass)
+      x->told_sync = true;
+      rc = OFDIS_ERR_DEVICE;
+    }
+  }
+  return rc;
+}
+
+int ofdis_batch_status(ofdis_batch* b) {
+  if (!b) return fail(OFDIS_ERR_INVALID, "batch is NULL");
+  return xcu_poll(b);
 }
 
 }  // extern "C"

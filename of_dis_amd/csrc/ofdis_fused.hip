@@ -140,11 +140,14 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   const int vo8 = vrec * 32, vo2 = vrec * 8;
   auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
 
-  // this lane's row of the AoS output (multi-wave variants with flow_out; S = 1: strip = frame)
+  // this lane's row of the AoS output (with flow_out; multi-wave variants: S = 1, a strip is a frame; throughput variant:
+  // row j of the strip's FIRST frame -- frame fs of the strip follows fs * npx pixels later)
   const int npx = w * h;
-  float2* const flow_row = MW && a.flow_out
-                               ? reinterpret_cast<float2*>(a.flow_out) + ((size_t)(s0 + fl) * npx + (size_t)j * w)
+  float2* const flow_row = a.flow_out
+                               ? reinterpret_cast<float2*>(a.flow_out) + ((size_t)(s0 + fl) * a.S * npx + (size_t)j * w)
                                : nullptr;
+  // MODE 0 / 1: the wavefront that runs the last fixed-point iteration writes the refined flow itself, in runs (aos_emit)
+  const bool aos_out = MODE != 2 && a.flow_out != nullptr;
 
   FRow W[6];
   FDer D[3];
@@ -165,7 +168,45 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
 #pragma unroll
   for (int s = 0; s < NS; ++s) { ru[s] = rv[s] = ru2[s] = rv2[s] = 0.0f; }
   float ldx = 0.0f, ldy = 0.0f;  // wx, wy of the pixel row being assembled minus those of the row before (set below)
+  // MODE 0 with an AoS output: (wx, wy) of the rows the sweeps are still working on (row rho at index (rho + 3) % 6: written
+  // when the row's system is assembled, read 2 (NS - 1) + 1 steps later when its last sweep finishes) and the refined flow
+  // of the last U finished columns of this lane's image row, written as one run per U steps
+  float2 Wd[6], ob[U];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) Wd[r] = make_float2(0.0f, 0.0f);
+#pragma unroll
+  for (int r = 0; r < U; ++r) ob[r] = make_float2(0.0f, 0.0f);
+  int ox = 0, ooff = 0;  // x and frame offset (pixels) within the strip of the column this lane finishes, last iteration
 
+  // The refined flow itself, uu = wx + du, vv = wy + dv of the LAST fixed-point iteration (refine_variational.cpp:209-221,
+  // 92-99), AoS row-major -- tv_finish and the round trip of du, dv through memory disappear.  `slot` = ob[u], `c` = the
+  // column within the last iteration's pass over the strip this lane finishes in this step (< 0: not there yet).  In a
+  // lane's image row the U columns finished since the last flush are consecutive pixels: one 8 U-byte run instead of U
+  // scattered 8-byte stores (a run that crosses into the strip's next frame, or the ends of the pass, goes pixel by pixel).
+  auto aos_emit = [&](float2& slot, bool flush, const float2& wq, float du, float dv, int c) {
+    slot = make_float2(wq.x + du, wq.y + dv);
+    if (flush) {
+      const int c0 = c - (U - 1);
+      if (row_ok & (c0 >= 0) & (c < rw) & (ox >= U - 1)) {
+        typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+        f4a8* d = reinterpret_cast<f4a8*>(flow_row + ooff + ox - (U - 1));
+#pragma unroll
+        for (int e = 0; e < U / 2; ++e) d[e] = f4a8{ob[2 * e].x, ob[2 * e].y, ob[2 * e + 1].x, ob[2 * e + 1].y};
+      } else if (row_ok & (c >= 0) & (c0 < rw)) {
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+          const int ce = c0 + e;
+          int xe = ox - (U - 1) + e, oe = ooff;
+          if (xe < 0) { xe += w; oe -= npx; }
+          if ((ce >= 0) & (ce < rw)) flow_row[oe + xe] = ob[e];
+        }
+      }
+    }
+    if (c >= 0) {  // x / frame of the next column
+      ++ox;
+      if (ox == w) { ox = 0; ooff += npx; }
+    }
+  };
   auto wrap_row = [&](int r) { r %= rw; return r < 0 ? r + rw : r; };  // diag row of the strip
   auto wrap_col = [&](int c) { c %= w; return c < 0 ? c + w : c; };    // column within a frame
   auto next_row = [&](int r) { return (r + 1 == rw) ? 0 : r + 1; };
@@ -180,7 +221,10 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
     }
   };
   // tau = unwrapped step number of the row (MW only): the LDS ring slot
-  auto load_w = [&](FRow& r, int drow, int tau) {
+  // (MODE 0) zero_uv: this lane's pixel of the row still belongs to the FIRST fixed-point iteration, where du = dv = 0
+  // (image_erase, refine_variational.cpp:186-187): the load gets an offset beyond the resource, for which the hardware
+  // returns +0 without a memory access -- the caller never has to clear the array and iteration 1 reads 8 bytes less per pixel
+  auto load_w = [&](FRow& r, int drow, int tau, bool zero_uv) {
     const int o = drow * h * 8;
     const auto t = __builtin_amdgcn_raw_buffer_load_b64(rsW, vo2, o, 0);
     // (through scalars: __builtin_bit_cast applied directly to a vector element reads element 0, ROCm 7.2)
@@ -189,7 +233,7 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
     if constexpr (MODE == 1) {
       ring_uv(r, tau);
     } else if constexpr (MODE == 0) {
-      const auto q = __builtin_amdgcn_raw_buffer_load_b64(rsU, vo2, o, 0);
+      const auto q = __builtin_amdgcn_raw_buffer_load_b64(rsU, zero_uv ? 0x7ffffff0 : vo2, o, 0);
       const unsigned q0 = q[0], q1 = q[1];
       r.du = asf(q0); r.dv = asf(q1);
     }  // MODE 2: du/dv follow one step later (PDU = 4)
@@ -215,17 +259,14 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   }
   // prologue: W rows -1, 0, 1 (indices 2, 3, 4)
   if (do_p) {
-    load_w(W[2], wrap_row(-1), -1);
-    load_w(W[3], wrap_row(0), 0);
-    if (PDW == 5) load_w(W[4], wrap_row(1), 1);
+    load_w(W[2], wrap_row(-1), -1, true);
+    load_w(W[3], wrap_row(0), 0, true);
+    if (PDW == 5) load_w(W[4], wrap_row(1), 1, true);
     if constexpr (MODE == 2) {  // du/dv rows -1, 0: the loop starts with row t + PDU = 1
       ring_uv(W[2], -1);
       ring_uv(W[3], 0);
     }
   }
-  // du, dv are zero before the first fixed-point iteration (refine_variational.cpp:186-187): the kernel never reads
-  // them during its first pass over the columns, so the caller does not have to clear them
-  if (!MW) W[2].du = W[2].dv = W[3].du = W[3].dv = W[4].du = W[4].dv = 0.0f;
   int rowW = wrap_row(PDW - 3);  // next W row to load (row t+PDW at t = -3)
   int tauW = PDW - 3;            // ... and its unwrapped step number
   int rowD = wrap_row(PDD - 3);  // next D row to load (row t+PDD at t = -3)
@@ -245,14 +286,10 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
       // step t = k0 + u - 3; up to U-1 steps past tend are executed: every pixel is then out of range
       if (do_p) {
         // ---- (1) loads: W row t+5, D row t+3
-        load_w(W[(u + PDW) % 6], rowW, tauW);
+        load_w(W[(u + PDW) % 6], rowW, tauW, first_w);  // (first_w: this lane's column on row t+5 is in the first iteration)
         if constexpr (MODE == 2) ring_uv(W[(u + PDU) % 6], tauW - (PDW - PDU));
         rowW = next_row(rowW);
         ++tauW;
-        if (!MW && first_w) {  // this lane's column on row t+5 still belongs to the first iteration: du = dv = 0 (image_erase)
-          W[(u + PDW) % 6].du = 0.0f;
-          W[(u + PDW) % 6].dv = 0.0f;
-        }
         load_d(D[(u + PDD) % 3], rowD);
         rowD = next_row(rowD);
         // ---- (2) uu, vv of row t+3 (refine_variational.cpp:210-216: uu = wx + du of before this call)
@@ -306,6 +343,7 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           b1 += sh_c * rdx;
           b2 += sh_c * rdy;
           ldx = rdx; ldy = rdy;
+          if (MODE != 2) Wd[(u + 1) % 6] = make_float2(rc.wx, rc.wy);
           b1 -= sv_t * (rc.wx - wx_u);
           b2 -= sv_t * (rc.wy - wy_u);
           b1 += sv_c * (wx_d - rc.wx);
@@ -372,17 +410,21 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           if (MW && it < n_iters - 1) {  // hand the row to the next iteration (lanes outside their columns publish finite
             // values nobody reads as a pixel: the reader's lane is outside its columns at the same step number)
             xring[(it * MW_RING + (taus & (MW_RING - 1))) * 64 + lane] = make_float2(nu[NS - 1], nv[NS - 1]);
-          } else if (MW && a.flow_out) {  // last iteration: the refined flow itself, AoS (one 8-byte store per lane;
-            // a lane's consecutive columns fill its cache lines over the next steps)
+          } else if (MODE == 2 && a.flow_out) {  // last iteration: the refined flow itself, AoS (one 8-byte store per lane;
+            // a lane's consecutive columns fill its cache lines over the next steps; S = 1)
             const auto q = __builtin_amdgcn_raw_buffer_load_b64(rsW, vo2, srow * h * 8, 0);
             const unsigned q0 = q[0], q1 = q[1];
             if (row_ok && ig >= 0 && ig < wtot)
               flow_row[ig] = make_float2(asf(q0) + nu[NS - 1], asf(q1) + nv[NS - 1]);
+          } else if (MODE == 1 && a.flow_out) {  // last iteration's wavefront: the refined flow, in runs
+            aos_emit(ob[u], u == U - 1, Wd[(u - 2 * (NS - 1) + 12) % 6], nu[NS - 1], nv[NS - 1], ig);
           } else if (!MW) {
             // (no branch: a lane outside its rows / columns stores at an offset beyond the resource, which the hardware drops)
             const u32x2 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), __builtin_bit_cast(unsigned, nv[NS - 1])};
-            const bool on = row_ok & (ig >= 0) & (ig < wtot);
+            const int lastc = ig - (wtot - rw);  // >= 0: this column belongs to the last fixed-point iteration
+            const bool on = row_ok & (ig >= 0) & (aos_out ? lastc < 0 : ig < wtot);
             __builtin_amdgcn_raw_buffer_store_b64(v, rsU, on ? vo2 : 0x7ffffff0, srow * h * 8, 0);
+            if (aos_out) aos_emit(ob[u], u == U - 1, Wd[(u - 2 * (NS - 1) + 12) % 6], nu[NS - 1], nv[NS - 1], lastc);
           } else if (row_ok && ig >= 0 && ig < wtot) {
             const u32x2 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), __builtin_bit_cast(unsigned, nv[NS - 1])};
             __builtin_amdgcn_raw_buffer_store_b64(v, rsU, vo2, srow * h * 8, 0);
@@ -430,10 +472,12 @@ int tv_fused_mode(const FusedArgs& a, const FusedXcu* x) {
   const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
   const int groups = (a.t.nframes + 64 / R - 1) / (64 / R);
   const int total = a.total_frames > 0 ? a.total_frames : a.t.nframes;
-  if (x && x->xbuf && a.S == 1 && a.n_inner >= 2 && groups <= x->max_groups && total <= MW_MAX_BATCH_FRAMES) return 3;
+  if (x && x->xbuf && x->err && a.S == 1 && a.n_inner >= 2 && groups <= x->max_groups && total <= MW_MAX_BATCH_FRAMES) return 3;
   const bool mw = a.S == 1 && a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS && groups <= a.mw_max_groups &&
                   (total <= MW_MAX_BATCH_FRAMES || a.mw_max_groups >= (1 << 30));
-  return mw ? ((a.split && a.n_inner <= SP_MAX_ITERS) ? 2 : 1) : 0;
+  if (mw) return (a.split && a.n_inner <= SP_MAX_ITERS) ? 2 : 1;
+  // throughput regime: one wavefront per strip group (0), or -- strips allowed -- a wavefront per fixed-point iteration (1)
+  return (a.tp_pipe && a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS) ? 1 : 0;
 }
 
 hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow, const FusedXcu* x) {
@@ -450,7 +494,7 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow, 
   const bool bright = a.half_delta_over3 != 0.0f;
   // small batches: one workgroup per frame group, one (MODE 1) or two (MODE 2) wavefronts per fixed-point iteration
   const int mode = tv_fused_mode(a, x);
-  if (wrote_flow) *wrote_flow = mode != 0 && a.flow_out != nullptr;
+  if (wrote_flow) *wrote_flow = a.flow_out != nullptr;  // every mapping writes the refined AoS flow itself
   if (mode == 3) return launch_tv_fused_xcu(a, *x, waves, R, s);
 #define OFDIS_FUSED_LAUNCH(NS)                                                                                         \
   if (mode == 2) {                                                                                                     \

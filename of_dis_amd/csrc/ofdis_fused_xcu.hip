@@ -22,7 +22,13 @@ namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled fo
 // Between iterations -- between CUs -- a finished du/dv row travels through global memory as self-validating 16-byte
 // granules {du, tag, dv, tag} written by ONE write-through (sc1) store per lane and read by sc1 loads that bypass the
 // reader's L1 (cdna_hip_programming.md Guideline 16, form R2: the data is the flag; each 8-byte half carries its own tag,
-// so no ordering between stores is needed and nothing depends on dispatch order, timing or workgroup -> XCD placement).
+// so no ordering between stores is needed; correctness does not depend on timing or workgroup -> XCD placement).
+// FORWARD PROGRESS, however, rests on one assumption about the dispatcher: workgroups start in block-index order.  A launch has
+// n_inner x G8 workgroups (up to ~15 k: far more than fit on the chip), a consumer spins while it occupies its CU, and it only
+// ever waits for a LOWER block index -- so it makes progress exactly when lower indices were dispatched before it.  That is
+// how the hardware dispatcher behaves today (also on a CU-masked stream, tests/test_gpu_xcu.py), not an API guarantee: the
+// wait is therefore bounded, and a context that ever sees it expire reports the pass as failed and stops using this variant
+// (ofdis_capi.hip: XcuState).
 // Only the fetch wave touches granules: memory returns in order, so in a wavefront that also computes, every nearer load
 // (and the compiler's conservative wait counts around the re-read loop) exposed the 1.2 us hand-off latency at every
 // step.  The fetch wave takes one row per step, requested XC_AHEAD steps earlier, checks the tag of every existing pixel -- when
@@ -32,8 +38,9 @@ namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled fo
 // Tag 0 = not yet written: the array is zeroed when it is allocated, and the fetch wave puts every granule it has taken
 // back to zero, so a launch leaves the array as it found it (no memset per launch).  Block index = iteration * G8 +
 // group with G8 a multiple of 8: an iteration only waits for a LOWER block index, and the iterations of a group share an
-// XCD under the observed round-robin placement (speed only).  A wait that exceeds XC_SPIN_LIMIT re-reads (seconds) sets
-// the caller's error word and the wavefront carries on without waiting: the call fails, nothing hangs.
+// XCD under the observed round-robin placement (speed only).  A wait that exceeds the spin limit (default XC_SPIN_LIMIT
+// re-reads of ~1 us: seconds; ofdis_tuning::fused_xcu_spin) sets the context's error word and the wavefront carries on
+// without waiting: the pass is reported as failed, nothing hangs.
 constexpr int XC_AHEAD = 3;  // steps a row is requested before the fetch wave takes it (= requests in flight; 3 x 0.4 us = the latency)
 constexpr int XC_LEAD = 1;   // rows the fetch wave lets the predecessor gain, beyond its requests, before it (re)starts
 constexpr int XC_SD = 1;     // rows between consecutive SOR sweeps in the solve wave
@@ -44,7 +51,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NS, bool BRIGHT>
 __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, const int R, const int G8, float* const xbuf,
-                                                            int* const err) {
+                                                            int* const err, const unsigned spin_limit) {
   constexpr int U = 6;
   constexpr int PDW = 5, PDD = 3, PDU = 3;  // (du/dv of row t+3 are read from the ring in the step that first uses them)
   static_assert(XC_SD * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
@@ -262,9 +269,9 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
         u32x4 g = request(drow);
         unsigned spins = 0;
         while (!dead && __builtin_amdgcn_ballot_w64(!ready(g, inr)) != 0) {
-          if (++spins >= XC_SPIN_LIMIT) {
+          if (++spins >= spin_limit) {
             dead = true;
-            if (err && lane == 0) atomicExch(err, 1);
+            if (lane == 0) atomicExch(err, 1);
             break;
           }
           __builtin_amdgcn_s_sleep(2);
@@ -436,12 +443,14 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
 
 hipError_t launch_tv_fused_xcu(const FusedArgs& a, const FusedXcu& x, int waves, int R, hipStream_t s) {
   const int G8 = (waves + 7) & ~7;  // workgroups per fixed-point iteration
+  if (!x.xbuf || !x.err) return hipErrorInvalidValue;  // never without an error word: a lost hand-over must be reportable
+  const unsigned spin = x.spin_limit ? x.spin_limit : XC_SPIN_LIMIT;
   const bool bright = a.half_delta_over3 != 0.0f;
 #define OFDIS_XCU_LAUNCH(NS)                                                                                           \
   if (bright)                                                                                                          \
-    hipLaunchKernelGGL((tv_fused_xcu_kernel<NS, true>), dim3(a.n_inner * G8), dim3(256), 0, s, a, R, G8, x.xbuf, x.err); \
+    hipLaunchKernelGGL((tv_fused_xcu_kernel<NS, true>), dim3(a.n_inner * G8), dim3(256), 0, s, a, R, G8, x.xbuf, x.err, spin); \
   else                                                                                                                 \
-    hipLaunchKernelGGL((tv_fused_xcu_kernel<NS, false>), dim3(a.n_inner * G8), dim3(256), 0, s, a, R, G8, x.xbuf, x.err)
+    hipLaunchKernelGGL((tv_fused_xcu_kernel<NS, false>), dim3(a.n_inner * G8), dim3(256), 0, s, a, R, G8, x.xbuf, x.err, spin)
   switch (a.iterations) {
     case 1: OFDIS_XCU_LAUNCH(1); break;
     case 2: OFDIS_XCU_LAUNCH(2); break;

@@ -126,13 +126,19 @@ struct FusedArgs {
   float* flow_out;
   int mw_max_groups;  // frame groups (workgroups) up to which the multi-wave variants are launched (0 = never)
   int split;          // 0 = never the split (producer / solver wavefronts) variant of the multi-wave kernel
+  int tp_pipe;        // 1: THROUGHPUT regime on the iteration-pipelined mapping (MODE 1) with strips of S frames: a workgroup of
+                      // n_inner wavefronts per strip group, du / dv from iteration to iteration through LDS, the derivative
+                      // records of a row read by n_inner wavefronts of ONE compute unit within a few steps (one HBM read, the
+                      // others hit the L2) -- 48 instead of 56 n_inner bytes of HBM traffic per pixel and level
 };
 // cross-CU variant (one workgroup per fixed-point iteration of a frame group), kept out of FusedArgs so that the other
 // variants' kernel arguments -- and register allocation -- stay what they were
 struct FusedXcu {
   float* xbuf = nullptr;   // [n_inner - 1][nframes][w*h] granules of 4 floats {du, tag, dv, tag}; null: never
   int max_groups = 0;      // frame groups up to which the variant is launched (0 = never)
-  int* err = nullptr;      // optional device-visible word, set to 1 when a hand-over row never arrived (results invalid)
+  int* err = nullptr;      // device-visible word, set to 1 when a hand-over row never arrived (results invalid); the variant
+                           // is only launched with one
+  unsigned spin_limit = 0; // re-reads of one row (~1 us each) before a workgroup gives up; 0 = the default (2^22, seconds)
 };
 
 

@@ -41,15 +41,19 @@ def orc():
     return o
 
 
-@pytest.fixture(params=["single-wave", "multi-wave", "multi-wave-split", "cross-cu"])
+@pytest.fixture(params=["single-wave", "multi-wave", "multi-wave-split", "cross-cu", "pipelined-strips"])
 def tv_variant(gpu, request):
-    """The four mappings of the fused TV kernel (ofdis_fused.hip): one wavefront walking all fixed-point iterations of a
+    """The mappings of the fused TV kernel (ofdis_fused.hip): one wavefront walking all fixed-point iterations of a
     frame group; a workgroup with one wavefront per iteration; the same with each iteration divided between a producer and
-    a solver wavefront (up to 6 iterations); one workgroup of three wavefronts per iteration, the iterations of a group on
+    a solver wavefront (up to 6 iterations); one workgroup of four wavefronts per iteration, the iterations of a group on
     different CUs with the du/dv rows handed over through global memory (what the launcher picks by itself for these
-    test sizes).  Bit-identical results are required of all."""
-    old = gpu.set_tuning(fused_mw_max=0 if request.param == "single-wave" else 1 << 30,
+    test sizes); and the throughput form of the second one: a wavefront per iteration over STRIPS of two frames (what large
+    batches run).  Bit-identical results are required of all (exact contract)."""
+    small = request.param in ("multi-wave", "multi-wave-split", "cross-cu")
+    old = gpu.set_tuning(fused_mw_max=(1 << 30) if small else 0,
                          fused_split=1 if request.param == "multi-wave-split" else 0,
-                         fused_xcu_max=(1 << 30) if request.param == "cross-cu" else 0)
+                         fused_xcu_max=(1 << 30) if request.param == "cross-cu" else 0,
+                         fused_tp_pipe=1 if request.param == "pipelined-strips" else 0,
+                         fused_strip=2 if request.param == "pipelined-strips" else 0)
     yield request.param
     gpu.restore_tuning(old)

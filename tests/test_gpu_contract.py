@@ -7,9 +7,15 @@ bit-exact tests use), on the full-resolution flow as it would be written to the 
 
     mean EPE < 1e-4 px   and   max EPE < 1e-3 px
 
-on BASELINE configs[1], configs[2], the 640x480 case, the block-world family and the 40 random configurations of
-test_gpu_flow.py.  The same statistics of the EXACT contract against the same plain reference are printed beside them
-(-s shows them; they also land in the assertion message): they are what the summation order alone costs.
+on BASELINE configs[1], configs[2], the 640x480 case and the 40 random configurations of test_gpu_flow.py.  The same
+statistics of the EXACT contract against the same plain reference are printed beside them (-s shows them; they also land
+in the assertion message): they are what the summation order alone costs.
+
+The block-world family (hard-edged flat rectangles: near-singular Hessians, outlier resets) is chaotic for ANY rounding
+change: the exact contract itself -- bit-identical to the reference compiled with the defined summation order -- sits at
+mean 2e-2 px / max 1.6-3.7 px from the reference compiled with sequential sums.  No arithmetic can meet the bar there, so
+that family asserts what can be asserted: the fused contract is no further from the plain reference than 1.5 x the exact
+contract is (and both numbers are printed).
 """
 import numpy as np
 import pytest
@@ -52,7 +58,7 @@ def _both_contracts(gpu, run):
     return ex, fu
 
 
-def _check(orc, p, w, h, ref, ex, fu, what):
+def _check(orc, p, w, h, ref, ex, fu, what, chaotic=False):
     rf = _full_res(orc, p, ref, w, h)
     se = oracle.epe_stats(_full_res(orc, p, ex, w, h), rf)
     sf = oracle.epe_stats(_full_res(orc, p, fu, w, h), rf)
@@ -61,7 +67,10 @@ def _check(orc, p, w, h, ref, ex, fu, what):
     print(msg)
     assert np.isfinite(fu).all(), msg
     assert not np.array_equal(ex, fu) or np.array_equal(ex, ref), msg + " (the fused contract gave the exact contract's bits?)"
-    assert sf[0] < MEAN_BAR and sf[1] < MAX_BAR, msg
+    if chaotic:  # (module docstring) the reference's own two builds are this far apart: compare with that
+        assert sf[0] < max(MEAN_BAR, 1.5 * se[0]) and sf[1] < max(MAX_BAR, 1.5 * se[1]) and sf[2] < max(1e-3, 1.5 * se[2]), msg
+    else:
+        assert sf[0] < MEAN_BAR and sf[1] < MAX_BAR, msg
     return se, sf
 
 
@@ -117,7 +126,7 @@ def test_fused_contract_block_world(gpu, orc, size, channels, opp, seed):
     pa, pb = O.build_pyramid(p, ia), O.build_pyramid(p, ib)
     ref = _plain_ref("int" if channels == 1 else "rgb").flow(p, pa[0], pa[1], pa[2], pb[0])
     ex, fu = _both_contracts(gpu, lambda: gpu.flow(p, pa[0], pa[1], pa[2], pb[0]))
-    _check(orc, p, w, h, ref, ex, fu, f"block world {size} noc={channels}")
+    _check(orc, p, w, h, ref, ex, fu, f"block world {size} noc={channels}", chaotic=True)
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -177,7 +186,9 @@ def test_fused_contract_mappings_agree(gpu, orc):
     old = gpu.set_tuning(contract=1)
     outs = {}
     try:
-        for name, knobs in {"throughput": dict(fused_mw_max=0, fused_xcu_max=0), "multi-wave": dict(fused_mw_max=1 << 30, fused_split=0, fused_xcu_max=0),
+        for name, knobs in {"throughput": dict(fused_mw_max=0, fused_xcu_max=0, fused_tp_pipe=0),
+                            "pipelined-strips": dict(fused_mw_max=0, fused_xcu_max=0, fused_tp_pipe=1, fused_strip=2),
+                            "multi-wave": dict(fused_mw_max=1 << 30, fused_split=0, fused_xcu_max=0),
                             "split": dict(fused_mw_max=1 << 30, fused_split=1, fused_xcu_max=0), "cross-cu": dict(fused_xcu_max=1 << 30),
                             "unfused": dict(fused_tv=0), "generic-patch": dict(gray8=0)}.items():
             o2 = gpu.set_tuning(**knobs)

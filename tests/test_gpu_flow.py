@@ -520,9 +520,10 @@ def test_fallback_kernels_at_the_benchmark_geometry(gpu, orc, knob):
         gpu.restore_tuning(old)
 
 
+@pytest.mark.parametrize("pipe", [0, 1])
 @pytest.mark.parametrize("nfr,strip", [(8, 2), (16, 4), (24, 8), (6, 2), (7, 2)])
 @pytest.mark.parametrize("size", [(256, 128), (1024, 436)])
-def test_fused_tv_strips(gpu, orc, nfr, strip, size):
+def test_fused_tv_strips(gpu, orc, nfr, strip, size, pipe):
     """Strips: S frames side by side as one image of S*w columns for the throughput fused TV kernel (the fill / drain of
     the skewed sweep once per strip).  A frame's bits must not depend on S, on its position in the strip, or on the
     frames it shares the strip with; a frame count S does not divide falls back to S = 1."""
@@ -530,7 +531,7 @@ def test_fused_tv_strips(gpu, orc, nfr, strip, size):
     cases = [synth_case(w, h, 2300 + k, 1, 2, 1) for k in range(3)]
     p = cases[0][0]
     refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
-    old = gpu.set_tuning(fused_mw_max=0, fused_xcu_max=0, fused_strip=strip)
+    old = gpu.set_tuning(fused_mw_max=0, fused_xcu_max=0, fused_strip=strip, fused_tp_pipe=pipe)
     try:
         b = gpu.Batch(p, nfr)
         for l in range(p.sc_l, p.sc_f + 1):               # slot s holds frame (s * s + s // 3) % 3: neighbours vary
@@ -678,7 +679,8 @@ def test_fused_tv_strips_odd_geometries(gpu, orc, size, level, nfr, strip):
         ia, ib, _ = gen_synth.make_pair(w, h, 2500 + k)
         cases.append((O.build_pyramid(p, ia), O.build_pyramid(p, ib)))
     refs = [orc.flow(p, pa[0], pa[1], pa[2], pb[0]) for pa, pb in cases]
-    for variant in ({"fused_mw_max": 0, "fused_xcu_max": 0, "fused_strip": strip},
+    for variant in ({"fused_mw_max": 0, "fused_xcu_max": 0, "fused_strip": strip, "fused_tp_pipe": 0},
+                    {"fused_mw_max": 0, "fused_xcu_max": 0, "fused_strip": strip, "fused_tp_pipe": 1},
                     {"fused_mw_max": 1 << 30, "fused_xcu_max": 0, "fused_strip": 0},
                     {"fused_xcu_max": 1 << 30, "fused_strip": 0}):
         old = gpu.set_tuning(**variant)

@@ -1,0 +1,203 @@
+"""-m gpu: the cross-CU variant of the fused TV kernel (ofdis_fused_xcu.hip) must NEVER return a wrong flow with status 0.
+
+Its workgroups hand du/dv rows to each other through global memory and wait -- bounded -- for workgroups with a lower
+block index.  These tests force the wait to expire (ofdis_tuning.fused_xcu_spin = 1: the first re-read gives up), run the
+variant on a CU-masked stream (8 compute units) and beside a second process that keeps the device busy, and check every
+synchronising route: ofdis_sync, ofdis_batch_status, ofdis_batch_download, ofdis_flow, the run_OF_INT binary.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from common import assert_bits_equal, synth_case
+
+pytestmark = pytest.mark.gpu
+ERR_DEVICE = -3
+
+
+def _fill(b, cases, n):
+    for slot in range(n):
+        c = cases[slot % len(cases)]
+        b.upload(slot, c[1][0], c[1][1], c[1][2], c[2][0])
+
+
+@pytest.fixture
+def cases(orc):
+    cs = [synth_case(1024, 436, 2700 + k, 1, 2, 1) for k in range(2)]
+    refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cs]
+    return cs, refs
+
+
+def test_lost_handover_is_reported_by_every_synchronising_route(gpu, cases):
+    """fused_xcu_spin = 1: every workgroup that has to wait gives up at once.  The pass must be reported as failed by
+    ofdis_sync (on the stream of the pass), ofdis_batch_status and ofdis_batch_download; the failure belongs to THAT context
+    (a second context run in between is unaffected); the next pass of the context no longer uses the variant and is exact."""
+    cs, refs = cases
+    p = cs[0][0]
+    L = gpu.lib()
+    old = gpu.set_tuning(fused_xcu_max=1 << 30, fused_xcu_spin=1)
+    try:
+        b = gpu.Batch(p, 6)
+        _fill(b, cs, 6)
+        gpu.check(L.ofdis_sync(None))
+        b.run()
+        rc_sync = L.ofdis_sync(None)
+        assert rc_sync == ERR_DEVICE, "a lost hand-over must make ofdis_sync fail"
+        assert b"hand-over" in L.ofdis_last_error()
+        assert b.status() == ERR_DEVICE, "the failure stays with the context until its next pass"
+        with pytest.raises(gpu.OfdisError):
+            b.download(0)
+        # another context, default spin limit: unaffected by the first one's failure
+        gpu.set_tuning(fused_xcu_spin=0)
+        other = gpu.Batch(p, 2)
+        _fill(other, cs, 2)
+        other.run()
+        assert L.ofdis_sync(None) == 0, "ofdis_sync reports a failed pass once; the context itself keeps saying so"
+        assert b.status() == ERR_DEVICE and other.status() == 0
+        assert_bits_equal(other.download(1), refs[1], "an unrelated context")
+        other.close()
+        # the failed context again: the variant is off for it, the pass is exact, every route reports success
+        b.run()
+        assert L.ofdis_sync(None) == 0
+        assert b.status() == 0
+        out = b.download_all()
+        for slot in range(6):
+            assert_bits_equal(out[slot], refs[slot % 2], f"second pass, slot {slot}")
+        b.close()
+    finally:
+        gpu.restore_tuning(old)
+
+
+def test_dropin_repeats_the_pass_itself(gpu, cases):
+    """ofdis_flow is synchronous: when the pass reports a lost hand-over it repeats it (without the variant) and returns the
+    right flow with status 0."""
+    cs, refs = cases
+    old = gpu.set_tuning(fused_xcu_max=1 << 30, fused_xcu_spin=1)
+    try:
+        for rep in range(3):
+            for k, c in enumerate(cs):
+                assert_bits_equal(gpu.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]), refs[k], f"ofdis_flow, call {rep}, pair {k}")
+    finally:
+        gpu.restore_tuning(old)
+
+
+def test_cli_never_writes_a_wrong_flo(gpu, tmp_path):
+    """run_OF_INT takes the device-pointer route (ofdis_batch_run -> ofdis_batch_upsample -> ofdis_sync -> copy).  With the
+    wait forced to expire (OFDIS_FUSED_XCU_SPIN=1) it must notice, repeat the pass and write the same bytes as a normal run."""
+    import gen_synth
+    from of_dis_amd import build
+    ia, ib, _ = gen_synth.make_pair(1024, 436, 99)
+    fa, fb = str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm")
+    gen_synth.write_pgm(fa, ia)
+    gen_synth.write_pgm(fb, ib)
+    exe = os.path.join(os.path.dirname(build.lib_path()), "run_OF_INT")
+    outs = []
+    for name, env in (("normal", {}), ("forced", {"OFDIS_FUSED_XCU_SPIN": "1", "OFDIS_FUSED_XCU_MAX": "1073741824"})):
+        out = str(tmp_path / f"{name}.flo")
+        r = subprocess.run([exe, fa, fb, out, "2"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (name, r.stdout, r.stderr)
+        if name == "forced":
+            assert "hand-over" in r.stderr, "the binary must have noticed the failed pass"
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1], "the forced-failure run wrote another .flo than the normal run"
+
+
+def _hip():
+    for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            return C.CDLL(name)
+        except OSError:
+            continue
+    pytest.skip("libamdhip64.so not loadable")
+
+
+@pytest.mark.parametrize("nfr", [1, 768])
+def test_on_a_cu_masked_stream(gpu, cases, nfr):
+    """The variant's forward progress rests on workgroups starting in block-index order while far more workgroups are
+    launched than fit on the chip.  A stream restricted to 8 compute units (hipExtStreamCreateWithCUMask) makes that as tight
+    as it gets: up to 3072 workgroups per launch on 8 CUs.  Either the bits are right or the pass reports itself as failed."""
+    cs, refs = cases
+    p = cs[0][0]
+    hip = _hip()
+    stream = C.c_void_p()
+    words = 8
+    mask = (C.c_uint32 * words)(*([0xFF] + [0] * (words - 1)))
+    hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+    if hip.hipExtStreamCreateWithCUMask(C.byref(stream), words, mask) != 0:
+        pytest.skip("hipExtStreamCreateWithCUMask failed")
+    L = gpu.lib()
+    old = gpu.set_tuning(fused_xcu_max=1 << 30)
+    try:
+        b = gpu.Batch(p, nfr)
+        _fill(b, cs, nfr)
+        gpu.check(L.ofdis_sync(None))
+        for rep in range(3):
+            b.run(stream)
+            rc = L.ofdis_sync(stream)
+            assert rc in (0, ERR_DEVICE)
+            assert (b.status() == 0) == (rc == 0)
+            if rc == 0:
+                out = b.download_all()
+                for slot in sorted({0, nfr // 2, nfr - 1}):
+                    assert_bits_equal(out[slot], refs[slot % 2], f"{nfr} pairs on 8 CUs, pass {rep}, slot {slot}")
+            else:  # reported: the repeated pass (variant off) must be exact
+                b.run(stream)
+                assert L.ofdis_sync(stream) == 0
+                assert_bits_equal(b.download(0), refs[0], "pass repeated after a reported failure")
+        b.close()
+    finally:
+        gpu.restore_tuning(old)
+        hip.hipStreamDestroy.argtypes = [C.c_void_p]
+        hip.hipStreamDestroy(stream)
+
+
+_LOAD = r"""
+import sys, time
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tools"); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+from of_dis_amd import capi
+from common import synth_case
+c = synth_case(1024, 436, 2700, 1, 2, 1)
+p = c[0]
+b = capi.Batch(p, 3000)
+for l in range(p.sc_l, p.sc_f + 1):
+    for kind in range(4):
+        plane = c[1][kind][l] if kind < 3 else c[2][0][l]
+        b.set_input(l, kind, np.broadcast_to(plane, (3000,) + plane.shape))
+print("ready", flush=True)
+t0 = time.time()
+while time.time() - t0 < {seconds}:
+    b.run()
+    capi.check(capi.lib().ofdis_sync(None))
+"""
+
+
+def test_beside_a_second_process(gpu, cases):
+    """A second PROCESS keeps every CU busy with 3000-pair passes of the throughput kernels while this one pushes single pairs
+    through ofdis_flow and runs a 768-pair context (cross-CU variant): right bits, pass after pass, or a reported failure."""
+    cs, refs = cases
+    p = cs[0][0]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    load = subprocess.Popen([sys.executable, "-c", _LOAD.format(root=root, seconds=25)], stdout=subprocess.PIPE, text=True)
+    try:
+        assert load.stdout.readline().strip() == "ready"
+        L = gpu.lib()
+        b = gpu.Batch(p, 768)
+        _fill(b, cs, 768)
+        for rep in range(10):
+            for k, c in enumerate(cs):
+                assert_bits_equal(gpu.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]), refs[k], f"ofdis_flow call {rep}, pair {k}")
+            b.run()
+            rc = L.ofdis_sync(None)
+            assert rc in (0, ERR_DEVICE)
+            if rc == 0:
+                for slot in (0, 383, 767):
+                    assert_bits_equal(b.download(slot), refs[slot % 2], f"768-pair context, pass {rep}, slot {slot}")
+        b.close()
+    finally:
+        load.kill()
+        load.wait()
