@@ -211,9 +211,10 @@ typedef struct ofdis_tuning {
   int flow_whole;     /* 1: ofdis_flow uploads the whole pyramid before the first launch                OFDIS_FLOW_WHOLE */
   int fused_xcu_max;  /* frame groups up to which the fused TV kernel runs every fixed-point iteration of a group as its
                        * own workgroup on its own CU (contexts of <= 768 frames; 0 = never)        OFDIS_FUSED_XCU_MAX */
-  int fused_tp_pipe;  /* 1: large batches run the fused TV kernel with one wavefront per fixed-point iteration and strip (the
-                       * iterations of a strip on one compute unit share the derivative records through the L2); 0: one
-                       * wavefront per strip walks all iterations                              OFDIS_FUSED_NO_TP_PIPE -> 0 */
+  int fused_tp_pipe;  /* large batches: the fused TV kernel with one wavefront per fixed-point iteration and strip (the
+                       * iterations of a strip on one compute unit share the derivative records through the L2) instead of
+                       * one wavefront per strip walking all iterations.  0 = never, 1 = where it is faster (levels of
+                       * more than 32 rows under the fused contract), 2 = always                    OFDIS_FUSED_TP_PIPE */
   int fused_xcu_spin; /* re-reads (~1 us each) a workgroup of that variant waits for a hand-over row before it reports the
                        * pass as failed; 0 = the default, 2^22 (seconds)                          OFDIS_FUSED_XCU_SPIN */
   int contract;       /* ARITHMETIC CONTRACT -- the one knob that changes bits.  0 = exact (default): the contract at the

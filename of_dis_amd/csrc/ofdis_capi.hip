@@ -86,7 +86,7 @@ void tuning_init_locked() {
   g_tuning.flow_dma = on("OFDIS_FLOW_DMA");
   g_tuning.flow_whole = on("OFDIS_FLOW_WHOLE");
   g_tuning.fused_xcu_max = std::max(0, num("OFDIS_FUSED_XCU_MAX", 768));
-  g_tuning.fused_tp_pipe = !on("OFDIS_FUSED_NO_TP_PIPE");
+  g_tuning.fused_tp_pipe = std::max(0, std::min(2, num("OFDIS_FUSED_TP_PIPE", 1)));
   g_tuning.fused_xcu_spin = std::max(0, num("OFDIS_FUSED_XCU_SPIN", 0));
   {  // arithmetic contract: "fused" / "1" = the tolerance contract, anything else (or unset) = exact
     const char* e = getenv("OFDIS_CONTRACT");
@@ -456,7 +456,13 @@ int run_varref(ofdis_batch* b, const LevelGeom& g, const float* im_a, const floa
     const FusedXcu fx{xcu_ok ? b->xbuf : nullptr, xcu_ok ? tn.fused_xcu_max : 0, xcu_ok ? b->xcu->dev : nullptr,
                       tn.fused_xcu_spin > 0 ? (unsigned)tn.fused_xcu_spin : 0u};
     if (K.tv_fused_mode(fa, &fx) == 0) {  // not the small-batch regime: strips, on one of the two throughput mappings
-      fa.tp_pipe = tn.fused_tp_pipe;
+      // which of the two: measured per 16384 pairs (profiles/README.md round 4), levels 3 / 4 / 5 of operating point 2:
+      //   fused contract  one wavefront per strip 5.47 / 1.75 / 0.44 ms (HBM-bound: 56 B per pixel and iteration),
+      //                   a wavefront per iteration, S = 8: 4.41 / 2.04 / 0.57 (issue-bound, 1/5 of the traffic)
+      //   exact contract  9.06 against 11.9 ms in total (370 instead of 220 instructions per step: issue-bound either way,
+      //                   and the pipelined form executes more wavefront-steps)
+      // so: levels of more than 32 rows (one strip per wavefront) under the fused contract; fused_tp_pipe = 2 forces it
+      fa.tp_pipe = tn.fused_tp_pipe >= 2 || (tn.fused_tp_pipe == 1 && b->contract == 1 && g.h > 32);
       fa.S = strip_length(b, g, tn, K.tv_fused_mode(fa, &fx) == 1);
     }
     {  // image_warp + get_derivatives (refine_variational.cpp:189-190): one kernel, records out
@@ -1557,6 +1563,7 @@ int ofdis_set_tuning(const ofdis_tuning* in) {
     return fail(OFDIS_ERR_INVALID, "negative knob");
   if (in->fused_strip > 64 || in->prep_band_rows > 64)  // (strips index their records with 32-bit byte offsets)
     return fail(OFDIS_ERR_INVALID, "fused_strip / prep_band_rows must be <= 64");
+  if (in->fused_tp_pipe < 0 || in->fused_tp_pipe > 2) return fail(OFDIS_ERR_INVALID, "fused_tp_pipe must be 0, 1 or 2");
   if (in->contract != 0 && in->contract != 1) return fail(OFDIS_ERR_INVALID, "contract must be 0 (exact) or 1 (fused)");
   ofdis::tuning();  // initialise from the environment first
   std::lock_guard<std::mutex> lock(ofdis::g_tuning_mutex);

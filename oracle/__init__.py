@@ -309,6 +309,26 @@ def have_ref(kind="int", wave64=False):
     return os.path.exists(os.path.join(_HERE, "_ref", fn)) or os.path.isdir("/root/reference")
 
 
+def ref_expected():
+    """The compiled reference is EXPECTED on this machine: its sources are here (/root/reference) or a build of it was
+    shipped with the snapshot (oracle/_ref/ holds libraries).  Only when neither is the case may a test skip its comparison
+    against the reference build."""
+    d = os.path.join(_HERE, "_ref")
+    return os.path.isdir("/root/reference") or (os.path.isdir(d) and any(f.endswith(".so") for f in os.listdir(d)))
+
+
+def need_ref(kind="int", wave64=False):
+    """The compiled reference for a parity test: the library, or -- only on a machine that has neither the reference sources
+    nor a shipped build -- None after saying what is being skipped.  A missing library where one is expected is a FAILURE."""
+    if have_ref(kind, wave64):
+        return ref(kind, wave64)
+    name = f"libofdis_ref_{kind}{'_w64' if wave64 else ''}.so"
+    if ref_expected():
+        raise AssertionError(f"oracle/_ref/{name} is missing although the reference build is expected here (run `make -C oracle`)")
+    print(f"[oracle] comparison against the compiled reference ({name}) SKIPPED: neither /root/reference nor oracle/_ref exists")
+    return None
+
+
 def epe_stats(a, b):
     """mean / max end-point error and fraction of pixels above 1e-3 px between two (h,w,2) flows."""
     d = np.sqrt(((a.astype(np.float64) - b.astype(np.float64)) ** 2).sum(-1))

@@ -53,7 +53,7 @@ def tv_variant(gpu, request):
     old = gpu.set_tuning(fused_mw_max=(1 << 30) if small else 0,
                          fused_split=1 if request.param == "multi-wave-split" else 0,
                          fused_xcu_max=(1 << 30) if request.param == "cross-cu" else 0,
-                         fused_tp_pipe=1 if request.param == "pipelined-strips" else 0,
+                         fused_tp_pipe=2 if request.param == "pipelined-strips" else 0,
                          fused_strip=2 if request.param == "pipelined-strips" else 0)
     yield request.param
     gpu.restore_tuning(old)

@@ -25,11 +25,13 @@ def test_flow_dropin_bit_exact(gpu, orc, size, opp, tv):
     ref = orc.flow(p, pa[0], pa[1], pa[2], pb[0])
     got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
     assert_bits_equal(got, ref, "flow vs restatement (wave64 order)")
-    if oracle.have_ref("int", True):
-        r = oracle.ref("int", True).flow(p, pa[0], pa[1], pa[2], pb[0])
+    R = oracle.need_ref("int", True)
+    if R is not None:
+        r = R.flow(p, pa[0], pa[1], pa[2], pb[0])
         assert_bits_equal(got, r, "flow vs reference sources (wave64 shim order)")
-    if oracle.have_ref("int", False):
-        r = oracle.ref("int", False).flow(p, pa[0], pa[1], pa[2], pb[0])
+    R = oracle.need_ref("int", False)
+    if R is not None:
+        r = R.flow(p, pa[0], pa[1], pa[2], pb[0])
         mean, mx, frac = oracle.epe_stats(got, r)
         # north_star tolerance: EPE < 1e-3 px vs the reference CPU path (here: its sequential-sum build),
         # measured at the computed level; the .flo is this flow times 2^sc_l, so scale the bound.
@@ -148,8 +150,9 @@ def test_initflow_warm_start(gpu, orc):
     assert not np.array_equal(ref, cold)
     got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0], initflow=init)
     assert_bits_equal(got, ref, "ofdis_flow with initflow vs restatement")
-    if oracle.have_ref("int", True):
-        r = oracle.ref("int", True).flow(p, pa[0], pa[1], pa[2], pb[0], initflow=init)
+    R = oracle.need_ref("int", True)
+    if R is not None:
+        r = R.flow(p, pa[0], pa[1], pa[2], pb[0], initflow=init)
         assert_bits_equal(got, r, "ofdis_flow with initflow vs reference sources")
     b = gpu.Batch(p, 2)
     for k in range(2):
@@ -180,11 +183,11 @@ def test_forward_backward_consistency(gpu, orc, size, noc, opp, tv):
     The checker is the reference itself (oracle/_ref, built from the unmodified sources with the defined summation
     order); the C restatement does not cover this mode."""
     kind = "int" if noc == 1 else "rgb"
-    if not oracle.have_ref(kind, True):
-        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    R = oracle.need_ref(kind, True)
+    if R is None:
+        pytest.skip("comparison against the compiled reference skipped: neither /root/reference nor oracle/_ref exists here")
     p, pa, pb, _, _ = synth_case(size[0], size[1], 2024, noc, opp, tv)
     p = p.copy(usefbcon=1)
-    R = oracle.ref(kind, True)
     ref = R.flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
     plain = R.flow(p.copy(usefbcon=0), pa[0], pa[1], pa[2], pb[0])
     assert not np.array_equal(ref, plain)
@@ -265,8 +268,14 @@ def test_rgb_flow_bit_exact(gpu, orc):
     ref = orc.flow(p, pa[0], pa[1], pa[2], pb[0])
     got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
     assert_bits_equal(got, ref, "rgb flow")
-    if oracle.have_ref("rgb", True):
-        assert_bits_equal(got, oracle.ref("rgb", True).flow(p, pa[0], pa[1], pa[2], pb[0]), "rgb flow vs reference")
+    R = oracle.need_ref("rgb", True)
+    if R is not None:
+        assert_bits_equal(got, R.flow(p, pa[0], pa[1], pa[2], pb[0]), "rgb flow vs reference")
+    R = oracle.need_ref("rgb", False)  # the PLAIN RGB reference build (sequential sums): the north star's tolerance
+    if R is not None:
+        full = lambda f: orc.upsample_crop(p, f, 320, 240)  # noqa: E731
+        mean, mx, frac = oracle.epe_stats(full(got), full(R.flow(p, pa[0], pa[1], pa[2], pb[0])))
+        assert mean < 1e-4 and mx < 1e-3, (mean, mx, frac)
 
 
 @pytest.mark.parametrize("size,cost", [((320, 240), 1), ((320, 240), 0), ((203, 131), 1)])
@@ -330,8 +339,9 @@ def test_baseline_config4_rgb_1080p(gpu, orc):
     ref = orc.flow(p, pa[0], pa[1], pa[2], pb[0])
     got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
     assert_bits_equal(got, ref, "config 4")
-    if oracle.have_ref("rgb", True):  # ... and directly against the reference sources compiled in place (defined-order build)
-        assert_bits_equal(got, oracle.ref("rgb", True).flow(p, pa[0], pa[1], pa[2], pb[0]), "config 4 vs the reference build")
+    R = oracle.need_ref("rgb", True)  # ... and directly against the reference sources compiled in place (defined-order build)
+    if R is not None:
+        assert_bits_equal(got, R.flow(p, pa[0], pa[1], pa[2], pb[0]), "config 4 vs the reference build")
 
 
 def _random_config(rng):
@@ -386,8 +396,8 @@ def test_random_configurations_modes(gpu, seed):
     over["usefbcon"] = 1 if (not stereo or seed % 4 == 3) else 0
     over["selectmode"] = 2 if stereo else 0
     kind = ("de_" if stereo else "") + ("int" if noc == 1 else "rgb")
-    if not oracle.have_ref(kind, True):
-        pytest.skip("oracle/_ref not built")
+    if oracle.need_ref(kind, True) is None:
+        pytest.skip("comparison against the compiled reference skipped: neither /root/reference nor oracle/_ref exists here")
     ia, ib, _ = gen_synth.make_pair(w, h, 9100 + seed, noc)
     if stereo:
         ia, ib = ib, ia
@@ -520,7 +530,7 @@ def test_fallback_kernels_at_the_benchmark_geometry(gpu, orc, knob):
         gpu.restore_tuning(old)
 
 
-@pytest.mark.parametrize("pipe", [0, 1])
+@pytest.mark.parametrize("pipe", [0, 2])
 @pytest.mark.parametrize("nfr,strip", [(8, 2), (16, 4), (24, 8), (6, 2), (7, 2)])
 @pytest.mark.parametrize("size", [(256, 128), (1024, 436)])
 def test_fused_tv_strips(gpu, orc, nfr, strip, size, pipe):
@@ -658,8 +668,9 @@ def test_block_world_inputs(gpu, orc, size, channels, opp, seed):
     got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
     assert_bits_equal(got, orc.flow(p, pa[0], pa[1], pa[2], pb[0]), "block world vs restatement")
     mode = "int" if channels == 1 else "rgb"
-    if oracle.have_ref(mode, True):
-        assert_bits_equal(got, oracle.ref(mode, True).flow(p, pa[0], pa[1], pa[2], pb[0]), "block world vs the reference build")
+    R = oracle.need_ref(mode, True)
+    if R is not None:
+        assert_bits_equal(got, R.flow(p, pa[0], pa[1], pa[2], pb[0]), "block world vs the reference build")
     assert np.isfinite(got).all()
 
 
@@ -680,7 +691,7 @@ def test_fused_tv_strips_odd_geometries(gpu, orc, size, level, nfr, strip):
         cases.append((O.build_pyramid(p, ia), O.build_pyramid(p, ib)))
     refs = [orc.flow(p, pa[0], pa[1], pa[2], pb[0]) for pa, pb in cases]
     for variant in ({"fused_mw_max": 0, "fused_xcu_max": 0, "fused_strip": strip, "fused_tp_pipe": 0},
-                    {"fused_mw_max": 0, "fused_xcu_max": 0, "fused_strip": strip, "fused_tp_pipe": 1},
+                    {"fused_mw_max": 0, "fused_xcu_max": 0, "fused_strip": strip, "fused_tp_pipe": 2},
                     {"fused_mw_max": 1 << 30, "fused_xcu_max": 0, "fused_strip": 0},
                     {"fused_xcu_max": 1 << 30, "fused_strip": 0}):
         old = gpu.set_tuning(**variant)

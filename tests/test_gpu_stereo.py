@@ -21,9 +21,10 @@ def _case(w, h, seed, noc, opp, tv):
 
 def _ref(noc):
     kind = "de_int" if noc == 1 else "de_rgb"
-    if not oracle.have_ref(kind, True):
-        pytest.skip("oracle/_ref stereo build missing (needs /root/reference at build time)")
-    return oracle.ref(kind, True)
+    R = oracle.need_ref(kind, True)
+    if R is None:
+        pytest.skip("comparison against the compiled reference skipped: neither /root/reference nor oracle/_ref exists here")
+    return R
 
 
 @pytest.mark.parametrize("noc,opp", [(1, 2), (3, 3)])
@@ -65,8 +66,9 @@ def test_stereo_flow_bit_exact(gpu, size, noc, opp, tv):
     assert ref.shape[-1] == 1 and (ref <= 0).all()
     got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
     assert_bits_equal(got, ref, "stereo displacement vs reference sources (SELECTMODE=2)")
-    if noc == 1 and oracle.have_ref("de_int", False):
-        seq = oracle.ref("de_int", False).flow(p, pa[0], pa[1], pa[2], pb[0])
+    S = oracle.need_ref("de_int", False) if noc == 1 else None
+    if S is not None:
+        seq = S.flow(p, pa[0], pa[1], pa[2], pb[0])
         assert np.abs(seq - got).mean() * (1 << p.sc_l) < 1e-3      # any summation order lands within the tolerance
     b = gpu.Batch(p, 3)
     for k in range(3):

@@ -138,6 +138,34 @@ def _run_bench(cmd, env):
     return json.loads(lines[0])
 
 
+def _parity_ok(d):
+    """parity_check of a bench line: the exact contract's bit-exact check (a string; under the fused contract the line carries
+    both contracts' checks in a dict)."""
+    pc = d["parity_check"]
+    return pc.startswith("bit-exact") if isinstance(pc, str) else pc["exact_contract"].startswith("bit-exact")
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_control_flow(gpu):
+    """BASELINE configs[4] as the driver will launch it on an 8-GPU node -- `bench.py --gpus 8`, 512 pairs in total, 64 per
+    rank -- with all eight ranks on this box's one GPU over gloo (developer mode): spawn_ranks(8), frame_range(512, r, 8), the
+    eight-way gathers, the max-over-ranks time and rank 0's re-computation of every other rank's frames all execute once."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OFDIS_BENCH_BACKEND="gloo", OFDIS_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    d = _run_bench([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--total-frames", "512", "--steps", "2",
+                    "--warmup", "1", "--cpu-seconds", "0", "--no-extras"], env)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["global_frames_per_step"] == 512 and d["config"]["frames_per_gpu_per_step"] == 64
+    rk = d["config"]["ranks"]
+    assert rk["world_size"] == 8 and len(rk["pci_bus_ids"]) == 8 and rk["launch"] == "self-spawned by bench.py --gpus"
+    assert rk["all_ranks_on_one_gpu_developer_mode"] and rk["distinct_gpus"] == 1
+    assert d["multi_gpu_check"]["frames_compared"] == 448 and d["multi_gpu_check"]["bit_identical_to_1gpu"]
+    assert _parity_ok(d) and d["contract"] in ("exact", "fused")
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_under_torchrun(gpu):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank)."""
@@ -153,8 +181,8 @@ def test_bench_two_ranks_under_torchrun(gpu):
     assert (rk["world_size"], rk["backend"], rk["launch"]) == (2, backend, "torch.distributed.run")
     # one PCI bus id per rank; distinct GPUs under RCCL (the one-GPU developer mode shares device 0)
     assert len(rk["pci_bus_ids"]) == 2 and rk["distinct_gpus"] == (2 if backend.startswith("rccl") else 1)
-    assert d["parity_check"].startswith("bit-exact")
-    assert d["multi_gpu_check"]["bit_identical_to_1gpu"] and d["multi_gpu_check"]["frames_compared"] == 32
+    assert _parity_ok(d)
+    assert d["multi_gpu_check"]["bit_identical_to_1gpu"] and d["multi_gpu_check"]["frames_compared"] == 64  # the other rank's whole share
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
 
 
@@ -209,7 +237,7 @@ def test_bench_strong_scaling_partition(gpu):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["global_frames_per_step"] == 75 and d["config"]["frames_per_gpu_per_step"] == [38, 37]
     assert d["multi_gpu_check"] == {**d["multi_gpu_check"], "frames_compared": 37, "mismatches": 0, "bit_identical_to_1gpu": True}
-    assert d["parity_check"].startswith("bit-exact")
+    assert _parity_ok(d)
 
 
 @pytest.mark.gpu
@@ -225,4 +253,4 @@ def test_bench_rccl_calls_with_one_rank(gpu):
                     "--batch", "64", "--cpu-seconds", "0", "--no-extras"], env)
     assert d["n_gpus"] == 1 and d["config"]["ranks"]["world_size"] == 1
     assert d["config"]["ranks"]["backend"] == "rccl (torch.distributed nccl)"
-    assert d["parity_check"].startswith("bit-exact")
+    assert _parity_ok(d)

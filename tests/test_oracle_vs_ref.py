@@ -9,7 +9,9 @@ import oracle
 from common import assert_bits_equal, rand_planes, synth_case
 
 _f32 = np.float32
-pytestmark = pytest.mark.skipif(not oracle.have_ref("int"), reason="oracle/_ref not built and /root/reference absent")
+# (skipped only on a machine with neither the reference sources nor a shipped build of them; a library missing where the
+# build is expected fails in oracle.need_ref)
+pytestmark = pytest.mark.skipif(not oracle.ref_expected(), reason="neither /root/reference nor oracle/_ref exists here")
 
 
 @pytest.fixture(scope="module", params=[False, True], ids=["seq", "wave64"])
@@ -150,8 +152,7 @@ def test_block_world_inputs_cpu():
     O = oracle.c_oracle()
     pa, pb = O.build_pyramid(p, ia), O.build_pyramid(p, ib)
     for wave64 in (False, True):
-        if not oracle.have_ref("int", wave64):
-            pytest.skip("oracle/_ref not built")
+        assert oracle.need_ref("int", wave64) is not None
         O.set_reduce_order(wave64)
         a = O.flow(p, pa[0], pa[1], pa[2], pb[0])
         b = oracle.ref("int", wave64).flow(p, pa[0], pa[1], pa[2], pb[0])

@@ -32,7 +32,7 @@ def collect(path, counter, scale):
             continue
         name = r.get("Kernel_Name", "")
         for key, cls in CLASS.items():
-            if "ofdis::" + key in name:
+            if any(("ofdis::" + ns + key) in name for ns in ("", "exact::", "fused::")):
                 acc[cls] += float(r["Counter_Value"]) * scale
     return acc
 
@@ -40,8 +40,12 @@ def collect(path, counter, scale):
 fetch = collect(sys.argv[1], "FETCH_SIZE", 2 * 1024.0)
 write = collect(sys.argv[2], "WRITE_SIZE", 1024.0)
 batch, tv, nsteps = int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
-sq_file = sys.argv[6] if len(sys.argv) > 6 else None
-out = {"batch": batch, "tv": tv, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 (calibrated)",
+sq_file = sys.argv[6] if len(sys.argv) > 6 and sys.argv[6] not in ("", "-") else None
+contract = sys.argv[7] if len(sys.argv) > 7 else "exact"
+out = {"batch": batch, "tv": tv, "contract": contract,
+       "what": "one un-pipelined pass over `batch` pairs = ONE sub-batch of the headline run (bench.py --batch 2*batch --pipeline 2): "
+               "same kernel selection and strip lengths; bench.py multiplies by the number of sub-batches",
+       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 (calibrated)",
        "bytes_per_step": {k: (fetch[k] + write[k]) / nsteps for k in sorted(set(fetch) | set(write))},
        "read_bytes_per_step": {k: fetch[k] / nsteps for k in sorted(fetch)},
        "write_bytes_per_step": {k: write[k] / nsteps for k in sorted(write)}}
@@ -54,7 +58,7 @@ if sq_file:
         if r["Counter_Name"] != "GRBM_GUI_ACTIVE":
             continue
         for key, cls in CLASS.items():
-            if "ofdis::" + key in r.get("Kernel_Name", ""):
+            if any(("ofdis::" + ns + key) in r.get("Kernel_Name", "") for ns in ("", "exact::", "fused::")):
                 cyc[cls] += float(r["Counter_Value"])
                 if r.get("Start_Timestamp") and r.get("End_Timestamp"):
                     dur[cls] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
