@@ -75,7 +75,10 @@ void tuning_init_locked() {
   auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
   g_tuning.gray8 = !on("OFDIS_NO_GRAY8");
   g_tuning.rgb12 = !on("OFDIS_NO_RGB12");
-  g_tuning.rgb12_lpp = num("OFDIS_RGB12_LPP", 64) == 32 ? 32 : 64;
+  {
+    const int l = num("OFDIS_RGB12_LPP", 0);
+    g_tuning.rgb12_lpp = (l == 16 || l == 32 || l == 64) ? l : 0;
+  }
   g_tuning.fused_tv = !on("OFDIS_NO_FUSED");
   g_tuning.fused_mw_max = std::max(0, num("OFDIS_FUSED_MW_MAX", 512));
   g_tuning.fused_split = !on("OFDIS_FUSED_NO_SPLIT");
@@ -1558,7 +1561,8 @@ int ofdis_get_tuning(ofdis_tuning* out) {
 }
 int ofdis_set_tuning(const ofdis_tuning* in) {
   if (!in) return fail(OFDIS_ERR_INVALID, "tuning is NULL");
-  if (in->rgb12_lpp != 64 && in->rgb12_lpp != 32) return fail(OFDIS_ERR_INVALID, "rgb12_lpp must be 64 or 32");
+  if (in->rgb12_lpp != 0 && in->rgb12_lpp != 16 && in->rgb12_lpp != 32 && in->rgb12_lpp != 64)
+    return fail(OFDIS_ERR_INVALID, "rgb12_lpp must be 0 (library's choice), 16, 32 or 64");
   if (in->fused_mw_max < 0 || in->fused_strip < 0 || in->prep_band_rows < 0 || in->fused_xcu_max < 0 || in->fused_xcu_spin < 0)
     return fail(OFDIS_ERR_INVALID, "negative knob");
   if (in->fused_strip > 64 || in->prep_band_rows > 64)  // (strips index their records with 32-bit byte offsets)

@@ -615,6 +615,259 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
   }
 }
 
+// ------------------------------------------------------------------------------------ RGB 12x12, fused contract
+// Operating points 3 / 4 and BASELINE configs[3] (noc = 3, P = 12: 432 entries per patch).  The generic kernel above gives a
+// patch a whole wavefront, lane l owning entries l, l + 64, ...: four 4-byte tap loads per entry, four 64-lane butterflies per
+// iteration and the scalar solve repeated in 64 lanes -- 353 instructions per patch and iteration, and its summation order
+// (64 strided partials + butterfly) IS the documented order of the exact contract.  The fused contract leaves the order of a
+// sum free (ofdis_dev.h), which opens the mapping of the gray 8x8 kernel to this geometry:
+//   * a patch is 16 lanes (one DPP row), FOUR patches per wavefront, neighbours along a grid row (same image rows);
+//   * lane (rg, cg) = (pl / 4, pl % 4) owns the 3 x 3 pixel block rows 3 rg .. 3 rg + 2, columns 3 cg .. 3 cg + 2: 27 entries,
+//     9 contiguous floats per row; T, Tx, Ty of the block live in VGPRs;
+//   * an evaluation needs the 4 x 4 pixel window around the block (one row above, one pixel to the left): per window row 12
+//     contiguous floats = three 16-byte buffer loads, 12 loads per evaluation for 27 entries (the generic kernel: 108), the
+//     row a scalar offset, one per-lane byte offset per evaluation;
+//   * sums: 27 in-lane terms, then four DPP steps inside the 16-lane row; the 2x2 solve, position update and termination
+//     tests are paid once per four patches.
+// About 105 instead of 353 instructions per patch and iteration.  Same algorithm, same taps, same control flow: results
+// within the fused contract's tolerance of the exact kernel (tests/test_gpu_contract.py).
+__device__ __forceinline__ float row16_sum(float x) {  // all-reduce inside a DPP row of 16 lanes
+  x = x + dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
+  x = x + dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+  x = x + dpp_mov<0x141>(x);  // row_half_mirror
+  x = x + dpp_mov<0x140>(x);  // row_mirror
+  return x;
+}
+
+template <int COST>
+__global__ __launch_bounds__(256) void patch_optimize_rgb12_kernel(const DisArgs a) {
+  constexpr int Q = 4, NE = 27, NV = 432;  // patches per wavefront, entries per lane, entries per patch
+  const LevelGeom& g = a.g;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int blocks_per_frame = (g.nop + 4 * Q - 1) / (4 * Q);
+  int frame, blk;
+  xcd_frame_map(blockIdx.x, blocks_per_frame, a.nframes, frame, blk);
+  if (frame >= a.nframes) return;               // block-uniform
+  if ((blk * 4 + wave) * Q >= g.nop) return;    // wave-uniform: no patch for this wavefront
+  const int sub = lane >> 4, pl = lane & 15;
+  const int rg = pl >> 2, cg = pl & 3;
+  int jp = (blk * 4 + wave) * Q + sub;          // row-major patch counter (see the gray 8x8 kernel)
+  const bool live = jp < g.nop;
+  if (!live) jp = g.nop - 1;                    // idle lane group: shadows the last patch, never stores
+  const int gy = jp / g.nopw, gx = jp - gy * g.nopw;
+  const int ip = gx * g.noph + gy;
+
+  const int tw = g.tmp_w;
+  const size_t plane = g.plane_elems;
+  auto plane_rsrc = [&](const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)frame * plane), 0, (int)(plane * sizeof(float)), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsB = plane_rsrc(a.im_b);
+  const int row_bytes = tw * 12;
+  auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
+  const float rx = (float)(gx * g.steps + g.offw), ry = (float)(gy * g.steps + g.offh);
+  const float inv_nv = 1.0f / (float)NV;
+
+  // ---- InitializePatch (patch.cpp:287-332): the lane's 3 x 3 pixel block, entry e = (row rr, pixel xx, channel c) at
+  //      e = rr * 9 + xx * 3 + c
+  float T[NE], Tx[NE], Ty[NE];
+  float meanT = 0.0f;  // mean of the stored (mean-normalised) template: a rounding residue, kept so that the residual's mean is exact
+  {
+    const int px = (int)roundf(rx) + g.pad, py = (int)roundf(ry) + g.pad;
+    const __amdgpu_buffer_rsrc_t rsA = plane_rsrc(a.im_a), rsAx = plane_rsrc(a.im_a_dx), rsAy = plane_rsrc(a.im_a_dy);
+    const int vbase = ((py - 6 + 3 * rg) * tw + px - 6 + 3 * cg) * 12;
+    auto ld9 = [&](const __amdgpu_buffer_rsrc_t& rs, int rr, float* dst) {
+      const auto q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, vbase, rr * row_bytes, 0);
+      const auto q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + 16, rr * row_bytes, 0);
+      const unsigned q2 = __builtin_amdgcn_raw_buffer_load_b32(rs, vbase + 32, rr * row_bytes, 0);
+      const unsigned u0 = q0[0], u1 = q0[1], u2 = q0[2], u3 = q0[3], u4 = q1[0], u5 = q1[1], u6 = q1[2], u7 = q1[3];
+      dst[0] = asf(u0); dst[1] = asf(u1); dst[2] = asf(u2); dst[3] = asf(u3); dst[4] = asf(u4);
+      dst[5] = asf(u5); dst[6] = asf(u6); dst[7] = asf(u7); dst[8] = asf(q2);
+    };
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      ld9(rsA, rr, T + 9 * rr);
+      ld9(rsAx, rr, Tx + 9 * rr);
+      ld9(rsAy, rr, Ty + 9 * rr);
+    }
+    if (a.patnorm > 0) {
+      float c = T[0];
+#pragma unroll
+      for (int e = 1; e < NE; ++e) c += T[e];
+      const float mean = row16_sum(c) * inv_nv;
+      float c2 = 0.0f;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) { T[e] -= mean; c2 += T[e]; }
+      meanT = row16_sum(c2) * inv_nv;
+    }
+  }
+  // ---- ComputeHessian + Cholesky factor (patch.cpp:71-88, Eigen LLT as in oracle/eigen_shim)
+  float l00, l10, l11;
+  {
+    float hxx = 0.0f, hxy = 0.0f, hyy = 0.0f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      hxx += Tx[e] * Tx[e];
+      hxy += Tx[e] * Ty[e];
+      hyy += Ty[e] * Ty[e];
+    }
+    float H00 = row16_sum(hxx);
+    const float H01 = row16_sum(hxy);
+    float H11 = row16_sum(hyy);
+    if (H00 * H11 - H01 * H01 == 0.0f) {
+      H00 = (float)((double)H00 + 1e-10);
+      H11 = (float)((double)H11 + 1e-10);
+    }
+    l00 = H00; l10 = H01; l11 = H11;
+    if (!(l00 <= 0.0f)) {
+      l00 = sqrtf(l00);
+      l10 = l10 / l00;
+      const float x = l11 - l10 * l10;
+      if (!(x <= 0.0f)) l11 = sqrtf(x);
+    }
+  }
+  // ---- InitializeFromCoarserOF (patchgrid.cpp:195-211)
+  float pin0 = 0.0f, pin1 = 0.0f;
+  if (a.flow_prev) {
+    const int x = (int)floorf(rx / 2), y = (int)floorf(ry / 2);
+    const int i = y * (g.w / 2) + x;
+    const float* fp = a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2) * 2;
+    pin0 = fp[2 * i] * 2;
+    pin1 = fp[2 * i + 1] * 2;
+  }
+  // ---- OptimizeIter (patch.cpp:159-212); state uniform per patch (16 lanes)
+  const float r00 = rcp_refined(l00), r11 = rcp_refined(l11);
+  float p0 = pin0, p1 = pin1;
+  float ptx = rx + p0, pty = ry + p1;
+  const float stx = ptx, sty = pty;
+  float dp0 = 0.0f, dp1 = 0.0f;
+  float dpsq = 1e-10f, dpsq_init = 1e-10f, mares = 1e20f, mares_old = 1e20f;
+  float b0 = 0.0f, b1 = 0.0f;
+  int cnt = 0;
+  bool converged = false;
+  // this lane's 3 rows of 9 weights within the patch's 432 (entry (row, col, c) at (row * 12 + col) * 3 + c)
+  float* const pwout = a.pweight + ((size_t)frame * g.nop + ip) * NV + (3 * rg * 12 + 3 * cg) * 3;
+  auto store_pw = [&](const float (&v)[NE], bool zero) {
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) pwout[rr * 36 + q] = zero ? 0.0f : fabsf(v[rr * 9 + q]);
+  };
+
+  auto compute_err = [&](bool stop) {  // patch.cpp:264-284, 335-402, 223-262
+    int pos0 = (int)ceilf(ptx + .00001f), pos1 = (int)ceilf(pty + .00001f);
+    const int pos2 = (int)floorf(ptx), pos3 = (int)floorf(pty);
+    const float r0 = ptx - (float)pos2, r1 = pty - (float)pos3;
+    const float we0 = r0 * r1, we1 = (1 - r0) * r1, we2 = r0 * (1 - r1), we3 = (1 - r0) * (1 - r1);
+    pos0 += g.pad;
+    pos1 += g.pad;
+    // window: rows pos1 - 7 + 3 rg + j, j = 0..3; pixels pos0 - 7 + 3 cg + i, i = 0..3 (12 floats per row).  Entry (rr, xx, c)
+    // takes a = W[rr+1][xx+1], b = W[rr+1][xx], c = W[rr][xx+1], d = W[rr][xx] (patch.cpp:335-402)
+    const int voff = ((pos1 - 7 + 3 * rg) * tw + pos0 - 7 + 3 * cg) * 12;
+    float W[4][12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 16 * q, j * row_bytes, 0);
+        const unsigned u0 = t[0], u1 = t[1], u2 = t[2], u3 = t[3];
+        W[j][4 * q] = asf(u0); W[j][4 * q + 1] = asf(u1); W[j][4 * q + 2] = asf(u2); W[j][4 * q + 3] = asf(u3);
+      }
+    }
+    float d[NE];
+    float se = 0.0f;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {  // q = xx * 3 + c: the left neighbour pixel is 3 floats back
+        const int e = rr * 9 + q;
+        float v = we0 * W[rr + 1][q + 3] - T[e];
+        v = we1 * W[rr + 1][q] + v;
+        v = we2 * W[rr][q + 3] + v;
+        v = we3 * W[rr][q] + v;
+        d[e] = v;  // interpolated value minus the (mean-normalised) template
+        se += v;
+      }
+    if (a.patnorm > 0) {  // the patch's own mean (patch.cpp:401): mean(v) = mean(v - T) + mean(T)
+      const float mean = row16_sum(se) * inv_nv + meanT;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) d[e] -= mean;
+    } else {              // T was not normalised: d = v - T already
+    }
+    float g0 = 0.0f, g1 = 0.0f, sa = 0.0f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      float r = d[e];
+      if (COST == 1) r = copysignf(__builtin_amdgcn_sqrtf(fabsf(r)), r);  // L1 (patch.cpp:238-246)
+      d[e] = r;
+      g0 += Tx[e] * r;
+      g1 += Ty[e] * r;
+      sa += fabsf(r);
+    }
+    b0 = row16_sum(g0);
+    b1 = row16_sum(g1);
+    dpsq = dp0 * dp0 + dp1 * dp1;
+    if (cnt == 1) dpsq_init = dpsq;
+    mares_old = mares;
+    mares = row16_sum(sa) * inv_nv;
+    bool go = (cnt < a.max_iter) && (mares > a.res_thresh);
+    if (go && cnt >= a.min_iter)
+      go = (div_rn(dpsq, dpsq_init) >= a.dp_thresh_sq) && (div_rn(mares, mares_old) <= a.dr_thresh);
+    if (!go | stop) {
+      converged = true;
+      if (live) store_pw(d, false);
+    }
+  };
+  auto oob = [&](float x, float y) { return (x < g.lb) | (y < g.lb) | (x > g.ubw) | (y > g.ubh); };
+
+  if (oob(ptx, pty) || !(isfinite(ptx) && isfinite(pty))) {
+    converged = true;  // OptimizeStart (patch.cpp:120-156): no evaluation, pweight keeps its initial zeros
+    if (live) store_pw(T, true);
+  } else {
+    dpsq = 1e-10f; dpsq_init = 1e-10f; mares = 1e5f; mares_old = 1e20f;
+    compute_err(false);
+  }
+  while (!converged) {
+    cnt++;
+    const float y0 = div_by(b0, l00, r00);
+    const float y1 = div_by(b1 - l10 * y0, l11, r11);
+    dp1 = div_by(y1, l11, r11);
+    dp0 = div_by(y0 - l10 * dp1, l00, r00);
+    p0 -= dp0;
+    p1 -= dp1;
+    ptx = rx + p0;
+    pty = ry + p1;
+    const float ex = stx - ptx, ey = sty - pty;
+    const bool reset = (ex * ex + ey * ey > a.outlier_sq_max) | oob(ptx, pty) | !(isfinite(ptx) & isfinite(pty));
+    p0 = reset ? pin0 : p0;
+    p1 = reset ? pin1 : p1;
+    ptx = rx + p0;
+    pty = ry + p1;
+    compute_err(reset);
+  }
+  if (live && pl == 0) {
+    float* pout = a.p_out + ((size_t)frame * g.nop + ip) * 2;
+    pout[0] = p0;
+    pout[1] = p1;
+  }
+}
+
+// (a template so that the exact contract's object never instantiates the kernel above)
+template <bool FUSED>
+hipError_t launch_patch_optimize_rgb12(const DisArgs& a, hipStream_t s) {
+  if constexpr (FUSED) {
+    const int wpf = (a.g.nop + 3) / 4;  // four patches per wavefront
+    const int blocks_per_frame = (wpf + 3) / 4;
+    const dim3 gd(((a.nframes + 7) / 8) * 8 * blocks_per_frame), bd(256);
+    if (a.costfct == 0) hipLaunchKernelGGL((patch_optimize_rgb12_kernel<0>), gd, bd, 0, s, a);
+    else hipLaunchKernelGGL((patch_optimize_rgb12_kernel<1>), gd, bd, 0, s, a);
+    return hipGetLastError();
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   const int M = (a.g.novals + 63) / 64;
   const bool full = a.g.novals == 64 * M;
@@ -625,8 +878,10 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   // 929 -> 705 instructions per patch and iteration, 82 -> 127 VGPRs).  Measured on configs[3] the same 19.6 +- 0.4 ms per
   // 16-pair level-1 launch either way -- patches that reset early leave their wavefront's other half running alone
   // (PMC: 18 % fewer VALU instructions, same time) -- so one patch per wavefront stays the default.
-  const int rgb12_lpp = tn.rgb12_lpp;
+  const int rgb12_lpp = tn.rgb12_lpp == 0 ? (kFusedContract ? 16 : 64) : tn.rgb12_lpp;
   const bool rgb12 = a.g.novals == 432 && !a.stereo && (a.costfct == 0 || a.costfct == 1) && tn.rgb12;
+  // fused contract: RGB 12x12 has its own mapping (16 lanes per patch, ofdis_tuning::rgb12_lpp = 16: the default there)
+  if (kFusedContract && rgb12 && rgb12_lpp == 16) return launch_patch_optimize_rgb12<kFusedContract>(a, s);
   const int lpp = (M <= 1) ? (gray8 ? 4 : 8) : ((rgb12 && rgb12_lpp == 32) ? 32 : 64);  // lanes per patch
   const int ppw = 64 / lpp;                           // patches per wavefront
   const int wpf = (a.g.nop + ppw - 1) / ppw;          // wavefronts per frame
