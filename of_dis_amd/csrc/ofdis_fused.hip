@@ -82,6 +82,8 @@ constexpr int SP_MAX_ITERS = 6;  // MODE 2: 2 wavefronts per iteration, 12 per w
 //         iteration's producer through the same LDS ring MODE 1 uses.  A lone wavefront issues one instruction per ~6
 //         clocks (dependent-issue latency), so halving the instructions per wavefront and step nearly halves the step.
 template <int NS, bool BRIGHT, int MODE>
+// (MODE 1 squeezed into 168 registers for three wavefronts per SIMD -- amdgpu_waves_per_eu(3): 7 spilled -- was measured at
+// 5.84 instead of 4.41 ms on level 3 of the headline: not kept)
 __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * MW_MAX_ITERS : 256)) void tv_fused_kernel(
     const FusedArgs a, const int R) {
   constexpr int U = 6;

@@ -48,7 +48,7 @@ def test_tuning_struct_layout_matches_header():
     names = [d.split()[-1] for d in body.split(";") if d.strip()]
     assert names == [n for n, _ in capi.OfdisTuning._fields_]
     t = capi.get_tuning()   # host only: read from the environment, no device work
-    assert (t.gray8, t.fused_tv, t.rgb12_lpp) == (1, 1, 64)
+    assert (t.gray8, t.fused_tv, t.rgb12_lpp, t.contract, t.fused_tp_pipe) == (1, 1, 0, 0, 1)
 
 
 def test_tuning_environment_variables_match_header():

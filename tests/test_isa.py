@@ -92,6 +92,8 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     ("tv_fused_xcu_kernelILi3ELb1EE", 128, "tv_fused_xcu_kernel<3, true>, cross-CU mapping: one wavefront per SIMD, four workgroups per CU at most"),
     ("patch_optimize_gray8_kernelILi0EE", 128, "gray 8x8 patch kernel: four wavefronts per SIMD"),
     ("patch_optimize_kernelILi7ELi64ELi432ELi1EE", 84, "RGB 12x12 patch kernel, L1 cost: six wavefronts per SIMD"),
+    ("patch_optimize_rgb12_kernelILi1EE", 184, "RGB 12x12 patch kernel of the fused contract (3x3 pixel block per lane): two wavefronts per SIMD"),
+    ("tv_fused_kernelILi3ELb1ELi1EE", 184, "tv_fused_kernel<3, true, 1>, iteration-pipelined mapping: two workgroups of n_inner wavefronts per CU"),
     ("densify_kernelILb1EE", 64, "densify_kernel<true>: eight wavefronts per SIMD"),
     ("densify_quad_kernel", 64, "densify_quad_kernel: eight wavefronts per SIMD"),
     ("tv_prep_kernelILi2EE", 84, "tv_prep_kernel<2> (two wavefronts per 128-column row): six wavefronts per SIMD by registers"),
