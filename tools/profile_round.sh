@@ -27,19 +27,8 @@ rm -rf $OUT/kt
 OFDIS_BENCH_CONFIG4_PAIRS=96 OFDIS_BENCH_BLOCKS=config4 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt4 -- python $R/bench.py --batch 64 --steps 1 --warmup 0 --cpu-seconds 0 --no-parity --contract $CONTRACT > $OUT/kt4.log 2>&1
 f=$(find $OUT/kt4 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/prof_summary.py $f > $OUT/config4_kernel_levels.csv
 rm -rf $OUT/kt4
-# PMC passes, each counter set in its own run with nothing but the kernel trace:
-# HBM traffic (FETCH_SIZE, WRITE_SIZE) and VALU issue (SQ_INSTS_VALU, GRBM_GUI_ACTIVE)
-for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
-  n=$(echo $c | cut -d' ' -f1)
-  timeout 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$n -- python $R/bench.py --batch $PMC_BATCH --steps 1 --warmup 0 --cpu-seconds 0 --no-parity --no-extras --pipeline 1 --contract $CONTRACT > $OUT/pmc_$n.log 2>&1
-done
-ff=$(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
-fw=$(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-fs=$(find $OUT/pmc_SQ_INSTS_VALU -name "*counter_collection.csv" | head -1)
+# PMC passes (HBM traffic, VALU issue) -> profiles/traffic.json: tools/pmc_round.sh (separate runs, no torch in the profiled process)
 cd $R
-if [ -n "$ff" ] && [ -n "$fw" ]; then
-  # bench.py --steps 1 --warmup 0 --no-extras = 1 timed + 3 timing passes of the pipeline
-  python tools/pmc_traffic.py $ff $fw $PMC_BATCH on 4 "${fs:--}" $CONTRACT > $OUT/traffic.log && cp profiles/traffic.json $OUT/traffic.json
-fi
-rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_INSTS_VALU
+bash tools/pmc_round.sh $TAG $PMC_BATCH $CONTRACT
+cp $R/gpurun_out/pmc_$TAG/traffic.json $OUT/traffic.json 2>/dev/null
 ls -la $OUT
