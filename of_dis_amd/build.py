@@ -93,26 +93,34 @@ def testhooks_path():
     return os.path.join(LIBDIR, "libofdis_testhooks.so")
 
 
-def build(force=False, verbose=False):
-    os.makedirs(LIBDIR, exist_ok=True)
+def compile_units(csrc, outdir, force=False, verbose=False, extra_flags=None):
+    """Compile every translation unit of the library (kernel files once per contract) from `csrc` into `outdir`; returns
+    the object list.  extra_flags: {file name: [flags]} on top of PER_FILE_FLAGS (developer A/B builds, tools/ab_build.py)."""
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    headers = [os.path.join(csrc, h) for h in os.listdir(csrc) if h.endswith((".h", ".inc"))]
     headers.append(os.path.join(ROOT, "include", "ofdis.h"))
     headers.append(os.path.abspath(__file__))  # the flags live here
-    headers += [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".inc")]
     objs, jobs = [], []
     units = [(src, c) for c in ("exact", "fused") for src in KERNEL_SOURCES] + [(src, "exact") for src in COMMON_SOURCES]
     for src, contract in units:
-        sp = os.path.join(CSRC, src)
+        sp = os.path.join(csrc, src)
         suffix = ".o" if contract == "exact" else "." + contract + ".o"
-        obj = os.path.join(LIBDIR, src.replace(".hip", suffix))
+        obj = os.path.join(outdir, src.replace(".hip", suffix))
         if force or _newer(obj, [sp] + headers):
-            jobs.append([hipcc] + BASEFLAGS + CONTRACT_FLAGS[contract] + PER_FILE_FLAGS.get(src, []) + ["-c", sp, "-o", obj])
+            flags = PER_FILE_FLAGS.get(src, []) + (extra_flags or {}).get(src, [])
+            jobs.append([hipcc] + BASEFLAGS + CONTRACT_FLAGS[contract] + flags + ["-c", sp, "-o", obj])
         objs.append(obj)
     if jobs:  # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
             list(ex.map(lambda cmd: _run(cmd, verbose), jobs))
+    return objs, headers
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    objs, headers = compile_units(CSRC, LIBDIR, force, verbose)
     so = lib_path()
     vs = _version_script()
     if force or _newer(so, objs + [vs]):

@@ -41,7 +41,7 @@
 // takes one frame group, wavefront k runs iteration k and trails wavefront k-1 by MW_LAG diagonal steps; the du/dv rows
 // travel from wavefront k to k+1 through an LDS ring (8 rows deep, indexed by the unwrapped step number, so the two
 // visits of a wrapped diag row never alias), one workgroup barrier per step keeps the wavefronts in lock step.  Steps per
-// level: w + h + (n_inner-1)*MW_LAG instead of n_inner*w + h (221 / 139 / 103 instead of 568 / 348 / 206 at 1024x436
+// level: w + h + (n_inner-1)*MW_LAG instead of n_inner*w + h (208 / 124 / 86 instead of 568 / 348 / 206 at 1024x436
 // op-2).  Same arithmetic, same order: bit-identical results.  The launcher picks this variant while the batch leaves
 // SIMDs idle (launch_tv_fused).
 //
@@ -65,7 +65,10 @@ namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled fo
 // every such system has at least one positive edge weight (quarter_alpha > 0 is a launch condition, a pixel is
 // never first and last column at once), so det >= (sum of weights)^2 > 0; the slot ring starts with a unit
 // diagonal and unit weights.
-constexpr int MW_LAG = 10;       // MODE 1: steps between consecutive iterations' wavefronts: PDW + 2*(NS-1) + 1 for NS = 3
+constexpr int MW_LAG = 8;        // MODE 1: steps between consecutive iterations' wavefronts: PDU + 2*(NS-1) + 1 for NS = 3, PDU = 3
+                                 // (du / dv come from LDS: they are read in the step that first uses them; 10 with PDU = PDW until
+                                 // round 4 -- every step of lag widens the window in which the iterations' wavefronts must find
+                                 // each other's derivative rows in the L2)
 constexpr int MW_MAX_ITERS = 8;  // MODE 1: wavefronts per workgroup (= fixed-point iterations it handles)
 constexpr int MW_RING = 8;       // LDS rows of du/dv per iteration (a power of two)
 constexpr int SP_LAG = 9;        // MODE 2: du/dv are read 4 rows ahead instead of PDW = 5: 4 + 2*(NS-1) + 1
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   // t+PDD are requested at step t; first uses are rows t+3 (uu, vv) and t+1 (data term): two steps of slack.  (One step of
   // slack, 128 VGPRs = 4 wavefronts per SIMD, measured the same kernel time: occupancy is not what limits this kernel.)
   constexpr int PDW = 5, PDD = 3;
-  constexpr int PDU = MODE == 2 ? 4 : PDW;  // read-ahead of du/dv (MODE 2: from LDS, one step before their first use)
+  constexpr int PDU = MODE == 2 ? 4 : (MODE == 1 ? 3 : PDW);  // read-ahead of du/dv (MODE 1 / 2: from LDS, in / one step before the step of their first use)
   constexpr int LAG = MODE == 2 ? SP_LAG : MW_LAG;
   static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
   static_assert(!MW || LAG >= PDU + 2 * (NS - 1) + 1, "a row must be published before the next iteration reads it");
@@ -232,13 +235,11 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
     // (through scalars: __builtin_bit_cast applied directly to a vector element reads element 0, ROCm 7.2)
     const unsigned t0 = t[0], t1 = t[1];
     r.wx = asf(t0); r.wy = asf(t1);
-    if constexpr (MODE == 1) {
-      ring_uv(r, tau);
-    } else if constexpr (MODE == 0) {
+    if constexpr (MODE == 0) {
       const auto q = __builtin_amdgcn_raw_buffer_load_b64(rsU, zero_uv ? 0x7ffffff0 : vo2, o, 0);
       const unsigned q0 = q[0], q1 = q[1];
       r.du = asf(q0); r.dv = asf(q1);
-    }  // MODE 2: du/dv follow one step later (PDU = 4)
+    }  // MODE 1 / 2: du/dv follow from the LDS ring, PDW - PDU steps later
   };
   auto load_d = [&](FDer& r, int drow) {
     const int o = drow * h * 32;
@@ -264,9 +265,9 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
     load_w(W[2], wrap_row(-1), -1, true);
     load_w(W[3], wrap_row(0), 0, true);
     if (PDW == 5) load_w(W[4], wrap_row(1), 1, true);
-    if constexpr (MODE == 2) {  // du/dv rows -1, 0: the loop starts with row t + PDU = 1
+    if constexpr (MW) {  // du/dv of the rows before the loop's first one (row t + PDU at t = -3)
       ring_uv(W[2], -1);
-      ring_uv(W[3], 0);
+      if (PDU == 4) ring_uv(W[3], 0);
     }
   }
   int rowW = wrap_row(PDW - 3);  // next W row to load (row t+PDW at t = -3)
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
       if (do_p) {
         // ---- (1) loads: W row t+5, D row t+3
         load_w(W[(u + PDW) % 6], rowW, tauW, first_w);  // (first_w: this lane's column on row t+5 is in the first iteration)
-        if constexpr (MODE == 2) ring_uv(W[(u + PDU) % 6], tauW - (PDW - PDU));
+        if constexpr (MW) ring_uv(W[(u + PDU) % 6], tauW - (PDW - PDU));
         rowW = next_row(rowW);
         ++tauW;
         load_d(D[(u + PDD) % 3], rowD);

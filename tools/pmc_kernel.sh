@@ -4,12 +4,12 @@
 K=$1; TAG=${2:-pmck}; BARGS=${3:-"--batch 4096"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
-SETS=${PMC_SETS:-"SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD|TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum TA_BUFFER_LOAD_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum GRBM_GUI_ACTIVE|TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum"}
+SETS=${PMC_SETS:-"SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD"}  # (TA_* / TCP_* sets abort rocprofv3 on this stack)
 i=0
 IFS='|' read -ra ARR <<< "$SETS"
 for set in "${ARR[@]}"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/raw$i -- python $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-parity --no-extras --pipeline 1 $BARGS > $OUT/set$i.log 2>&1
+  timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/raw$i -- python $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-parity --no-extras --pipeline 1 $BARGS > $OUT/set$i.log 2>&1
   f=$(find $OUT/raw$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python $R/tools/pmc_summary.py $f $K > $OUT/set$i.txt || tail -5 $OUT/set$i.log
   rm -rf $OUT/raw$i
