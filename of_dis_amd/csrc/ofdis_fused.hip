@@ -99,6 +99,9 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   // prefetch distances: the (wx, wy) record (MODE 0: and du, dv) of diag row t+PDW and the derivative record of row
   // t+PDD are requested at step t; first uses are rows t+3 (uu, vv) and t+1 (data term): two steps of slack.  (One step of
   // slack, 128 VGPRs = 4 wavefronts per SIMD, measured the same kernel time: occupancy is not what limits this kernel.)
+  // (MODE 1 with the derivative rows requested six and the (wx, wy) rows eight steps ahead -- a six-row register ring and a
+  // staging ring, 197 VGPRs -- measured 4.30-4.33 against 4.34-4.36 ms on level 3 of the headline: memory latency is not what
+  // its steps wait for; not kept)
   constexpr int PDW = 5, PDD = 3;
   constexpr int PDU = MODE == 2 ? 4 : (MODE == 1 ? 3 : PDW);  // read-ahead of du/dv (MODE 1 / 2: from LDS, in / one step before the step of their first use)
   constexpr int LAG = MODE == 2 ? SP_LAG : MW_LAG;
