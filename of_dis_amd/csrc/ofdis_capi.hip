@@ -29,6 +29,7 @@ namespace {
 struct Launchers {
   decltype(&exact::launch_patch_optimize) patch_optimize;
   decltype(&exact::launch_densify) densify;
+  decltype(&exact::launch_patch_p_reference_order) patch_p_reference_order;
   decltype(&exact::launch_warp) warp;
   decltype(&exact::launch_derivatives) derivatives;
   decltype(&exact::tv_prep_supported) tv_prep_supported;
@@ -49,7 +50,7 @@ struct Launchers {
   decltype(&exact::launch_de_update) de_update;
 };
 #define OFDIS_LAUNCHER_TABLE(ns)                                                                                        \
-  {ns::launch_patch_optimize, ns::launch_densify, ns::launch_warp, ns::launch_derivatives, ns::tv_prep_supported,       \
+  {ns::launch_patch_optimize, ns::launch_densify, ns::launch_patch_p_reference_order, ns::launch_warp, ns::launch_derivatives, ns::tv_prep_supported,       \
    ns::launch_tv_prep, ns::launch_tv_system, ns::launch_sor, ns::tv_fused_supported, ns::tv_fused_params_ok,            \
    ns::tv_fused_mode, ns::launch_tv_fused, ns::launch_tv_finish_records, ns::launch_to_diag, ns::launch_from_diag,      \
    ns::launch_tv_finish, ns::launch_flow_split, ns::launch_de_system, ns::launch_de_sor, ns::launch_de_update}
@@ -1474,8 +1475,7 @@ int ofdis_patchgrid_level(const ofdis_params* p, int level, const float* im_a, c
     d.stereo = p->selectmode == 2;
     e = K.densify(d, s);
   }
-  if (e == hipSuccess && p_out)
-    e = hipMemcpyAsync(p_out, pv, (size_t)g.nop * 2 * nframes * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess && p_out) e = K.patch_p_reference_order(g, nframes, pv, p_out, s);  // (the kernels keep p grid-row major)
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)hipFree(pv);
   (void)hipFree(pw);

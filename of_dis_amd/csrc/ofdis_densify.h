@@ -10,7 +10,8 @@ namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled fo
 //   absw = 1/max(2,|r|)  (RGB: 1/sum_c max(2,|r_c|));  we += absw;  flow += p*absw;
 // A pixel is covered by at most ceil(P/steps)^2 patches; visiting them with gx ascending then gy ascending
 // reproduces the reference's ip order, so the sums are bit-identical without atomics.
-// pf = this frame's [nop][2] displacements, pwf = its [nop][novals] weights; accumulates into we, fu, fv.
+// pf = this frame's displacements, pwf = its weights, both in the internal grid-row-major layout (ofdis_dev.h: patch_slot,
+// pweight_row); accumulates into we, fu, fv.
 __device__ __forceinline__ void densify_accumulate(const LevelGeom& g, const float* __restrict__ pf,
                                                    const float* __restrict__ pwf, int x, int y, float& we, float& fu,
                                                    float& fv) {
@@ -32,29 +33,33 @@ __device__ __forceinline__ void densify_accumulate(const LevelGeom& g, const flo
   if (gy_hi > g.noph - 1) gy_hi = g.noph - 1;
   for (int gx = gx_lo; gx <= gx_hi; ++gx)
     for (int gy = gy_lo; gy <= gy_hi; ++gy) {
-      const int ip = gx * g.noph + gy;
+      const int ip = patch_slot(g, gx, gy);
       const int rxi = gx * st + g.offw, ryi = gy * st + g.offh;
       const int kx = x - rxi - lb, ky = y - ryi - lb;
       // The reference walks pweight with a RUNNING pointer: +1 per visited patch pixel and, for RGB,
       // +2 more only for pixels inside the image (patchgrid.cpp:242,256-257), so for RGB patches that
       // overlap the border the entries are shifted.  Closed form of that pointer for pixel (kx,ky):
-      int pidx;
+      float absw;
       if (noc == 1) {
-        pidx = ky * P + kx;
+        const float pw0 = pwf[pweight_row(g, gx, gy, ky) + kx];
+        absw = div_rn(1.0f, fmaxf(2.0f, pw0));  // == 1.0f / x: numerator 1, denominator >= 2 (ofdis_dev.h)
       } else {
         const int left_out = max(0, -(rxi + lb)), right_out = max(0, rxi + ub - (g.w - 1));
         const int top_out = max(0, -(ryi + lb));
-        const int in_row = P - left_out - right_out;
-        pidx = top_out * P + (ky - top_out) * (3 * in_row + (P - in_row)) + left_out + (kx - left_out) * 3;
-      }
-      const float* pw = pwf + (size_t)ip * g.novals + pidx;
-      float absw;
-      if (noc == 1) {
-        absw = div_rn(1.0f, fmaxf(2.0f, pw[0]));  // == 1.0f / x: numerator 1, denominator >= 2 (ofdis_dev.h)
-      } else {
-        absw = fmaxf(2.0f, pw[0]);
-        absw += fmaxf(2.0f, pw[1]);
-        absw += fmaxf(2.0f, pw[2]);
+        float pw0, pw1, pw2;
+        if ((left_out | right_out | top_out) == 0) {  // the patch lies inside the image: the pointer is (ky * P + kx) * 3
+          const float* pw = pwf + pweight_row(g, gx, gy, ky) + kx * 3;
+          pw0 = pw[0]; pw1 = pw[1]; pw2 = pw[2];
+        } else {  // shifted entries of a border patch: three consecutive LINEAR indices, possibly across a row end
+          const int in_row = P - left_out - right_out;
+          const int pidx = top_out * P + (ky - top_out) * (3 * in_row + (P - in_row)) + left_out + (kx - left_out) * 3;
+          pw0 = pwf[pweight_entry(g, gx, gy, pidx)];
+          pw1 = pwf[pweight_entry(g, gx, gy, pidx + 1)];
+          pw2 = pwf[pweight_entry(g, gx, gy, pidx + 2)];
+        }
+        absw = fmaxf(2.0f, pw0);
+        absw += fmaxf(2.0f, pw1);
+        absw += fmaxf(2.0f, pw2);
         absw = div_rn(1.0f, absw);
       }
       we += absw;
@@ -93,10 +98,10 @@ __device__ __forceinline__ void densify_accumulate_gray(const LevelGeom& g, cons
       const int gx = gx_lo + a, gy = gy_lo + b;
       ok[a * C + b] = (gx <= gx_hi) & (gy <= gy_hi);
       const int gxc = min(gx, g.nopw - 1), gyc = min(gy, g.noph - 1);  // gx_lo, gy_lo >= 0
-      const int ip = gxc * g.noph + gyc;
+      const int ip = patch_slot(g, gxc, gyc);
       const int kx = x - (gxc * st + g.offw) - lb, ky = y - (gyc * st + g.offh) - lb;
-      const int pidx = min(max(ky * P + kx, 0), P * P - 1);  // in range for every existing candidate
-      pw[a * C + b] = pwf[(size_t)ip * g.novals + pidx];
+      // (clamped: in range for every candidate, the right entry for every EXISTING one)
+      pw[a * C + b] = pwf[pweight_row(g, gxc, gyc, clampi(ky, 0, P - 1)) + clampi(kx, 0, P - 1)];
       p0[a * C + b] = pf[2 * ip];
       p1[a * C + b] = pf[2 * ip + 1];
     }

@@ -179,6 +179,24 @@ inline float outlier_sq_threshold(float t) {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Internal layout of the patch results (the patch kernels write them, the densify kernels read them; per frame nop * 2 and
+// nop * novals floats as in the reference, but ordered for the accesses of a wavefront, which works along a GRID ROW --
+// sixteen neighbouring patches in the patch kernels, consecutive pixels of an image row in the densify kernels):
+//   p       [gy][gx][2]                       the reference's index is ip = gx * noph + gy (patchgrid.cpp:62-69)
+//   pweight [gy][patch row r][gx][P * noc]    entry (r, col, c) of patch (gx, gy) at column col * noc + c of its row
+// so that one patch row of the neighbouring patches of a grid row is ONE contiguous run: the patch kernel's weight stores
+// and the densification's weight loads touch 2-4 cache lines per instruction instead of one line per patch (round 4).
+// ofdis_patchgrid_level() returns p in the reference's order through launch_patch_p_reference_order().
+__host__ __device__ __forceinline__ int patch_slot(const LevelGeom& g, int gx, int gy) { return gy * g.nopw + gx; }
+__host__ __device__ __forceinline__ size_t pweight_row(const LevelGeom& g, int gx, int gy, int r) {
+  return ((size_t)(gy * g.P + r) * g.nopw + gx) * (size_t)(g.P * g.noc);
+}
+// entry with the reference's linear index k = (r * P + col) * noc + c of patch (gx, gy)
+__host__ __device__ __forceinline__ size_t pweight_entry(const LevelGeom& g, int gx, int gy, int k) {
+  const int rowlen = g.P * g.noc, r = k / rowlen;
+  return pweight_row(g, gx, gy, r) + (size_t)(k - r * rowlen);
+}
+
 // "diag" plane layout used for the SOR solver's operands (7 system planes, du, dv): pixel (x,y) of a
 // w x h plane lives at ((x+y) mod w)*h + y, i.e. wrapped anti-diagonal d = (x+y) mod w is ONE
 // contiguous row of h floats (a bijection onto w*h, no padding).  The wavefront SOR reads/writes

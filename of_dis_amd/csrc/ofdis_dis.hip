@@ -332,16 +332,16 @@ __global__ __launch_bounds__(256) void patch_optimize_kernel(const DisArgs a) {
     compute_err();
   }
 
-  if (live) {
-    float* pout = a.p_out + ((size_t)frame * g.nop + ip) * 2;
+  if (live) {  // results in the internal grid-row-major layout (ofdis_dev.h: patch_slot, pweight_entry)
+    float* pout = a.p_out + ((size_t)frame * g.nop + patch_slot(g, gx, gy)) * 2;
     if (pl == 0) {
       pout[0] = p0;
       pout[1] = p1;
     }
-    float* pwout = a.pweight + ((size_t)frame * g.nop + ip) * nv;
+    float* pwout = a.pweight + (size_t)frame * g.nop * nv;
 #pragma unroll
     for (int e = 0; e < E; ++e)
-      if (valid[e]) pwout[kidx[e]] = pw[e];
+      if (valid[e]) pwout[pweight_entry(g, gx, gy, kidx[e])] = pw[e];
   }
 }
 
@@ -422,8 +422,7 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
   int jp = (blk * wpb + wave) * Q + sub;
   const bool live = jp < g.nop;
   if (!live) jp = g.nop - 1;  // idle lane group: shadows the last patch, never stores
-  const int gy = jp / g.nopw, gx = jp - gy * g.nopw;
-  const int ip = gx * g.noph + gy;
+  const int gy = jp / g.nopw, gx = jp - gy * g.nopw;  // (results are stored by (gx, gy): ofdis_dev.h patch_slot / pweight_row)
 
   const int tw = g.tmp_w;
   const size_t plane = g.plane_elems;
@@ -510,7 +509,10 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
   float b0 = 0.0f, b1 = 0.0f;  // sum Tx.r, sum Ty.r of the latest evaluation (patch.cpp:178-181)
   int cnt = 0;
   bool converged = false;
-  float2* pwout = reinterpret_cast<float2*>(a.pweight + ((size_t)frame * g.nop + ip) * 64) + pl;
+  // row r of this patch's weights: 8 floats inside the run of its grid row's patches (ofdis_dev.h: pweight_row); rows are
+  // nopw * 8 floats apart.  The wavefront's 16 patches are neighbours along the grid row: one store instruction = 512 B
+  float2* const pwout = reinterpret_cast<float2*>(a.pweight + (size_t)frame * g.nop * 64 + pweight_row(g, gx, gy, 0)) + pl;
+  const int pwstride = g.nopw * 4;  // float2 per patch row
 
   auto cost = [&](float d) {
     if (costfct == 1) return copysignf(sqrtf(fabsf(d)), d);
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
       converged = true;
       if (live) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) pwout[r * 4] = make_float2(fabsf(v[r].x), fabsf(v[r].y));
+        for (int r = 0; r < R; ++r) pwout[r * pwstride] = make_float2(fabsf(v[r].x), fabsf(v[r].y));
       }
     }
   };
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
     converged = true;  // OptimizeStart (patch.cpp:120-156): no evaluation, pweight keeps its initial zeros
     if (live) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) pwout[r * 4] = make_float2(0.0f, 0.0f);
+      for (int r = 0; r < R; ++r) pwout[r * pwstride] = make_float2(0.0f, 0.0f);
     }
   } else {
     dpsq = 1e-10f; dpsq_init = 1e-10f; mares = 1e5f; mares_old = 1e20f;
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
   }
 
   if (live && pl == 0) {
-    float* pout = a.p_out + ((size_t)frame * g.nop + ip) * 2;
+    float* pout = a.p_out + ((size_t)frame * g.nop + patch_slot(g, gx, gy)) * 2;
     pout[0] = p0;
     pout[1] = p1;
   }
@@ -670,8 +672,7 @@ __global__ __launch_bounds__(256) void patch_optimize_rgb12_kernel(const DisArgs
   int jp = (blk * 4 + wave) * Q + sub;          // row-major patch counter (see the gray 8x8 kernel)
   const bool live = jp < g.nop;
   if (!live) jp = g.nop - 1;                    // idle lane group: shadows the last patch, never stores
-  const int gy = jp / g.nopw, gx = jp - gy * g.nopw;
-  const int ip = gx * g.noph + gy;
+  const int gy = jp / g.nopw, gx = jp - gy * g.nopw;  // (results are stored by (gx, gy): ofdis_dev.h patch_slot / pweight_row)
 
   const int tw = g.tmp_w;
   const size_t plane = g.plane_elems;
@@ -762,12 +763,14 @@ __global__ __launch_bounds__(256) void patch_optimize_rgb12_kernel(const DisArgs
   int cnt = 0;
   bool converged = false;
   // this lane's 3 rows of 9 weights within the patch's 432 (entry (row, col, c) at (row * 12 + col) * 3 + c)
-  float* const pwout = a.pweight + ((size_t)frame * g.nop + ip) * NV + (3 * rg * 12 + 3 * cg) * 3;
+  // (internal layout, ofdis_dev.h: pweight_row -- patch rows are nopw * 36 floats apart)
+  float* const pwout = a.pweight + (size_t)frame * g.nop * NV + pweight_row(g, gx, gy, 3 * rg) + 9 * cg;
+  const int pwstride = g.nopw * 36;
   auto store_pw = [&](const float (&v)[NE], bool zero) {
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-      for (int q = 0; q < 9; ++q) pwout[rr * 36 + q] = zero ? 0.0f : fabsf(v[rr * 9 + q]);
+      for (int q = 0; q < 9; ++q) pwout[rr * pwstride + q] = zero ? 0.0f : fabsf(v[rr * 9 + q]);
   };
 
   auto compute_err = [&](bool stop) {  // patch.cpp:264-284, 335-402, 223-262
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(256) void patch_optimize_rgb12_kernel(const DisArgs
     compute_err(reset);
   }
   if (live && pl == 0) {
-    float* pout = a.p_out + ((size_t)frame * g.nop + ip) * 2;
+    float* pout = a.p_out + ((size_t)frame * g.nop + patch_slot(g, gx, gy)) * 2;
     pout[0] = p0;
     pout[1] = p1;
   }
@@ -947,7 +950,7 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
 // w2 from t+(0,1), w3 from t+(1,1).  The block first compacts -- preserving the index order -- the patches whose
 // footprint reaches its rows into LDS (256 candidates per round), then every pixel walks that list.
 struct FbCand {
-  int ip, pos0, pos1;
+  int gx, gy, pos0, pos1;
   float w0, w1, w2, w3, p0, p1;
 };
 
@@ -992,10 +995,11 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
       FbCand c;
       bool hit = false;
       if (ipc < g.nop) {
-        const int gx = ipc / g.noph, gy = ipc - gx * g.noph;
-        c.ip = ipc;
-        c.p0 = cpf[2 * ipc];
-        c.p1 = cpf[2 * ipc + 1];
+        const int gx = ipc / g.noph, gy = ipc - gx * g.noph;  // candidates in the reference's index order
+        c.gx = gx;
+        c.gy = gy;
+        c.p0 = cpf[2 * patch_slot(g, gx, gy)];
+        c.p1 = cpf[2 * patch_slot(g, gx, gy) + 1];
         // GetPointPos(): pt_iter = pt_ref + p_iter (patch.cpp:214-221)
         const float rp0 = (float)(gx * st + g.offw) + c.p0, rp1 = (float)(gy * st + g.offh) + c.p1;
         c.pos0 = (int)ceil((double)rp0 + .00001);  // the reference adds a DOUBLE here (patchgrid.cpp:304-305)
@@ -1027,7 +1031,6 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
           const int L = max(0, 1 - (cc.pos0 + lb)), Rr = min(P - 1, g.w - 2 - (cc.pos0 + lb));
           const int T = max(0, 1 - (cc.pos1 + lb)), Bt = min(P - 1, g.h - 2 - (cc.pos1 + lb));
           const int in_row = Rr - L + 1;
-          const float* pwp = cpwf + (size_t)cc.ip * g.novals;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int kx = x + (q & 1) - cc.pos0 - lb, ky = y + (q >> 1) - cc.pos1 - lb;
@@ -1035,12 +1038,12 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
             const float wq = q == 0 ? cc.w0 : (q == 1 ? cc.w1 : (q == 2 ? cc.w2 : cc.w3));
             float absw;
             if (noc == 1) {
-              absw = 1.0f / fmaxf(2.0f, pwp[ky * P + kx]);
+              absw = 1.0f / fmaxf(2.0f, cpwf[pweight_row(g, cc.gx, cc.gy, ky) + kx]);
             } else {  // running pointer: +1 per visited pixel, +2 more per pixel that passed the condition
-              const float* pw = pwp + ky * P + kx + 2 * ((ky - T) * in_row + (kx - L));
-              absw = fmaxf(2.0f, pw[0]);
-              absw += fmaxf(2.0f, pw[1]);
-              absw += fmaxf(2.0f, pw[2]);
+              const int pidx = ky * P + kx + 2 * ((ky - T) * in_row + (kx - L));
+              absw = fmaxf(2.0f, cpwf[pweight_entry(g, cc.gx, cc.gy, pidx)]);
+              absw += fmaxf(2.0f, cpwf[pweight_entry(g, cc.gx, cc.gy, pidx + 1)]);
+              absw += fmaxf(2.0f, cpwf[pweight_entry(g, cc.gx, cc.gy, pidx + 2)]);
               absw = 1.0f / absw;
             }
             we += wq * absw;
@@ -1096,10 +1099,11 @@ __global__ __launch_bounds__(256) void densify_quad_kernel(const DensifyArgs a, 
   for (int c = 0; c < 4; ++c) {  // c = 2 * (grid column: 0 = bx-1, 1 = bx) + (grid row: 0 = by-1, 1 = by)
     const int gx = bx - 1 + (c >> 1), gy = by - 1 + (c & 1);
     ok[c] = (gx >= 0) & (gx < g.nopw) & (gy >= 0) & (gy < g.noph);
-    const int ip = clampi(gx, 0, g.nopw - 1) * g.noph + clampi(gy, 0, g.noph - 1);
+    const int gxc = clampi(gx, 0, g.nopw - 1), gyc = clampi(gy, 0, g.noph - 1);
     const int kx0 = (c >> 1) ? 0 : 4, ky = (c & 1) ? ty : ty + 4;
-    pw[c] = *reinterpret_cast<const float4*>(pwf + (size_t)ip * 64 + ky * 8 + kx0);
-    pp[c] = *reinterpret_cast<const float2*>(pf + 2 * ip);
+    // (internal layout: consecutive threads = consecutive grid columns read consecutive 32-byte patch rows)
+    pw[c] = *reinterpret_cast<const float4*>(pwf + pweight_row(g, gxc, gyc, ky) + kx0);
+    pp[c] = *reinterpret_cast<const float2*>(pf + 2 * patch_slot(g, gxc, gyc));
   }
   float2* out = reinterpret_cast<float2*>(a.flow_aos) + ((size_t)frame * h + y) * w;
 #pragma unroll
@@ -1121,6 +1125,23 @@ __global__ __launch_bounds__(256) void densify_quad_kernel(const DensifyArgs a, 
     const int x = x0 + t;
     if (x >= 0 && x < w) out[x] = make_float2(fu, fv);
   }
+}
+
+// p in the reference's patch order (ip = gx * noph + gy, patchgrid.cpp:62-69) from the internal grid-row-major array: the
+// public p_out of ofdis_patchgrid_level
+__global__ __launch_bounds__(256) void patch_p_reference_order_kernel(const LevelGeom g, int nframes, const float2* __restrict__ src,
+                                                                      float2* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)nframes * g.nop) return;
+  const int frame = (int)(i / g.nop), ip = (int)(i - (long long)frame * g.nop);
+  const int gx = ip / g.noph, gy = ip - gx * g.noph;
+  dst[i] = src[(size_t)frame * g.nop + patch_slot(g, gx, gy)];
+}
+hipError_t launch_patch_p_reference_order(const LevelGeom& g, int nframes, const float* p_internal, float* p_out, hipStream_t s) {
+  const long long n = (long long)nframes * g.nop;
+  hipLaunchKernelGGL(patch_p_reference_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, nframes,
+                     reinterpret_cast<const float2*>(p_internal), reinterpret_cast<float2*>(p_out));
+  return hipGetLastError();
 }
 
 hipError_t launch_densify(const DensifyArgs& a_in, hipStream_t s) {

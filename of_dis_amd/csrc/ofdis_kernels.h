@@ -23,8 +23,8 @@ struct DisArgs {
   const float* im_a_dy;
   const float* im_b;
   const float* flow_prev;  // AoS [B][h/2][w/2][2] or nullptr
-  float* p_out;            // [B][nop][2]
-  float* pweight;          // [B][nop][novals]
+  float* p_out;            // [B][nop][2]       both in the internal grid-row-major layout (ofdis_dev.h: patch_slot,
+  float* pweight;          // [B][nop][novals]  pweight_row): the densify kernels read them, nobody else
 };
 // snapshot of the kernel-selection knobs (include/ofdis.h: ofdis_tuning; ofdis_capi.hip); *epoch counts the changes
 ofdis_tuning tuning(unsigned* epoch = nullptr);
@@ -32,7 +32,7 @@ ofdis_tuning tuning(unsigned* epoch = nullptr);
 struct DensifyArgs {
   LevelGeom g;
   int nframes;
-  const float* p;        // [B][nop][2]
+  const float* p;        // [B][nop][2]       (internal layout, as the patch kernels write them)
   const float* pweight;  // [B][nop][novals]
   float* flow_aos;       // if non-null: AoS output
   float* wx;             // else planar outputs (row-major)
