@@ -8,6 +8,7 @@
 #include <sys/time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -211,12 +212,14 @@ hipError_t launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t s
 struct XcuState {
   int* host = nullptr;             // mapped, device-visible
   int* dev = nullptr;
-  bool off = false;                // the variant is off for this context
-  bool failed = false;             // the results of the last pass are invalid (until the next pass starts)
-  bool told_sync = false;          // ofdis_sync has reported the failure (it does so once; status / download keep saying it)
-  bool rezero = false;             // the granule array may hold stale tags
-  hipStream_t last_stream = nullptr;  // where the last pass was enqueued (ofdis_sync polls the contexts of its stream)
-  bool ran = false;
+  // (atomics: ofdis_sync polls the contexts of its stream from whichever thread synchronises, possibly while the context's
+  // own thread starts its next pass)
+  std::atomic<bool> off{false};        // the variant is off for this context
+  std::atomic<bool> failed{false};     // the results of the last pass are invalid (until the next pass starts)
+  std::atomic<bool> told_sync{false};  // ofdis_sync has reported the failure (it does so once; status / download keep saying it)
+  std::atomic<bool> rezero{false};     // the granule array may hold stale tags
+  std::atomic<hipStream_t> last_stream{nullptr};  // where the last pass was enqueued (ofdis_sync polls the contexts of its stream)
+  std::atomic<bool> ran{false};
 };
 
 struct ofdis_batch {
