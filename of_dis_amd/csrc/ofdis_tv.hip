@@ -65,18 +65,22 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4 nt_load(const f4* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void nt_store(f4 v, f4* p) { __builtin_nontemporal_store(v, p); }
 
-// grid = (column chunks, row groups, frame), block = TX x (256/TX) threads with TX a power of two >= w/VEC (<= 256):
-// pixel coordinates come from shifts and masks -- no division, no 64-bit index arithmetic.
+// 1-D grid of (column chunks x row groups) blocks per frame, a frame's blocks on ONE XCD (xcd_frame_map: its source plane is
+// fetched into one L2 instead of up to eight); block = TX x (256/TX) threads with TX a power of two >= w/VEC (<= 256): pixel
+// coordinates come from shifts and masks -- no 64-bit index arithmetic.
 template <bool PADDED, int VEC, int NOC>
-__global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a, const int tx_shift) {
+__global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a, const int tx_shift, const int gx, const int gy) {
   const int w = a.t.w, h = a.t.h;
   constexpr int noc = NOC;
   const int npx = w * h;
-  const int frame = blockIdx.z;
+  int frame, blk;
+  xcd_frame_map(blockIdx.x, gx * gy, a.t.nframes, frame, blk);
+  if (frame >= a.t.nframes) return;
+  const int by = blk / gx, bx = blk - by * gx;
   const size_t fo = (size_t)frame * npx;
   const int tx = threadIdx.x & ((1 << tx_shift) - 1), ty = threadIdx.x >> tx_shift;
-  const int i = ((blockIdx.x << tx_shift) + tx) * VEC;
-  const int j = blockIdx.y * (256 >> tx_shift) + ty;
+  const int i = ((bx << tx_shift) + tx) * VEC;
+  const int j = by * (256 >> tx_shift) + ty;
   if (i >= w || j >= h) return;
   const int o = j * w + i;
   if constexpr (VEC == 4) {
@@ -84,10 +88,47 @@ __global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a, const int t
     const f4 fyv = nt_load(reinterpret_cast<const f4*>(a.wy + fo + o));
     float4 m;
     float r0[3], r1[3], r2[3], r3[3];
+    // Gray fast path: where the flow is smooth the four pixels of a thread have CONSECUTIVE tap columns in the same two
+    // source rows, away from every border -- their 16 taps are 2 x 5 consecutive floats: four loads instead of sixteen
+    // 4-byte gathers (the kernel is bound by its memory instructions, not its bytes).  Same values into the same
+    // expression as warp_pixel: same bits.  Threads for which it does not hold take the general path below.
+    bool fast = false;
+    if constexpr (NOC == 1) {
+      const float fxs[4] = {fxv.x, fxv.y, fxv.z, fxv.w}, fys[4] = {fyv.x, fyv.y, fyv.z, fyv.w};
+      float xx[4], yy[4];
+      int xb[4], yb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xx[k] = (i + k) + fxs[k];
+        yy[k] = j + fys[k];
+        xb[k] = (int)floorf(xx[k]);
+        yb[k] = (int)floorf(yy[k]);
+      }
+      fast = (xb[1] == xb[0] + 1) & (xb[2] == xb[0] + 2) & (xb[3] == xb[0] + 3) & (yb[1] == yb[0]) & (yb[2] == yb[0]) &
+             (yb[3] == yb[0]) & (xb[0] >= 0) & (xb[0] + 4 <= w - 1) & (yb[0] >= 0) & (yb[0] + 1 <= h - 1);
+      if (fast) {  // (inside the image: every mask is 1, no tap is clamped)
+        const float* s = PADDED ? a.src + (size_t)frame * a.tmp_w * a.tmp_h + (size_t)(yb[0] + a.pad) * a.tmp_w + xb[0] + a.pad
+                                : a.src + (size_t)frame * npx + (size_t)yb[0] * w + xb[0];
+        const int pitch = PADDED ? a.tmp_w : w;
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        const f4u t1 = *reinterpret_cast<const f4u*>(s), t2 = *reinterpret_cast<const f4u*>(s + pitch);
+        const float R1[5] = {t1.x, t1.y, t1.z, t1.w, s[4]}, R2[5] = {t2.x, t2.y, t2.z, t2.w, s[pitch + 4]};
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float dx = xx[k] - (float)xb[k], dy = yy[k] - (float)yb[k];
+          out[k] = R1[k] * (1.0f - dx) * (1.0f - dy) + R1[k + 1] * dx * (1.0f - dy) + R2[k] * (1.0f - dx) * dy + R2[k + 1] * dx * dy;
+        }
+        m = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        r0[0] = out[0]; r1[0] = out[1]; r2[0] = out[2]; r3[0] = out[3];
+      }
+    }
+    if (!fast) {
     warp_pixel<PADDED, NOC>(a, frame, i + 0, j, fxv.x, fyv.x, m.x, r0);
     warp_pixel<PADDED, NOC>(a, frame, i + 1, j, fxv.y, fyv.y, m.y, r1);
     warp_pixel<PADDED, NOC>(a, frame, i + 2, j, fxv.z, fyv.z, m.z, r2);
     warp_pixel<PADDED, NOC>(a, frame, i + 3, j, fxv.w, fyv.w, m.w, r3);
+    }
     nt_store((f4){m.x, m.y, m.z, m.w}, reinterpret_cast<f4*>(a.mask + fo + o));
 #pragma unroll
     for (int c = 0; c < noc; ++c)
@@ -103,18 +144,19 @@ __global__ __launch_bounds__(256) void warp_kernel(const WarpArgs a, const int t
 
 hipError_t launch_warp(const WarpArgs& a, hipStream_t s) {
   const bool v4 = (a.t.w % 4) == 0;
-  if (a.t.nframes > 65535 || (a.t.noc != 1 && a.t.noc != 3)) return hipErrorInvalidValue;
+  if (a.t.noc != 1 && a.t.noc != 3) return hipErrorInvalidValue;
   const int cols = a.t.w / (v4 ? 4 : 1);
   int tx_shift = 0;
   while ((1 << tx_shift) < cols && tx_shift < 8) ++tx_shift;
   const int rows_per_block = 256 >> tx_shift;
-  const dim3 g((unsigned)((cols + (1 << tx_shift) - 1) >> tx_shift), (unsigned)((a.t.h + rows_per_block - 1) / rows_per_block),
-               (unsigned)a.t.nframes), b(256);
-  if (g.y > 65535) return hipErrorInvalidValue;
+  const int gx = (cols + (1 << tx_shift) - 1) >> tx_shift, gy = (a.t.h + rows_per_block - 1) / rows_per_block;
+  const long long blocks = (long long)((a.t.nframes + 7) / 8) * 8 * gx * gy;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  const dim3 g((unsigned)blocks), b(256);
 #define OFDIS_WARP_LAUNCH(P, V)                                                                          \
   do {                                                                                                   \
-    if (a.t.noc == 1) hipLaunchKernelGGL((warp_kernel<P, V, 1>), g, b, 0, s, a, tx_shift);             \
-    else hipLaunchKernelGGL((warp_kernel<P, V, 3>), g, b, 0, s, a, tx_shift);                          \
+    if (a.t.noc == 1) hipLaunchKernelGGL((warp_kernel<P, V, 1>), g, b, 0, s, a, tx_shift, gx, gy);     \
+    else hipLaunchKernelGGL((warp_kernel<P, V, 3>), g, b, 0, s, a, tx_shift, gx, gy);                  \
   } while (0)
   if (a.src_padded) {
     if (v4) OFDIS_WARP_LAUNCH(true, 4);

@@ -83,6 +83,29 @@ def test_image_warp(gpu, orc, w, h, noc):
         assert_bits_equal(mask[b], rm, f"warp mask frame {b}")
 
 
+@pytest.mark.parametrize("w,h,noc", [(128, 56, 1), (64, 28, 1), (240, 136, 3), (132, 40, 1)])
+def test_image_warp_smooth_flow(gpu, orc, w, h, noc):
+    """A smooth flow (what the densified flow of a level looks like): away from the borders the four pixels of a thread
+    have consecutive tap columns in the same two source rows and the gray kernel takes its vector-load path (four loads
+    instead of sixteen gathers); near the borders, at the wrap of the flow's integer part and for RGB the general path.
+    Both in one image, and the integer-valued and out-of-image flows of the random test on top."""
+    rng = np.random.default_rng(11)
+    B = 3
+    src = rand_planes(rng, B, noc, h, w, scale=50)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    wx = np.stack([(3.0 * np.sin(xx / 37.0 + b) + 1.5 * np.cos(yy / 23.0) + 0.37) for b in range(B)]).astype(_f32)
+    wy = np.stack([(2.0 * np.cos(xx / 41.0 - b) - 1.0 * np.sin(yy / 29.0) - 0.21) for b in range(B)]).astype(_f32)
+    wx[1, 5, 8:16] = [0.0, 1.0, -1.0, 2.0, 0.5, 0.5, 0.5, 0.5]     # a thread with integer flows, one with a constant flow
+    wx[2, 3, :4] = -7.0                                           # left border: clamped taps, zero mask
+    wy[2, h - 1, 4:12] = 0.75                                     # last row: the lower taps are clamped
+    dst, mask = gpu.image_warp(src, wx, wy)
+    for b in range(B):
+        rd, rm = orc.image_warp(src[b], wx[b], wy[b])
+        assert_bits_equal(dst[b], rd.reshape(noc, h, w), f"warp dst frame {b}")
+        assert_bits_equal(mask[b], rm, f"warp mask frame {b}")
+    assert mask.mean() > 0.9
+
+
 @pytest.mark.parametrize("w,h,noc", [(128, 56, 1), (32, 14, 1), (30, 17, 3), (67, 33, 1), (5, 4, 1), (40, 5, 1)])
 def test_get_derivatives(gpu, orc, w, h, noc):
     rng = np.random.default_rng(2)
