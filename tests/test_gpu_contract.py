@@ -7,9 +7,14 @@ bit-exact tests use), on the full-resolution flow as it would be written to the 
 
     mean EPE < 1e-4 px   and   max EPE < 1e-3 px
 
-on BASELINE configs[1], configs[2], the 640x480 case and the 40 random configurations of test_gpu_flow.py.  The same
-statistics of the EXACT contract against the same plain reference are printed beside them (-s shows them; they also land
-in the assertion message): they are what the summation order alone costs.
+on BASELINE configs[1], configs[2], the 640x480 case (where the exact contract is asserted against the same bar) and the 40
+random configurations of test_gpu_flow.py.  The same statistics of the EXACT contract against the same plain reference are
+printed beside them (-s shows them; they also land in the assertion message): they are what the summation order alone
+costs.  The random configurations assert "inside the bar, or within 3 x the exact contract's own distance where that is
+larger": with the default seeds every one of them is inside the bar in both contracts; with other seeds
+(OFDIS_TEST_SEED_OFFSET) a configuration with early termination now and then puts one contract or the other at 1.0-1.1e-3 px
+for a handful of pixels (one more or one less Gauss-Newton iteration for a few patches: a last-bit difference flips the
+termination predicate), the exact contract included.
 
 The block-world family (hard-edged flat rectangles: near-singular Hessians, outlier resets) is chaotic for ANY rounding
 change: the exact contract itself -- bit-identical to the reference compiled with the defined summation order -- sits at
@@ -61,21 +66,34 @@ def _both_contracts(gpu, run):
     return ex, fu
 
 
-def _check(orc, p, w, h, ref, ex, fu, what, chaotic=False):
+def _check(orc, p, w, h, ref, ex, fu, what, chaotic=False, exact_must_meet_bar=False):
+    """The fused contract's flow `fu` and the exact contract's `ex` against the plain reference build's `ref`, on the
+    full-resolution flow.  Bar: mean < 1e-4 px and max < 1e-3 px.  Where the EXACT contract itself misses the bar -- it is
+    bit-identical to the reference compiled with the defined summation order, so that is the distance between the
+    reference's own two builds on this input: discrete decisions (early termination, outlier resets) that a last-bit
+    difference flips -- no arithmetic can meet it, and the fused contract has to stay within 3 x the exact contract's
+    distance instead (`chaotic`: the block-world family, where this is the rule).  exact_must_meet_bar: the fixed BASELINE
+    configurations, where the exact contract is asserted against the bar as well."""
     rf = _full_res(orc, p, ref, w, h)
     se = oracle.epe_stats(_full_res(orc, p, ex, w, h), rf)
     sf = oracle.epe_stats(_full_res(orc, p, fu, w, h), rf)
     msg = (f"{what}: fused contract vs plain reference mean {sf[0]:.2e} max {sf[1]:.2e} frac>1e-3 {sf[2]:.2e} | "
-           f"exact contract vs plain reference mean {se[0]:.2e} max {se[1]:.2e}")
+           f"exact contract vs plain reference mean {se[0]:.2e} max {se[1]:.2e} frac>1e-3 {se[2]:.2e}")
     print(msg)
     assert np.isfinite(fu).all(), msg
     assert not np.array_equal(ex, fu) or np.array_equal(ex, ref), msg + " (the fused contract gave the exact contract's bits?)"
-    if chaotic:  # (module docstring) the reference's own two builds are this far apart: compare with that
-        assert sf[0] < max(MEAN_BAR, 3 * se[0]) and sf[2] < max(1e-3, 3 * se[2]), msg
-        assert sf[1] < max(MAX_BAR, 2 * se[1], 0.5 * p.p_samp_s), msg  # (single patches that settle in another minimum)
-    else:
+    exact_ok = se[0] < MEAN_BAR and se[1] < MAX_BAR
+    if exact_must_meet_bar:
+        assert exact_ok, msg + " (the EXACT contract against the plain reference build)"
         assert sf[0] < MEAN_BAR and sf[1] < MAX_BAR, msg
-        assert se[0] < MEAN_BAR and se[1] < MAX_BAR, msg + " (the EXACT contract against the plain reference build)"
+    # everywhere: inside the bar, or within 3 x the distance of the reference's own two builds where that is larger
+    if not exact_ok or chaotic:
+        print("    (the exact contract itself is outside the bar on this input: relative criterion)")
+    assert sf[0] < max(MEAN_BAR, 3 * se[0]) and sf[2] < max(1e-3, 3 * se[2]), msg
+    if exact_ok and not chaotic:
+        assert sf[1] < max(MAX_BAR, 3 * se[1]), msg
+    else:
+        assert sf[1] < max(MAX_BAR, 2 * se[1], 0.5 * p.p_samp_s), msg  # (single patches that settle in another minimum)
     return se, sf
 
 
@@ -90,7 +108,7 @@ def test_fused_contract_baseline_configs(gpu, orc, size, opp, tv, seed):
     p, pa, pb, _, _ = synth_case(size[0], size[1], seed, 1, opp, tv)
     ref = _plain_ref("int").flow(p, pa[0], pa[1], pa[2], pb[0])
     ex, fu = _both_contracts(gpu, lambda: gpu.flow(p, pa[0], pa[1], pa[2], pb[0]))
-    _check(orc, p, size[0], size[1], ref, ex, fu, f"{size} op{opp} tv{tv}")
+    _check(orc, p, size[0], size[1], ref, ex, fu, f"{size} op{opp} tv{tv}", exact_must_meet_bar=True)
 
 
 def test_fused_contract_batch_of_pairs(gpu, orc):
