@@ -807,17 +807,17 @@ int ofdis_batch_build_pyramids_u8(ofdis_batch* b, const uint8_t* img_a, const ui
   }
   for (int which = 0; which < 2; ++which) {
     const uint8_t* src = which ? img_b : img_a;
+    HIPCHK(launch_pyr_base(src, b->pyr_tmp[0], b->nframes, width_org, height_org, p.width, p.height, p.noc, p.sc_l, s));
     for (int i = 0; i < b->nlevels; ++i) {
       const LevelGeom& g = b->geom[i];
-      if (i == 0)
-        HIPCHK(launch_pyr_base(src, b->pyr_tmp[0], b->nframes, width_org, height_org, p.width, p.height, p.noc, p.sc_l, s));
-      else
-        HIPCHK(launch_pyr_down(b->pyr_tmp[i - 1], b->pyr_tmp[i], b->nframes, b->geom[i - 1].w, b->geom[i - 1].h, p.noc, s));
+      // the planes of level i and, in the same launch where the geometry allows, the unpadded image of level i + 1
+      // (2x2 means: cv::resize(.5,.5), run_dense.cpp:150)
+      float* down = i + 1 < b->nlevels ? b->pyr_tmp[i + 1] : nullptr;
       if (which == 0)
-        HIPCHK(launch_pyr_planes(b->pyr_tmp[i], b->in[0][i], b->in[1][i], b->in[2][i], b->nframes, g.w, g.h, p.noc, g.pad, s));
+        HIPCHK(launch_pyr_planes(b->pyr_tmp[i], b->in[0][i], b->in[1][i], b->in[2][i], b->nframes, g.w, g.h, p.noc, g.pad, s, down));
       else
-        HIPCHK(launch_pyr_planes(b->pyr_tmp[i], b->in[3][i], b->in[4][i], b->in[5][i], b->nframes, g.w, g.h, p.noc, g.pad,
-                                 s));  // B's gradients only exist (non-null) with usefbcon
+        HIPCHK(launch_pyr_planes(b->pyr_tmp[i], b->in[3][i], b->in[4][i], b->in[5][i], b->nframes, g.w, g.h, p.noc, g.pad, s,
+                                 down));  // B's gradients only exist (non-null) with usefbcon
     }
   }
   return OFDIS_OK;

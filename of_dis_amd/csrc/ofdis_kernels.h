@@ -148,8 +148,11 @@ struct FusedXcu {
 hipError_t launch_pyr_base(const uint8_t* src, float* dst, int nframes, int wo, int ho, int W, int H, int noc, int l,
                            hipStream_t s);
 hipError_t launch_pyr_down(const float* src, float* dst, int nframes, int w, int h, int noc, hipStream_t s);
+// `down` (optional): also the next coarser level's unpadded image [B][h/2][w/2][noc] (what launch_pyr_down computes), in the
+// same launch where the geometry allows (pyr_planes_fuses_down), else by a launch of its own
 hipError_t launch_pyr_planes(const float* src, float* img, float* dx, float* dy, int nframes, int w, int h, int noc,
-                             int pad, hipStream_t s);
+                             int pad, hipStream_t s, float* down = nullptr);
+bool pyr_planes_fuses_down(int w, int h, int noc, int pad);
 
 // x 2^sc_l, bilinear upsample (cv::resize INTER_LINEAR) and crop of the AoS result (run_dense.cpp:406-414)
 hipError_t launch_upsample_crop(const float* flow, float* out, int nframes, int sw, int sh, int sc_l, int left, int top,

@@ -165,6 +165,74 @@ __global__ __launch_bounds__(256) void pyr_planes_kernel(const float* __restrict
   }
 }
 
+// Gray planes, four padded-plane columns per thread (round 4): the kernel above issues ten 4-byte loads and three 4-byte
+// stores per element -- it is bound by its memory instructions, not its bytes.  Here a thread owns the quad X0 .. X0+3 of a
+// padded row (X0 a multiple of 4; needs w and pad multiples of 4): the three source rows of the Sobel window are read once
+// per quad (one 16-byte load + two scalars each where the quad lies inside the image, clamped / reflected scalars at its
+// border), the three planes are written with 16-byte stores, and -- `down` -- the quad's two pixels of the NEXT level's
+// image (2x2 means, cv::resize(.5,.5,INTER_LINEAR), the expression of pyr_down_kernel) come from the same rows, so that
+// level is read once instead of twice.  Same expressions per element as pyr_planes_kernel / pyr_down_kernel: same bits.
+typedef float f4p __attribute__((ext_vector_type(4)));
+typedef float f4pu __attribute__((ext_vector_type(4), aligned(4)));
+__global__ __launch_bounds__(256) void pyr_planes_gray4_kernel(const float* __restrict__ src, float* __restrict__ img,
+                                                               float* __restrict__ dx, float* __restrict__ dy,
+                                                               float* __restrict__ down, int nframes, int w, int h, int pad) {
+  const int tw = w + 2 * pad, th = h + 2 * pad, qpr = tw >> 2;  // quads per padded row
+  const unsigned q = blockIdx.x * 256u + threadIdx.x;
+  const int f = blockIdx.y;
+  if (q >= (unsigned)(qpr * th)) return;
+  const int Y = (int)(q / (unsigned)qpr), X0 = (int)(q - (unsigned)Y * (unsigned)qpr) * 4;
+  const int x0 = X0 - pad, y = Y - pad;
+  const float* s = src + (size_t)f * w * h;
+  const size_t o = (size_t)f * tw * th + (size_t)Y * tw + X0;
+  const bool yin = (y >= 0) & (y < h), xin = (x0 >= 0) & (x0 + 3 < w);  // (w, pad multiples of 4: a quad is inside or outside)
+  const bool xinner = (x0 >= 1) & (x0 + 4 <= w - 1);
+  // the six columns x0-1 .. x0+4 of source row r, replicate-clamped for the image, reflect-101 for the Sobel window: inside
+  // the image the two rules only differ at columns -1 and w, which the image plane never uses
+  auto row6 = [&](int r, bool reflect, float (&v)[6]) {
+    const float* p = s + (size_t)r * w;
+    if (xinner) {
+      const f4pu t = *reinterpret_cast<const f4pu*>(p + x0);
+      v[0] = p[x0 - 1]; v[1] = t.x; v[2] = t.y; v[3] = t.z; v[4] = t.w; v[5] = p[x0 + 4];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        int x = x0 - 1 + i;
+        if (reflect) x = x < 0 ? (w > 1 ? -x : 0) : (x > w - 1 ? (w > 1 ? 2 * (w - 1) - x : 0) : x);
+        v[i] = p[clampi(x, 0, w - 1)];
+      }
+    }
+  };
+  float mid[6];
+  row6(clampi(y, 0, h - 1), yin & xin, mid);
+  // (outside the image: row and columns clamped = the replicate border of the image plane)
+  *reinterpret_cast<f4p*>(img + o) = f4p{mid[1], mid[2], mid[3], mid[4]};
+  float up[6], lo[6];
+  const bool need_lo = yin & xin & ((dx != nullptr) | ((down != nullptr) & ((y & 1) == 0)));
+  if (need_lo) row6(y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0), true, lo);
+  if (dx) {
+    f4p gx = {0.0f, 0.0f, 0.0f, 0.0f}, gy = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (yin & xin) {  // Sobel / 8 with BORDER_REFLECT_101 (the expression of pyr_planes_kernel)
+      row6(y > 0 ? y - 1 : (h > 1 ? 1 : 0), true, up);
+      float gxs[4], gys[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        gxs[k] = ((up[k + 2] - up[k]) + 2.0f * (mid[k + 2] - mid[k]) + (lo[k + 2] - lo[k])) * 0.125f;
+        gys[k] = ((lo[k] - up[k]) + 2.0f * (lo[k + 1] - up[k + 1]) + (lo[k + 2] - up[k + 2])) * 0.125f;
+      }
+      gx = f4p{gxs[0], gxs[1], gxs[2], gxs[3]};
+      gy = f4p{gys[0], gys[1], gys[2], gys[3]};
+    }
+    *reinterpret_cast<f4p*>(dx + o) = gx;
+    *reinterpret_cast<f4p*>(dy + o) = gy;
+  }
+  if (down && yin && xin && (y & 1) == 0) {  // (h, w even here: the launcher only passes `down` then; row y + 1 exists)
+    const int w2 = w >> 1;
+    float2* d = reinterpret_cast<float2*>(down + (size_t)f * w2 * (h >> 1) + (size_t)(y >> 1) * w2 + (x0 >> 1));
+    *d = make_float2(((mid[1] + mid[2]) + (lo[1] + lo[2])) * 0.25f, ((mid[3] + mid[4]) + (lo[3] + lo[4])) * 0.25f);
+  }
+}
+
 static unsigned grid_for(long long total) {
   long long b = (total + 255) / 256;
   if (b > (1 << 20)) b = 1 << 20;
@@ -188,15 +256,29 @@ hipError_t launch_pyr_base(const uint8_t* src, float* dst, int nframes, int wo, 
   hipLaunchKernelGGL(pyr_base_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, dst, nframes, wo, ho, W, H, noc, l);
   return hipGetLastError();
 }
+// the quad kernel also produces the next level's image (even sizes, gray, quads inside or outside the image)
+bool pyr_planes_fuses_down(int w, int h, int noc, int pad) {
+  return noc == 1 && (w & 3) == 0 && (pad & 3) == 0 && (h & 1) == 0 && w >= 8 && h >= 2;
+}
 hipError_t launch_pyr_down(const float* src, float* dst, int nframes, int w, int h, int noc, hipStream_t s) {
   const long long total = (long long)nframes * (h / 2) * (w / 2) * noc;
   hipLaunchKernelGGL(pyr_down_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, dst, nframes, w, h, noc);
   return hipGetLastError();
 }
 hipError_t launch_pyr_planes(const float* src, float* img, float* dx, float* dy, int nframes, int w, int h, int noc,
-                             int pad, hipStream_t s) {
+                             int pad, hipStream_t s, float* down) {
   const long long per_frame = (long long)(h + 2 * pad) * (w + 2 * pad) * noc;
   if (nframes > 65535 || per_frame >= (1ll << 31)) return hipErrorInvalidValue;
+  if (pyr_planes_fuses_down(w, h, noc, pad) || (!down && noc == 1 && (w & 3) == 0 && (pad & 3) == 0 && w >= 8 && h >= 2)) {
+    // gray, quads: one launch for the three planes and (down != nullptr) the next level's image
+    hipLaunchKernelGGL(pyr_planes_gray4_kernel, dim3((unsigned)((per_frame / 4 + 255) / 256), (unsigned)nframes), dim3(256), 0, s,
+                       src, img, dx, dy, down, nframes, w, h, pad);
+    return hipGetLastError();
+  }
+  if (down) {  // no fused form for this geometry: the caller asked for the next level too
+    hipError_t e = launch_pyr_down(src, down, nframes, w, h, noc, s);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(pyr_planes_kernel, dim3((unsigned)((per_frame + 255) / 256), (unsigned)nframes), dim3(256), 0, s, src, img,
                      dx, dy, nframes, w, h, noc, pad);
   return hipGetLastError();
