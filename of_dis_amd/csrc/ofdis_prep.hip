@@ -89,6 +89,10 @@ __device__ __forceinline__ float h5r(float m2, float m1, float s0, float p1, flo
   return D5_C0 * m2 + D5_C1 * m1 + D5_C2 * s0 + D5_C3 * p1 + D5_C4 * p2;
 }
 
+// (Round 4: the flushes with everything block-independent precomputed once per wavefront -- which pieces a lane moves, their
+// byte offsets, the per-frame strip bases: ~9 instead of ~30 instructions per piece, no scalar divisions per flush -- measured
+// 1.83-2.03 against 1.86 ms on level 3 of the headline, 105 instead of 72 VGPRs: no gain, not kept.  Like the test-free
+// interior loop body of round 3, it removes instructions the kernel was not waiting for.)
 constexpr int PREP_KD = 2;  // rows of derivative records staged before a flush (runs of KD * 32 bytes)
 constexpr int PREP_KW = 8;  // rows of (wx, wy) records staged before a flush (runs of KW * 8 bytes)
 // (measured at 4096 pairs, ms per step of this kernel: KD = 1 / 2 / 4: 1.17 / 0.79 / 0.76, KW = 4 / 8: 0.79 / 0.70 --
