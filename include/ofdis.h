@@ -198,10 +198,10 @@ int ofdis_batch_kernel_times(ofdis_batch* b, int kernel_class, double* ms_out, i
 typedef struct ofdis_tuning {
   int gray8;          /* 1: gray 8x8 patches use the 4-lanes-per-patch kernel; 0: generic kernel     OFDIS_NO_GRAY8 -> 0 */
   int rgb12;          /* 1: RGB 12x12 patches use the compile-time instantiations                  OFDIS_NO_RGB12 -> 0 */
-  int rgb12_lpp;      /* lanes per RGB 12x12 patch: 0 = the library's choice (exact contract 64, fused contract 16), 64 = one
-                       * patch per wavefront, 32 = two, 16 = four (a 3x3 pixel block per lane; it sums in another order
-                       * than the exact contract documents, so it exists under the fused contract only: the exact contract
-                       * then runs 64)                                                                OFDIS_RGB12_LPP */
+  int rgb12_lpp;      /* lanes per RGB 12x12 patch: 0 = the library's choice (16), 64 = one patch per wavefront, 32 = two,
+                       * 16 = four (a 3x3 pixel block per lane for the taps; the exact contract moves the interpolated
+                       * values through LDS into the entry order its documented summation needs, the fused contract sums
+                       * block-wise)                                                                  OFDIS_RGB12_LPP */
   int fused_tv;       /* 1: gray levels of <= 64 rows take the fused TV path (prep + fused kernel)   OFDIS_NO_FUSED -> 0 */
   int fused_mw_max;   /* frame groups up to which the multi-wave fused TV kernels are launched       OFDIS_FUSED_MW_MAX
                        * (default 512 and at most 1024 frames per batch; 0 = never; >= 2^30 = always) */

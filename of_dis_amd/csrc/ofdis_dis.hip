@@ -871,19 +871,269 @@ __global__ __launch_bounds__(256) void patch_optimize_rgb12_kernel(const DisArgs
   }
 }
 
+// ------------------------------------------------------------------------------------ RGB 12x12, exact contract
+// The same 16-lanes-per-patch mapping for the EXACT contract.  Its sums must run in the documented order for more than 64
+// entries -- 64 strided partials x[l], x[l + 64], ... accumulated in turn, then the butterfly at distance 1, 2, 4, 8, 16, 32
+// (patch_sum<M, 64>, oracle/eigen_shim -DOFDIS_SHIM_WAVE64) -- which is tied to entry indices, not to the 3x3 pixel blocks the
+// taps want.  So an evaluation works in TWO layouts:
+//   A  "blocks": lane (rg, cg) owns the 3x3 pixel block as above: the 12 sixteen-byte tap loads, the interpolation
+//      ((we0 a + we1 b) + we2 c) + we3 d in the reference's order;
+//   B  "chains": lane pl owns the four virtual lanes L = 16 c + pl (c = 0..3) of the one-patch-per-wavefront mapping, i.e.
+//      the entries k = L + 64 m: the template, its gradients, the residual and every sum.  A sum = the four chains
+//      accumulated in turn (m ascending), each reduced over the patch's 16 lanes by the four DPP steps (distance 1, 2, 4, 8
+//      of the documented butterfly), then (s0 + s1) + (s2 + s3): distance 16 and 32, in the operand order of
+//      swap16_sum / swap32_sum.  Same additions in the same order as the generic kernel: same bits.
+// The interpolated values go from A to B through LDS once per evaluation (27 four-byte writes and reads per lane, inside
+// the wavefront: LDS operations of a wavefront execute in order, no barrier).  About 150 instead of 515 instructions per
+// patch and iteration.
+template <int COST>
+__global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const DisArgs a) {
+  constexpr int Q = 4, NV = 432;
+  __shared__ float xl[4 * Q * NV];  // [wavefront][patch][entry]: the A -> B hand-over
+  const LevelGeom& g = a.g;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int blocks_per_frame = (g.nop + 4 * Q - 1) / (4 * Q);
+  int frame, blk;
+  xcd_frame_map(blockIdx.x, blocks_per_frame, a.nframes, frame, blk);
+  if (frame >= a.nframes) return;               // block-uniform
+  if ((blk * 4 + wave) * Q >= g.nop) return;    // wave-uniform: no patch for this wavefront
+  const int sub = lane >> 4, pl = lane & 15;
+  const int rg = pl >> 2, cg = pl & 3;
+  int jp = (blk * 4 + wave) * Q + sub;
+  const bool live = jp < g.nop;
+  if (!live) jp = g.nop - 1;
+  const int gy = jp / g.nopw, gx = jp - gy * g.nopw;
+  float* const xp = xl + (wave * Q + sub) * NV;  // this patch's hand-over vector
+
+  const int tw = g.tmp_w;
+  const size_t plane = g.plane_elems;
+  auto plane_rsrc = [&](const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)frame * plane), 0, (int)(plane * sizeof(float)), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsB = plane_rsrc(a.im_b);
+  const int row_bytes = tw * 12;
+  auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
+  const float rx = (float)(gx * g.steps + g.offw), ry = (float)(gy * g.steps + g.offh);
+  const float fnv = (float)NV, rcp_nv = rcp_refined(fnv);
+  auto div_nv = [&](float x) { return div_by(x, fnv, rcp_nv); };  // == x / 432, correctly rounded (ofdis_dev.h)
+  // layout B: entry i = c * 7 + m of this lane is k = 16 c + pl + 64 m; chain 3 has six entries (k < 432)
+  auto kB = [&](int c, int m) { return 16 * c + pl + 64 * m; };
+  // sum of one value per entry in the documented order (see above): the four chain sums (accumulated by the caller, m
+  // ascending, starting FROM the first entry), each reduced over the patch's 16 lanes, then distance 16 and 32
+  auto finish4 = [&](const float (&sc)[4]) {
+    const float r0 = row16_sum(sc[0]), r1 = row16_sum(sc[1]), r2 = row16_sum(sc[2]), r3 = row16_sum(sc[3]);
+    return (r0 + r1) + (r2 + r3);
+  };
+  auto sumB = [&](const float (&x)[28]) {
+    float sc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float t = x[c * 7];
+#pragma unroll
+      for (int m = 1; m < (c == 3 ? 6 : 7); ++m) t = t + x[c * 7 + m];
+      sc[c] = t;
+    }
+    return finish4(sc);
+  };
+
+  // ---- InitializePatch (patch.cpp:287-332) in layout B
+  float T[28], Tx[28], Ty[28];
+  {
+    const int px = (int)roundf(rx) + g.pad, py = (int)roundf(ry) + g.pad;
+    const float* __restrict__ imA = a.im_a + (size_t)frame * plane;
+    const float* __restrict__ imAx = a.im_a_dx + (size_t)frame * plane;
+    const float* __restrict__ imAy = a.im_a_dy + (size_t)frame * plane;
+    const int base = ((py - 6) * tw + px - 6) * 3;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < 7; ++m) {
+        const int i = c * 7 + m;
+        if (c == 3 && m == 6) { T[i] = Tx[i] = Ty[i] = 0.0f; continue; }
+        const int k = kB(c, m), row = k / 36, col = k - row * 36;
+        const unsigned o = (unsigned)(base + row * tw * 3 + col);
+        T[i] = imA[o]; Tx[i] = imAx[o]; Ty[i] = imAy[o];
+      }
+    if (a.patnorm > 0) {
+      const float mean = div_nv(sumB(T));
+#pragma unroll
+      for (int i = 0; i < 27; ++i) T[i] -= mean;
+    }
+  }
+  // ---- ComputeHessian + Cholesky factor (patch.cpp:71-88, Eigen LLT as in oracle/eigen_shim)
+  float l00, l10, l11;
+  {
+    float sxx[4], sxy[4], syy[4];  // chain sums on the fly (the products are not kept)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < (c == 3 ? 6 : 7); ++m) {
+        const int i = c * 7 + m;
+        const float xx = Tx[i] * Tx[i], xy = Tx[i] * Ty[i], yy = Ty[i] * Ty[i];
+        sxx[c] = m ? sxx[c] + xx : xx;
+        sxy[c] = m ? sxy[c] + xy : xy;
+        syy[c] = m ? syy[c] + yy : yy;
+      }
+    float H00 = finish4(sxx);
+    const float H01 = finish4(sxy);
+    float H11 = finish4(syy);
+    if (H00 * H11 - H01 * H01 == 0.0f) {
+      H00 = (float)((double)H00 + 1e-10);
+      H11 = (float)((double)H11 + 1e-10);
+    }
+    l00 = H00; l10 = H01; l11 = H11;
+    if (!(l00 <= 0.0f)) {
+      l00 = sqrtf(l00);
+      l10 = l10 / l00;
+      const float x = l11 - l10 * l10;
+      if (!(x <= 0.0f)) l11 = sqrtf(x);
+    }
+  }
+  // ---- InitializeFromCoarserOF (patchgrid.cpp:195-211)
+  float pin0 = 0.0f, pin1 = 0.0f;
+  if (a.flow_prev) {
+    const int x = (int)floorf(rx / 2), y = (int)floorf(ry / 2);
+    const int i = y * (g.w / 2) + x;
+    const float* fp = a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2) * 2;
+    pin0 = fp[2 * i] * 2;
+    pin1 = fp[2 * i + 1] * 2;
+  }
+  // ---- OptimizeIter (patch.cpp:159-212)
+  const float r00 = rcp_refined(l00), r11 = rcp_refined(l11);
+  float p0 = pin0, p1 = pin1;
+  float ptx = rx + p0, pty = ry + p1;
+  const float stx = ptx, sty = pty;
+  float dp0 = 0.0f, dp1 = 0.0f;
+  float dpsq = 1e-10f, dpsq_init = 1e-10f, mares = 1e20f, mares_old = 1e20f;
+  float b0 = 0.0f, b1 = 0.0f;
+  int cnt = 0;
+  bool converged = false;
+  float* const pwf = a.pweight + (size_t)frame * g.nop * NV;
+  auto store_pw = [&](const float (&v)[28], bool zero) {  // |residual| of this lane's entries (layout B)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < (c == 3 ? 6 : 7); ++m) {
+        const int k = kB(c, m), row = k / 36;  // (36 floats per patch row: a compile-time divisor)
+        pwf[pweight_row(g, gx, gy, row) + (k - row * 36)] = zero ? 0.0f : fabsf(v[c * 7 + m]);
+      }
+  };
+
+  auto compute_err = [&](bool stop) {  // patch.cpp:264-284, 335-402, 223-262
+    int pos0 = (int)ceilf(ptx + .00001f), pos1 = (int)ceilf(pty + .00001f);
+    const int pos2 = (int)floorf(ptx), pos3 = (int)floorf(pty);
+    const float r0 = ptx - (float)pos2, r1 = pty - (float)pos3;
+    const float we0 = r0 * r1, we1 = (1 - r0) * r1, we2 = r0 * (1 - r1), we3 = (1 - r0) * (1 - r1);
+    pos0 += g.pad;
+    pos1 += g.pad;
+    {  // layout A: the lane's 3x3 pixel block from its 4x4 pixel window, handed over entry by entry
+      const int voff = ((pos1 - 7 + 3 * rg) * tw + pos0 - 7 + 3 * cg) * 12;
+      float W[4][12];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 16 * q, j * row_bytes, 0);
+          const unsigned u0 = t[0], u1 = t[1], u2 = t[2], u3 = t[3];
+          W[j][4 * q] = asf(u0); W[j][4 * q + 1] = asf(u1); W[j][4 * q + 2] = asf(u2); W[j][4 * q + 3] = asf(u3);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // (the previous evaluation's reads of the hand-over vector come first)
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+          xp[(3 * rg + rr) * 36 + 9 * cg + q] =
+              we0 * W[rr + 1][q + 3] + we1 * W[rr + 1][q] + we2 * W[rr][q + 3] + we3 * W[rr][q];  // patch.cpp:391
+      __builtin_amdgcn_wave_barrier();
+    }
+    float v[28];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < 7; ++m) v[c * 7 + m] = (c == 3 && m == 6) ? 0.0f : xp[kB(c, m)];
+    if (a.patnorm > 0) {
+      const float mean = div_nv(sumB(v));
+#pragma unroll
+      for (int i = 0; i < 27; ++i) v[i] -= mean;
+    }
+    float sgx[4], sgy[4], spw[4];  // chain sums on the fly: Tx . r, Ty . r, |r|
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < (c == 3 ? 6 : 7); ++m) {
+        const int i = c * 7 + m;
+        float d = v[i] - T[i];
+        if (COST == 1) d = copysignf(sqrt_rn(fabsf(d)), d);  // L1 (patch.cpp:238-246)
+        v[i] = d;
+        const float gx_ = Tx[i] * d, gy_ = Ty[i] * d, pw_ = fabsf(d);
+        sgx[c] = m ? sgx[c] + gx_ : gx_;
+        sgy[c] = m ? sgy[c] + gy_ : gy_;
+        spw[c] = m ? spw[c] + pw_ : pw_;
+      }
+    b0 = finish4(sgx);
+    b1 = finish4(sgy);
+    dpsq = dp0 * dp0 + dp1 * dp1;
+    if (cnt == 1) dpsq_init = dpsq;
+    mares_old = mares;
+    mares = div_nv(finish4(spw));
+    bool go = (cnt < a.max_iter) && (mares > a.res_thresh);
+    if (go && cnt >= a.min_iter)
+      go = (div_rn(dpsq, dpsq_init) >= a.dp_thresh_sq) && (div_rn(mares, mares_old) <= a.dr_thresh);
+    if (!go | stop) {
+      converged = true;
+      if (live) store_pw(v, false);
+    }
+  };
+  auto oob = [&](float x, float y) { return (x < g.lb) | (y < g.lb) | (x > g.ubw) | (y > g.ubh); };
+
+  if (oob(ptx, pty) || !(isfinite(ptx) && isfinite(pty))) {
+    converged = true;  // OptimizeStart (patch.cpp:120-156): no evaluation, pweight keeps its initial zeros
+    if (live) store_pw(T, true);
+  } else {
+    dpsq = 1e-10f; dpsq_init = 1e-10f; mares = 1e5f; mares_old = 1e20f;
+    compute_err(false);
+  }
+  while (!converged) {
+    cnt++;
+    const float y0 = div_by(b0, l00, r00);
+    const float y1 = div_by(b1 - l10 * y0, l11, r11);
+    dp1 = div_by(y1, l11, r11);
+    dp0 = div_by(y0 - l10 * dp1, l00, r00);
+    p0 -= dp0;
+    p1 -= dp1;
+    ptx = rx + p0;
+    pty = ry + p1;
+    const float ex = stx - ptx, ey = sty - pty;
+    const bool reset = (ex * ex + ey * ey > a.outlier_sq_max) | oob(ptx, pty) | !(isfinite(ptx) & isfinite(pty));
+    p0 = reset ? pin0 : p0;
+    p1 = reset ? pin1 : p1;
+    ptx = rx + p0;
+    pty = ry + p1;
+    compute_err(reset);
+  }
+  if (live && pl == 0) {
+    float* pout = a.p_out + ((size_t)frame * g.nop + patch_slot(g, gx, gy)) * 2;
+    pout[0] = p0;
+    pout[1] = p1;
+  }
+}
+
 // (a template so that the exact contract's object never instantiates the kernel above)
 template <bool FUSED>
 hipError_t launch_patch_optimize_rgb12(const DisArgs& a, hipStream_t s) {
+  const int wpf = (a.g.nop + 3) / 4;  // four patches per wavefront
+  const int blocks_per_frame = (wpf + 3) / 4;
+  const dim3 gd(((a.nframes + 7) / 8) * 8 * blocks_per_frame), bd(256);
   if constexpr (FUSED) {
-    const int wpf = (a.g.nop + 3) / 4;  // four patches per wavefront
-    const int blocks_per_frame = (wpf + 3) / 4;
-    const dim3 gd(((a.nframes + 7) / 8) * 8 * blocks_per_frame), bd(256);
     if (a.costfct == 0) hipLaunchKernelGGL((patch_optimize_rgb12_kernel<0>), gd, bd, 0, s, a);
     else hipLaunchKernelGGL((patch_optimize_rgb12_kernel<1>), gd, bd, 0, s, a);
-    return hipGetLastError();
   } else {
-    return hipErrorInvalidValue;
+    if (a.costfct == 0) hipLaunchKernelGGL((patch_optimize_rgb12x_kernel<0>), gd, bd, 0, s, a);
+    else hipLaunchKernelGGL((patch_optimize_rgb12x_kernel<1>), gd, bd, 0, s, a);
   }
+  return hipGetLastError();
 }
 
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
@@ -896,10 +1146,10 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   // 929 -> 705 instructions per patch and iteration, 82 -> 127 VGPRs).  Measured on configs[3] the same 19.6 +- 0.4 ms per
   // 16-pair level-1 launch either way -- patches that reset early leave their wavefront's other half running alone
   // (PMC: 18 % fewer VALU instructions, same time) -- so one patch per wavefront stays the default.
-  const int rgb12_lpp = tn.rgb12_lpp == 0 ? (kFusedContract ? 16 : 64) : tn.rgb12_lpp;
+  const int rgb12_lpp = tn.rgb12_lpp == 0 ? 16 : tn.rgb12_lpp;
   const bool rgb12 = a.g.novals == 432 && !a.stereo && (a.costfct == 0 || a.costfct == 1) && tn.rgb12;
-  // fused contract: RGB 12x12 has its own mapping (16 lanes per patch, ofdis_tuning::rgb12_lpp = 16: the default there)
-  if (kFusedContract && rgb12 && rgb12_lpp == 16) return launch_patch_optimize_rgb12<kFusedContract>(a, s);
+  // RGB 12x12 has its own mapping (16 lanes per patch, four patches per wavefront: ofdis_tuning::rgb12_lpp = 16, the default)
+  if (rgb12 && rgb12_lpp == 16) return launch_patch_optimize_rgb12<kFusedContract>(a, s);
   const int lpp = (M <= 1) ? (gray8 ? 4 : 8) : ((rgb12 && rgb12_lpp == 32) ? 32 : 64);  // lanes per patch
   const int ppw = 64 / lpp;                           // patches per wavefront
   const int wpf = (a.g.nop + ppw - 1) / ppw;          // wavefronts per frame

@@ -261,12 +261,19 @@ def test_error_behaviour(gpu):
         gpu.Batch(bad, 1)
 
 
-def test_rgb_flow_bit_exact(gpu, orc):
-    """run_OF_RGB path: 3 channels, P=12 (432 values per patch, 7 per lane), L1 cost."""
+@pytest.mark.parametrize("lpp,cost", [(0, 1), (16, 0), (64, 1), (64, 0)])
+def test_rgb_flow_bit_exact(gpu, orc, lpp, cost):
+    """run_OF_RGB path: 3 channels, P=12 (432 values per patch), L1 / L2 cost, with the 16-lanes-per-patch kernel (the
+    default: taps by 3x3 pixel blocks, sums by entry chains after a pass through LDS) and the one-patch-per-wavefront kernel
+    (7 entries per lane): the same documented summation order, the same bits."""
     p, pa, pb, _, _ = synth_case(320, 240, 77, 3, 3, 1)
-    p = p.copy(costfct=1, max_iter=8, min_iter=8)
+    p = p.copy(costfct=cost, max_iter=8, min_iter=8)
     ref = orc.flow(p, pa[0], pa[1], pa[2], pb[0])
-    got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
+    old = gpu.set_tuning(rgb12_lpp=lpp)
+    try:
+        got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
+    finally:
+        gpu.restore_tuning(old)
     assert_bits_equal(got, ref, "rgb flow")
     R = oracle.need_ref("rgb", True)
     if R is not None:

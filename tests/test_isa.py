@@ -72,7 +72,10 @@ def kernels():
 
 # the 1024-thread block SOR (levels of 641 ... 1024 rows: 16 wavefronts of one workgroup on a CU = 128 VGPRs each) is the one
 # kernel allowed to spill; every kernel of the benchmarked configurations must not
-SPILL_OK = ("sor_block_kernelILi3ELi3ELi1024EE",)
+# ... and the exact contract's 16-lanes-per-patch RGB kernel: squeezed into 168 registers for three wavefronts per SIMD it
+# spills 9 of them (40 bytes of scratch) and is still 22 % faster than at 177 registers and two wavefronts (configs[3], exact
+# contract: patch search 119 against 141 ms per 96 pairs; the one-patch-per-wavefront kernel: 153)
+SPILL_OK = ("sor_block_kernelILi3ELi3ELi1024EE", "patch_optimize_rgb12x_kernel")
 
 
 def test_no_kernel_spills_or_uses_scratch(kernels):
@@ -92,6 +95,7 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     ("tv_fused_xcu_kernelILi3ELb1EE", 128, "tv_fused_xcu_kernel<3, true>, cross-CU mapping: one wavefront per SIMD, four workgroups per CU at most"),
     ("patch_optimize_gray8_kernelILi0EE", 128, "gray 8x8 patch kernel: four wavefronts per SIMD"),
     ("patch_optimize_kernelILi7ELi64ELi432ELi1EE", 84, "RGB 12x12 patch kernel, L1 cost: six wavefronts per SIMD"),
+    ("patch_optimize_rgb12x_kernelILi1EE", 168, "RGB 12x12 patch kernel of the exact contract (blocks for the taps, chains for the sums): three wavefronts per SIMD"),
     ("patch_optimize_rgb12_kernelILi1EE", 184, "RGB 12x12 patch kernel of the fused contract (3x3 pixel block per lane): two wavefronts per SIMD"),
     ("tv_fused_kernelILi3ELb1ELi1EE", 184, "tv_fused_kernel<3, true, 1>, iteration-pipelined mapping: two workgroups of n_inner wavefronts per CU"),
     ("densify_kernelILb1EE", 64, "densify_kernel<true>: eight wavefronts per SIMD"),
