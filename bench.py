@@ -856,7 +856,8 @@ def main():
         # profiles/r01_pmc_calibration.txt), collected by tools/pmc_traffic.py for this batch size
         traffic, valu, traffic_note = {}, {}, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            tpath = os.path.join(ROOT, "profiles", f"traffic_{contract}.json")  # (one file per arithmetic contract)
+            tj = json.load(open(tpath if os.path.exists(tpath) else os.path.join(ROOT, "profiles", "traffic.json")))
             # The PMC passes run ONE sub-batch of the headline (rocprofv3 does not survive the counter pass over 16384 pairs):
             # the file is attached only when it was collected on exactly the launches this run makes -- same contract, same
             # TV setting, a PMC batch equal to this run's sub-batch (kernel selection and strip lengths depend on the

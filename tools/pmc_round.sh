@@ -15,7 +15,7 @@ fw=$(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 fs=$(find $OUT/pmc_SQ_INSTS_VALU -name "*counter_collection.csv" | head -1)
 cd $R
 if [ -n "$ff" ] && [ -n "$fw" ]; then
-  python tools/pmc_traffic.py $ff $fw $BATCH on $PASSES "${fs:--}" $CONTRACT > $OUT/traffic.log && cp profiles/traffic.json $OUT/traffic.json
+  python tools/pmc_traffic.py $ff $fw $BATCH on $PASSES "${fs:--}" $CONTRACT > $OUT/traffic.log && cp profiles/traffic_$CONTRACT.json $OUT/traffic_$CONTRACT.json
   for f in $ff $fw $fs; do python tools/pmc_summary.py $f >> $OUT/pmc_sums.txt; done
 fi
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_INSTS_VALU

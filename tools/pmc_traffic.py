@@ -69,5 +69,8 @@ if sq_file:
             out["sustained_clock_ghz"] = round(ghz, 3)
             out["sustained_clock_kernel"] = dom
             out["sustained_clock_source"] = "GRBM_GUI_ACTIVE (sum over 8 XCDs) / 8 / dispatch duration, serialised PMC pass"
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1)
+prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+json.dump(out, open(os.path.join(prof, "traffic_%s.json" % contract), "w"), indent=1)  # one file per arithmetic contract
+if contract == "fused":  # ... and the default name for the contract the headline normally runs under
+    json.dump(out, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 print(json.dumps(out["bytes_per_step"], indent=1))
