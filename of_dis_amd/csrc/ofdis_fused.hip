@@ -102,6 +102,9 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   // (MODE 1 with the derivative rows requested six and the (wx, wy) rows eight steps ahead -- a six-row register ring and a
   // staging ring, 197 VGPRs -- measured 4.30-4.33 against 4.34-4.36 ms on level 3 of the headline: memory latency is not what
   // its steps wait for; not kept)
+  // (MODE 1 with the step loop compiled once per role -- the last iteration's wavefront writes the flow, the others hand their
+  // rows on: 223 instead of 292 instructions per step for the others, 278 for the last -- measured 4.48 against 4.29 ms on the
+  // same box, 4.46 with the roles rotated between the workgroups that share a compute unit: not kept)
   constexpr int PDW = 5, PDD = 3;
   constexpr int PDU = MODE == 2 ? 4 : (MODE == 1 ? 3 : PDW);  // read-ahead of du/dv (MODE 1 / 2: from LDS, in / one step before the step of their first use)
   constexpr int LAG = MODE == 2 ? SP_LAG : MW_LAG;
