@@ -85,10 +85,13 @@ constexpr int SP_MAX_ITERS = 6;  // MODE 2: 2 wavefronts per iteration, 12 per w
 //         iteration's producer through the same LDS ring MODE 1 uses.  A lone wavefront issues one instruction per ~6
 //         clocks (dependent-issue latency), so halving the instructions per wavefront and step nearly halves the step.
 template <int NS, bool BRIGHT, int MODE>
-// (MODE 1 squeezed into 168 registers for three wavefronts per SIMD -- amdgpu_waves_per_eu(3): 7 spilled -- was measured at
-// 5.84 instead of 4.41 ms on level 3 of the headline: not kept)
-__global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * MW_MAX_ITERS : 256)) void tv_fused_kernel(
-    const FusedArgs a, const int R) {
+// MODE 1 is held to 168 registers = three wavefronts per SIMD (amdgpu_waves_per_eu): three workgroups of four iterations per
+// compute unit instead of two.  That only pays without scratch: with the (wx, wy) ring and the run buffer of the wavefront that
+// writes the flow in registers (24 that one of a workgroup's wavefronts uses) the allocator spilled 7 and level 3 of the
+// headline took 5.84 instead of 4.41 ms; with both in LDS (wdring, obring: two ds_write and two ds_read per step of that one
+// wavefront) nothing spills: 4.30-4.34 -> 4.13-4.15 ms on the same box (fused contract; exact: 167 registers, unchanged time).
+__global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * MW_MAX_ITERS : 256))
+__attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(const FusedArgs a, const int R) {
   constexpr int U = 6;
   constexpr bool MW = MODE != 0;
   constexpr int MAXIT = MODE == 2 ? SP_MAX_ITERS : MW_MAX_ITERS;
@@ -96,6 +99,10 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   __shared__ float2 xring[MW ? (MAXIT - 1) * MW_RING * 64 : 1];
   // MODE 2: FSlot of the pixel row handed from an iteration's producer to its solver: [iteration][step & 1][field][lane]
   __shared__ float sring[MODE == 2 ? SP_MAX_ITERS * 2 * SLOT_FLOATS * 64 : 1];
+  // MODE 1: the (wx, wy) ring of the wavefront that writes the flow (Wd below) lives here: twelve registers that only one
+  // of the workgroup's wavefronts uses
+  __shared__ float2 wdring[MODE == 1 ? 6 * 64 : 1];
+  __shared__ float2 obring[MODE == 1 ? 6 * 64 : 1];  // ... and its run buffer (ob below), [lane][column of the run]
   // prefetch distances: the (wx, wy) record (MODE 0: and du, dv) of diag row t+PDW and the derivative record of row
   // t+PDD are requested at step t; first uses are rows t+3 (uu, vv) and t+1 (data term): two steps of slack.  (One step of
   // slack, 128 VGPRs = 4 wavefronts per SIMD, measured the same kernel time: occupancy is not what limits this kernel.)
@@ -194,22 +201,33 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
   // column within the last iteration's pass over the strip this lane finishes in this step (< 0: not there yet).  In a
   // lane's image row the U columns finished since the last flush are consecutive pixels: one 8 U-byte run instead of U
   // scattered 8-byte stores (a run that crosses into the strip's next frame, or the ends of the pass, goes pixel by pixel).
-  auto aos_emit = [&](float2& slot, bool flush, const float2& wq, float du, float dv, int c) {
-    slot = make_float2(wq.x + du, wq.y + dv);
+  auto ob_put = [&](int e, const float2& v) {
+    if constexpr (MODE == 1) obring[lane * U + e] = v;
+    else ob[e] = v;
+  };
+  auto ob_get = [&](int e) -> float2 {
+    if constexpr (MODE == 1) return obring[lane * U + e];
+    else return ob[e];
+  };
+  auto aos_emit = [&](int slot, bool flush, const float2& wq, float du, float dv, int c) {
+    ob_put(slot, make_float2(wq.x + du, wq.y + dv));
     if (flush) {
       const int c0 = c - (U - 1);
       if (row_ok & (c0 >= 0) & (c < rw) & (ox >= U - 1)) {
         typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
         f4a8* d = reinterpret_cast<f4a8*>(flow_row + ooff + ox - (U - 1));
 #pragma unroll
-        for (int e = 0; e < U / 2; ++e) d[e] = f4a8{ob[2 * e].x, ob[2 * e].y, ob[2 * e + 1].x, ob[2 * e + 1].y};
+        for (int e = 0; e < U / 2; ++e) {
+          const float2 p0 = ob_get(2 * e), p1 = ob_get(2 * e + 1);
+          d[e] = f4a8{p0.x, p0.y, p1.x, p1.y};
+        }
       } else if (row_ok & (c >= 0) & (c0 < rw)) {
 #pragma unroll
         for (int e = 0; e < U; ++e) {
           const int ce = c0 + e;
           int xe = ox - (U - 1) + e, oe = ooff;
           if (xe < 0) { xe += w; oe -= npx; }
-          if ((ce >= 0) & (ce < rw)) flow_row[oe + xe] = ob[e];
+          if ((ce >= 0) & (ce < rw)) flow_row[oe + xe] = ob_get(e);
         }
       }
     }
@@ -352,7 +370,10 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
           b1 += sh_c * rdx;
           b2 += sh_c * rdy;
           ldx = rdx; ldy = rdy;
-          if (MODE != 2) Wd[(u + 1) % 6] = make_float2(rc.wx, rc.wy);
+          if constexpr (MODE == 0) Wd[(u + 1) % 6] = make_float2(rc.wx, rc.wy);
+          if constexpr (MODE == 1) {
+            if (it == n_iters - 1) wdring[((u + 1) % 6) * 64 + lane] = make_float2(rc.wx, rc.wy);
+          }
           b1 -= sv_t * (rc.wx - wx_u);
           b2 -= sv_t * (rc.wy - wy_u);
           b1 += sv_c * (wx_d - rc.wx);
@@ -426,14 +447,14 @@ __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * 
             if (row_ok && ig >= 0 && ig < wtot)
               flow_row[ig] = make_float2(asf(q0) + nu[NS - 1], asf(q1) + nv[NS - 1]);
           } else if (MODE == 1 && a.flow_out) {  // last iteration's wavefront: the refined flow, in runs
-            aos_emit(ob[u], u == U - 1, Wd[(u - 2 * (NS - 1) + 12) % 6], nu[NS - 1], nv[NS - 1], ig);
+            aos_emit(u, u == U - 1, wdring[((u - 2 * (NS - 1) + 12) % 6) * 64 + lane], nu[NS - 1], nv[NS - 1], ig);
           } else if (!MW) {
             // (no branch: a lane outside its rows / columns stores at an offset beyond the resource, which the hardware drops)
             const u32x2 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), __builtin_bit_cast(unsigned, nv[NS - 1])};
             const int lastc = ig - (wtot - rw);  // >= 0: this column belongs to the last fixed-point iteration
             const bool on = row_ok & (ig >= 0) & (aos_out ? lastc < 0 : ig < wtot);
             __builtin_amdgcn_raw_buffer_store_b64(v, rsU, on ? vo2 : 0x7ffffff0, srow * h * 8, 0);
-            if (aos_out) aos_emit(ob[u], u == U - 1, Wd[(u - 2 * (NS - 1) + 12) % 6], nu[NS - 1], nv[NS - 1], lastc);
+            if (aos_out) aos_emit(u, u == U - 1, Wd[(u - 2 * (NS - 1) + 12) % 6], nu[NS - 1], nv[NS - 1], lastc);
           } else if (row_ok && ig >= 0 && ig < wtot) {
             const u32x2 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), __builtin_bit_cast(unsigned, nv[NS - 1])};
             __builtin_amdgcn_raw_buffer_store_b64(v, rsU, vo2, srow * h * 8, 0);
