@@ -657,8 +657,12 @@ __device__ __forceinline__ float row16_sum(float x) {  // all-reduce inside a DP
 }
 
 template <int COST>
-__global__ __launch_bounds__(256) void patch_optimize_rgb12_kernel(const DisArgs a) {
+__global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisArgs a) {
   constexpr int Q = 4, NE = 27, NV = 432;  // patches per wavefront, entries per lane, entries per patch
+  // The template's y gradient lives in LDS, [entry / 4][thread] as 16-byte groups (a lane reads its own seven groups once
+  // per evaluation, conflict-free): 27 registers less = 168 without scratch = three wavefronts per SIMD instead of two
+  typedef float f4l __attribute__((ext_vector_type(4)));
+  __shared__ f4l tyl[7 * 256];
   const LevelGeom& g = a.g;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -743,6 +747,9 @@ __global__ __launch_bounds__(256) void patch_optimize_rgb12_kernel(const DisArgs
       if (!(x <= 0.0f)) l11 = sqrtf(x);
     }
   }
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+    tyl[q * 256 + threadIdx.x] = f4l{Ty[4 * q], Ty[4 * q + 1], Ty[4 * q + 2], q < 6 ? Ty[4 * q + 3] : 0.0f};
   // ---- InitializeFromCoarserOF (patchgrid.cpp:195-211)
   float pin0 = 0.0f, pin1 = 0.0f;
   if (a.flow_prev) {
@@ -815,13 +822,21 @@ __global__ __launch_bounds__(256) void patch_optimize_rgb12_kernel(const DisArgs
     }
     float g0 = 0.0f, g1 = 0.0f, sa = 0.0f;
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      float r = d[e];
-      if (COST == 1) r = copysignf(__builtin_amdgcn_sqrtf(fabsf(r)), r);  // L1 (patch.cpp:238-246)
-      d[e] = r;
-      g0 += Tx[e] * r;
-      g1 += Ty[e] * r;
-      sa += fabsf(r);
+    for (int q = 0; q < 7; ++q) {
+      const f4l ty = tyl[q * 256 + threadIdx.x];
+      const float tyq[4] = {ty.x, ty.y, ty.z, ty.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = 4 * q + i;
+        if (e < NE) {
+          float r = d[e];
+          if (COST == 1) r = copysignf(__builtin_amdgcn_sqrtf(fabsf(r)), r);  // L1 (patch.cpp:238-246)
+          d[e] = r;
+          g0 += Tx[e] * r;
+          g1 += tyq[i] * r;
+          sa += fabsf(r);
+        }
+      }
     }
     b0 = row16_sum(g0);
     b1 = row16_sum(g1);

@@ -75,7 +75,10 @@ def kernels():
 # ... and the exact contract's 16-lanes-per-patch RGB kernel: squeezed into 168 registers for three wavefronts per SIMD it
 # spills 9 of them (40 bytes of scratch) and is still 22 % faster than at 177 registers and two wavefronts (configs[3], exact
 # contract: patch search 119 against 141 ms per 96 pairs; the one-patch-per-wavefront kernel: 153)
-SPILL_OK = ("sor_block_kernelILi3ELi3ELi1024EE", "patch_optimize_rgb12x_kernel")
+# ... and the fused contract's: with the template's y gradient in LDS it fits 168 registers for three wavefronts per SIMD
+# except for 2 registers spilled OUTSIDE the iteration loop (template set-up and the final stores; no scratch access between
+# the loop's first and last instruction): configs[3] at 96 pairs 82.4 -> 76.9 ms on one box
+SPILL_OK = ("sor_block_kernelILi3ELi3ELi1024EE", "patch_optimize_rgb12x_kernel", "patch_optimize_rgb12_kernel")
 
 
 def test_no_kernel_spills_or_uses_scratch(kernels):
@@ -96,7 +99,7 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     ("patch_optimize_gray8_kernelILi0EE", 128, "gray 8x8 patch kernel: four wavefronts per SIMD"),
     ("patch_optimize_kernelILi7ELi64ELi432ELi1EE", 84, "RGB 12x12 patch kernel, L1 cost: six wavefronts per SIMD"),
     ("patch_optimize_rgb12x_kernelILi1EE", 168, "RGB 12x12 patch kernel of the exact contract (blocks for the taps, chains for the sums): three wavefronts per SIMD"),
-    ("patch_optimize_rgb12_kernelILi1EE", 184, "RGB 12x12 patch kernel of the fused contract (3x3 pixel block per lane): two wavefronts per SIMD"),
+    ("patch_optimize_rgb12_kernelILi1EE", 168, "RGB 12x12 patch kernel of the fused contract (3x3 pixel block per lane, Ty in LDS): three wavefronts per SIMD"),
     ("tv_fused_kernelILi3ELb1ELi1EE", 168, "tv_fused_kernel<3, true, 1>, iteration-pipelined mapping: three wavefronts per SIMD (three workgroups of four iterations per CU)"),
     ("densify_kernelILb1EE", 64, "densify_kernel<true>: eight wavefronts per SIMD"),
     ("densify_quad_kernel", 64, "densify_quad_kernel: eight wavefronts per SIMD"),
@@ -108,3 +111,38 @@ def test_register_budgets(kernels, pattern, max_vgprs, what):
     assert hits, pattern
     for n, m in hits:
         assert int(m["vgpr_count"]) <= max_vgprs, (what, n, m["vgpr_count"])
+
+
+def test_rgb12_fused_kernel_spills_only_outside_its_iteration_loop():
+    """The fused contract's RGB 12x12 patch kernel is allowed two spilled registers (SPILL_OK above) because no scratch
+    access lies inside its Gauss-Newton loop: checked on the disassembly (largest backward-branch loop of the kernel)."""
+    llvm = _llvm_bin()
+    if llvm is None:
+        pytest.skip("ROCm LLVM tools not found")
+    obj = os.path.join(os.path.dirname(B.lib_path()), "ofdis_dis.fused.o")
+    if not os.path.exists(obj):
+        B.build()
+    tmp = tempfile.mkdtemp()
+    fb, co = os.path.join(tmp, "fatbin"), os.path.join(tmp, "gfx950.co")
+    subprocess.check_call([llvm + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fb])
+    subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fb,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    text = subprocess.run([llvm + "/llvm-objdump", "-d", "--demangle", co], capture_output=True, text=True, check=True).stdout
+    checked = 0
+    for m in re.finditer(r"^[0-9a-f]+ <(void ofdis::fused::patch_optimize_rgb12_kernel<\d>\(ofdis::DisArgs\))>:\n(.*?)(?=^[0-9a-f]+ <|\Z)",
+                         text, flags=re.S | re.M):
+        lines = [l for l in m.group(2).splitlines() if re.search(r"//\s*[0-9A-Fa-f]+:", l)]
+        addr = [int(re.search(r"//\s*([0-9A-Fa-f]+):", l).group(1), 16) for l in lines]
+        loops = []
+        for i, l in enumerate(lines):
+            b = re.match(r"\s+(s_cbranch_\w+|s_branch)\s+(\d+)", l)
+            if b and int(b.group(2)) >= 32768:  # backward branch: target = next instruction + signed 16-bit word offset
+                tgt = addr[i] + 4 + (int(b.group(2)) - 65536) * 4
+                loops.append((i - addr.index(tgt), addr.index(tgt), i))
+        assert loops, m.group(1)
+        _, lo, hi = max(loops)
+        assert hi - lo > 300, (m.group(1), lo, hi)  # the iteration loop, not a short wait loop
+        inside = [l for l in lines[lo:hi + 1] if "scratch_" in l]
+        assert not inside, (m.group(1), inside[:3])
+        checked += 1
+    assert checked == 2, checked  # COST = 0 (L2) and 1 (L1)
