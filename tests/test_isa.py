@@ -146,3 +146,18 @@ def test_rgb12_fused_kernel_spills_only_outside_its_iteration_loop():
         assert not inside, (m.group(1), inside[:3])
         checked += 1
     assert checked == 2, checked  # COST = 0 (L2) and 1 (L1)
+
+
+@pytest.mark.parametrize("pattern,blocks_per_cu,what", [
+    ("tv_fused_kernelILi3ELb1ELi1EE", 3, "iteration-pipelined fused TV: three workgroups of four wavefronts per compute unit"),
+    ("patch_optimize_rgb12_kernelILi1EE", 3, "fused contract's RGB 12x12 patch kernel: three blocks of four wavefronts per compute unit"),
+    ("patch_optimize_rgb12x_kernelILi1EE", 3, "exact contract's RGB 12x12 patch kernel: three blocks of four wavefronts per compute unit"),
+])
+def test_lds_budgets(kernels, pattern, blocks_per_cu, what):
+    """The occupancy these kernels were brought to by moving registers into LDS must not be taken away by the LDS itself
+    (160 KB per compute unit on gfx950)."""
+    names = [n for n in kernels if pattern in n]
+    assert names, pattern
+    for n in names:
+        lds = int(kernels[n]["group_segment_fixed_size"])
+        assert lds * blocks_per_cu <= 160 * 1024, (what, n, lds)
