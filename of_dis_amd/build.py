@@ -125,18 +125,25 @@ def build(force=False, verbose=False):
     vs = _version_script()
     if force or _newer(so, objs + [vs]):
         _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={vs}", "-o", so] + objs, verbose)
-    # host executables (reference CLI contract: run_OF_INT / run_OF_RGB and the stereo-depth run_DE_INT / run_DE_RGB)
+    # host executables: the reference's CLI contract (run_OF_INT / run_OF_RGB and the stereo-depth run_DE_INT / run_DE_RGB,
+    # one pair per process: host/run_dense_main.cpp) and the sequence driver (run_OF_INT_seq / run_OF_RGB_seq: many pairs,
+    # one host thread per GPU: host/run_seq_main.cpp); every other .cpp under host/ is shared by both mains
     host_dir = os.path.join(CSRC, "host")
-    main_cpp = os.path.join(host_dir, "run_dense_main.cpp")
-    if os.path.exists(main_cpp):
-        host_srcs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".cpp")]
+    mains = {"run_dense_main.cpp": (("run_OF_INT", 1, 1), ("run_OF_RGB", 3, 1), ("run_DE_INT", 1, 2), ("run_DE_RGB", 3, 2)),
+             "run_seq_main.cpp": (("run_OF_INT_seq", 1, 1), ("run_OF_RGB_seq", 3, 1))}
+    if os.path.isdir(host_dir):
+        common = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".cpp") and f not in mains]
         host_hdrs = [os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".h")]
-        for name, noc, mode in (("run_OF_INT", 1, 1), ("run_OF_RGB", 3, 1), ("run_DE_INT", 1, 2), ("run_DE_RGB", 3, 2)):
-            exe = os.path.join(LIBDIR, name)
-            if force or _newer(exe, host_srcs + host_hdrs + headers + [so]):
-                _run(["g++", "-O2", "-std=c++17", "-Wall", f"-DOFDIS_NOC={noc}", f"-DOFDIS_MODE={mode}", "-I",
-                      os.path.join(ROOT, "include")]
-                     + host_srcs + ["-o", exe, "-L", LIBDIR, "-lofdis_hip", "-lz", "-Wl,-rpath,$ORIGIN"], verbose)
+        for main_name, exes in mains.items():
+            main_cpp = os.path.join(host_dir, main_name)
+            if not os.path.exists(main_cpp):
+                continue
+            for name, noc, mode in exes:
+                exe = os.path.join(LIBDIR, name)
+                if force or _newer(exe, [main_cpp] + common + host_hdrs + headers + [so]):
+                    _run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", f"-DOFDIS_NOC={noc}", f"-DOFDIS_MODE={mode}", "-I",
+                          os.path.join(ROOT, "include"), main_cpp] + common
+                         + ["-o", exe, "-L", LIBDIR, "-lofdis_hip", "-lz", "-Wl,-rpath,$ORIGIN"], verbose)
     # test-only artefacts: a failure here must not take the product down with it (it is reported, the tests that need
     # them fail on their own)
     try:

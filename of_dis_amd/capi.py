@@ -32,7 +32,9 @@ ABI_SYMBOLS = [
     "ofdis_image_warp", "ofdis_get_derivatives", "ofdis_tv_system", "ofdis_sor_coupled", "ofdis_patchgrid_level",
     "ofdis_varref_level", "ofdis_dev_alloc", "ofdis_dev_free", "ofdis_memcpy_h2d", "ofdis_memcpy_d2h", "ofdis_memcpy_d2d", "ofdis_sync",
     "ofdis_batch_set_graph", "ofdis_batch_status", "ofdis_flow_cache_clear", "ofdis_get_tuning", "ofdis_set_tuning", "ofdis_batch_kernel_times", "ofdis_device_pci_bus_id",
+    "ofdis_batch_upsample_frames",
 ]
+OFDIS_VERSION = 2  # include/ofdis.h: the struct layouts below (OfdisTuning: 16 ints) belong to this ABI version
 
 
 class OfdisTuning(C.Structure):
@@ -57,6 +59,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise OfdisError(f"{LIB_PATH} is missing: run `python -m of_dis_amd.build` (no CPU fallback exists)")
         L = C.CDLL(LIB_PATH)
+        if L.ofdis_version() != OFDIS_VERSION:  # a stale build: ofdis_get_tuning would write past / read garbage from our struct
+            raise OfdisError(f"{LIB_PATH} has ABI version {L.ofdis_version()}, this binding expects {OFDIS_VERSION}: "
+                             "rebuild with `python -m of_dis_amd.build`")
         L.ofdis_last_error.restype = C.c_char_p
         L.ofdis_dev_alloc.restype = VP
         L.ofdis_dev_alloc.argtypes = [C.c_size_t]
@@ -92,6 +97,7 @@ def lib():
         L.ofdis_flow.argtypes = [C.POINTER(OfdisParams)] + [C.POINTER(FP)] * 6 + [FP, FP]
         L.ofdis_params_oppoint.argtypes = [C.POINTER(OfdisParams), C.c_int, C.c_int, C.c_int]
         L.ofdis_batch_upsample.argtypes = [VP, VP, C.c_int, C.c_int, VP]
+        L.ofdis_batch_upsample_frames.argtypes = [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, VP]
         L.ofdis_batch_set_pipeline.argtypes = [VP, C.c_int]
         L.ofdis_batch_join.argtypes = [VP, VP]
         L.ofdis_batch_set_graph.argtypes = [VP, C.c_int]
@@ -361,6 +367,15 @@ class Batch:
         out = np.zeros((self.nframes, height_org, width_org, self.p.nop), _f32)
         d = Dev(nbytes=out.nbytes)
         check(lib().ofdis_batch_upsample(self.h, d.ptr, width_org, height_org, stream))
+        check(lib().ofdis_sync(stream))
+        check(lib().ofdis_memcpy_d2h(out.ctypes.data, d.ptr, out.nbytes))
+        return out
+
+    def upsample_frames(self, first, count, width_org, height_org, stream=None):
+        """ofdis_batch_upsample_frames: the full-resolution flow of frames [first, first + count) as a host array."""
+        out = np.zeros((count, height_org, width_org, self.p.nop), _f32)
+        d = Dev(nbytes=out.nbytes)
+        check(lib().ofdis_batch_upsample_frames(self.h, first, count, d.ptr, width_org, height_org, stream))
         check(lib().ofdis_sync(stream))
         check(lib().ofdis_memcpy_d2h(out.ctypes.data, d.ptr, out.nbytes))
         return out

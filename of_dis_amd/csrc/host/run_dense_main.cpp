@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "cli_params.h"
 #include "image_io.h"
 #include "ofdis.h"
 
@@ -60,36 +61,10 @@ int main(int argc, char** argv) {
   }
   const int width_org = ia.width, height_org = ia.height;
 
-  // *** parameters (run_dense.cpp:225-294)
+  // *** parameters (run_dense.cpp:225-294) and padding to a multiple of 2^lv_f (run_dense.cpp:298-311)
   ofdis_params p;
-  if (argc <= 5) {
-    const int op = (argc == 5) ? atoi(argv[4]) : 2;
-    if (ofdis_params_oppoint(&p, op, width_org, OFDIS_NOC) != OFDIS_OK) {
-      fprintf(stderr, "%s\n", ofdis_last_error());
-      return 1;
-    }
-  } else {
-    if (argc < 24) {
-      fprintf(stderr, "need all 20 parameters (README.md:57-88), got %d\n", argc - 4);
-      return 2;
-    }
-    ofdis_params_oppoint(&p, 2, width_org, OFDIS_NOC);
-    int k = 4;
-    p.sc_f = atoi(argv[k++]); p.sc_l = atoi(argv[k++]);
-    p.max_iter = atoi(argv[k++]); p.min_iter = atoi(argv[k++]);
-    p.dp_thresh = (float)atof(argv[k++]); p.dr_thresh = (float)atof(argv[k++]); p.res_thresh = (float)atof(argv[k++]);
-    p.p_samp_s = atoi(argv[k++]); p.patove = (float)atof(argv[k++]);
-    p.usefbcon = atoi(argv[k++]); p.patnorm = atoi(argv[k++]); p.costfct = atoi(argv[k++]); p.usetvref = atoi(argv[k++]);
-    p.tv_alpha = (float)atof(argv[k++]); p.tv_gamma = (float)atof(argv[k++]); p.tv_delta = (float)atof(argv[k++]);
-    p.tv_innerit = atoi(argv[k++]); p.tv_solverit = atoi(argv[k++]); p.tv_sor = (float)atof(argv[k++]);
-    p.verbosity = atoi(argv[k++]);
-    p.imgpadding = p.p_samp_s;
-  }
-  p.selectmode = OFDIS_MODE;
-  // *** pad to a multiple of 2^lv_f (run_dense.cpp:298-311)
-  const int scfct = 1 << p.sc_f;
-  p.width = width_org + (scfct - width_org % scfct) % scfct;
-  p.height = height_org + (scfct - height_org % scfct) % scfct;
+  if (int st = ofdis_host::parse_params(argc, argv, 4, width_org, OFDIS_NOC, OFDIS_MODE, &p)) return st;
+  ofdis_host::pad_size(&p, width_org, height_org);
   const int verbosity = p.verbosity;
   if (verbosity > 1) printf("TIME (Image loading     ) (ms): %3g\n", now_ms() - t_start);
 

@@ -217,6 +217,7 @@ struct XcuState {
   std::atomic<bool> off{false};        // the variant is off for this context
   std::atomic<bool> failed{false};     // the results of the last pass are invalid (until the next pass starts)
   std::atomic<bool> told_sync{false};  // ofdis_sync has reported the failure (it does so once; status / download keep saying it)
+  std::atomic<bool> missed{false};     // a pass failed and the NEXT pass was started before anybody polled: reported once, late
   std::atomic<bool> rezero{false};     // the granule array may hold stale tags
   std::atomic<hipStream_t> last_stream{nullptr};  // where the last pass was enqueued (ofdis_sync polls the contexts of its stream)
   std::atomic<bool> ran{false};
@@ -263,6 +264,7 @@ struct ofdis_batch {
   hipGraphExec_t graph_exec = nullptr;
   const float* graph_initflow = nullptr; // the warm-start pointer the captured graph was built with
   unsigned graph_epoch = 0;              // ... and the state of the kernel-selection knobs (ofdis_set_tuning)
+  bool graph_xcu_off = false;            // ... and whether the cross-CU fused TV variant was already off for this context
   hipStream_t cap_stream = nullptr;      // capture stream
   // sub-batches on internal streams (ofdis_batch_run)
   std::vector<hipStream_t> sub_streams;  // streams of sub-batches 1..S-1 (sub-batch 0 runs on the caller's stream)
@@ -370,17 +372,28 @@ int xcu_poll(ofdis_batch* b) {
   if (x->failed)
     return fail(OFDIS_ERR_DEVICE, "fused TV kernel (cross-CU variant): a hand-over row never arrived; the results of this pass are "
                                   "invalid -- run the context again (it no longer uses the variant)");
+  if (x->missed.exchange(false))  // said once: whoever consumed the earlier pass's results without asking learns it here
+    return fail(OFDIS_ERR_DEVICE, "fused TV kernel (cross-CU variant): an EARLIER pass of this context lost a hand-over row and "
+                                  "was never polled; its results were invalid (the pass since then ran without the variant)");
   return OFDIS_OK;
 }
 int xcu_begin_pass(ofdis_batch* b, hipStream_t s) {
   XcuState* x = b->xcu;
   if (!x) return OFDIS_OK;
-  if (*(volatile int*)x->host) (void)xcu_poll(b);  // a failure nobody has polled yet: the variant goes off all the same
+  if (*(volatile int*)x->host) {  // a failure nobody has polled yet: the variant goes off all the same, and the failure
+    (void)xcu_poll(b);            // stays latched (`missed`) until one synchronising route has reported it
+    x->missed = true;
+  }
   x->failed = false;
   x->told_sync = false;
   x->last_stream = s;
   x->ran = true;
   if (x->rezero && b->xbuf) {  // stale tags of the pass that failed
+    // (a previous pipelined pass leaves its sub-streams unjoined on purpose; they may still be using the granules)
+    if (b->join_pending) {
+      for (hipEvent_t ev : b->sub_done) HIPCHK(hipStreamWaitEvent(s, ev, 0));
+      b->join_pending = false;
+    }
     HIPCHK(hipMemsetAsync(b->xbuf, 0, b->xbuf_per_frame * b->total_frames * sizeof(float), s));
     x->rezero = false;
   }
@@ -1071,7 +1084,11 @@ int run_graph_or_levels(ofdis_batch* b, hipStream_t s) {
   const bool want = b->graph_mode != 0 && !env_off && !b->timing && b->p.verbosity == 0 && (b->graph_mode == 1 || b->runs >= 1);
   b->runs++;
   if (!want) return run_levels(b, s);
-  if (b->graph_exec && (b->graph_initflow != b->initflow || b->graph_epoch != epoch)) {  // the knobs are baked into the capture
+  // the kernel selection is baked into the capture: the knobs (epoch), the warm-start pointer, and -- per context -- whether
+  // the cross-CU fused TV variant is still allowed (a context that has seen a lost hand-over must not replay a graph that
+  // still contains tv_fused_xcu_kernel: "run again" has to run the other kernel)
+  const bool xcu_off = b->xcu && b->xcu->off;
+  if (b->graph_exec && (b->graph_initflow != b->initflow || b->graph_epoch != epoch || b->graph_xcu_off != xcu_off)) {
     (void)hipGraphExecDestroy(b->graph_exec);
     b->graph_exec = nullptr;
   }
@@ -1097,6 +1114,7 @@ int run_graph_or_levels(ofdis_batch* b, hipStream_t s) {
     }
     b->graph_initflow = b->initflow;
     b->graph_epoch = epoch;
+    b->graph_xcu_off = xcu_off;
   }
   HIPCHK(hipGraphLaunch(b->graph_exec, s));
   return OFDIS_OK;
@@ -1152,16 +1170,24 @@ int ofdis_batch_upload_initflow(ofdis_batch* b, int frame, const float* initflow
   return OFDIS_OK;
 }
 
-int ofdis_batch_upsample(ofdis_batch* b, float* out_dev, int width_org, int height_org, void* stream) {
+int ofdis_batch_upsample_frames(ofdis_batch* b, int first_frame, int count, float* out_dev, int width_org,
+                                int height_org, void* stream) {
   if (!b || !out_dev) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  if (first_frame < 0 || count < 1 || first_frame > b->nframes - count) return fail(OFDIS_ERR_INVALID, "frame range outside the batch");
   const ofdis_params& p = b->p;
   if (width_org < 1 || height_org < 1 || width_org > p.width || height_org > p.height)
     return fail(OFDIS_ERR_INVALID, "original size exceeds the padded size");
   const LevelGeom& g = b->geom[0];
   if (int rc = ofdis_batch_join(b, stream)) return rc;
-  HIPCHK(launch_upsample_crop(b->flow[0], out_dev, b->nframes, g.w, g.h, p.sc_l, (p.width - width_org) / 2,
-                              (p.height - height_org) / 2, width_org, height_org, b->nop, (hipStream_t)stream));
+  HIPCHK(launch_upsample_crop(b->flow[0] + (size_t)first_frame * g.w * g.h * b->nop, out_dev, count, g.w, g.h, p.sc_l,
+                              (p.width - width_org) / 2, (p.height - height_org) / 2, width_org, height_org, b->nop,
+                              (hipStream_t)stream));
   return OFDIS_OK;
+}
+
+int ofdis_batch_upsample(ofdis_batch* b, float* out_dev, int width_org, int height_org, void* stream) {
+  if (!b) return fail(OFDIS_ERR_INVALID, "bad arguments");
+  return ofdis_batch_upsample_frames(b, 0, b->nframes, out_dev, width_org, height_org, stream);
 }
 
 int ofdis_batch_timing(ofdis_batch* b, int enable) {

@@ -28,7 +28,16 @@ def test_library_exports_every_declared_symbol():
     L = capi.lib()
     for name in _declared_functions():
         assert hasattr(L, name), f"{name} declared in include/ofdis.h but not exported"
-    assert L.ofdis_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "ofdis.h")).read()
+    assert L.ofdis_version() == capi.OFDIS_VERSION == int(re.search(r"#define OFDIS_VERSION (\d+)", hdr).group(1))
+
+
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
+    """The struct layouts of the binding belong to one ABI version: a stale libofdis_hip.so must not be handed our structs."""
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "OFDIS_VERSION", capi.OFDIS_VERSION + 1)
+    with pytest.raises(capi.OfdisError, match="ABI version"):
+        capi.lib()
 
 
 def test_library_exports_nothing_but_the_header():

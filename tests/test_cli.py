@@ -194,3 +194,92 @@ def test_c_program_through_the_abi(gpu, tmp_path):
         r = subprocess.run([os.path.join(LIB, "dropin_test"), path, "5"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (name, r.stdout, r.stderr)
         assert "OK" in r.stdout and "identical" in r.stdout, r.stdout
+
+
+# ------------------------------------------------------------------------------------------------ sequence driver
+SEQ = {1: os.path.join(LIB, "run_OF_INT_seq"), 3: os.path.join(LIB, "run_OF_RGB_seq")}
+
+
+def test_sequence_driver_usage_and_bad_lists(tmp_path):
+    for exe in SEQ.values():
+        assert os.path.exists(exe), f"{exe} missing: python -m of_dis_amd.build"
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "pairs.txt" in r.stderr
+    lst = tmp_path / "bad.txt"
+    lst.write_text("only_two fields\n")
+    r = subprocess.run([SEQ[1], str(lst)], capture_output=True, text=True)
+    assert r.returncode == 2 and "expected" in r.stderr
+    lst.write_text("# nothing\n\n")
+    r = subprocess.run([SEQ[1], str(lst)], capture_output=True, text=True)
+    assert r.returncode == 1 and "no pairs" in r.stderr
+    r = subprocess.run([SEQ[1], str(tmp_path / "missing.txt")], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot read" in r.stderr
+
+
+def _write_pairs(tmp_path, n, w, h, channels=1, seed0=500):
+    pairs = []
+    for k in range(n):
+        ia, ib, _ = gen_synth.make_pair(w, h, seed0 + k, channels=channels)
+        ext = "pgm" if channels == 1 else "ppm"
+        fa, fb = str(tmp_path / f"a{k:03d}.{ext}"), str(tmp_path / f"b{k:03d}.{ext}")
+        gen_synth.write_pgm(fa, ia if channels == 1 else ia[..., ::-1])
+        gen_synth.write_pgm(fb, ib if channels == 1 else ib[..., ::-1])
+        pairs.append((fa, fb))
+    return pairs
+
+
+@pytest.mark.gpu
+def test_sequence_driver_matches_the_single_pair_binary(gpu, tmp_path):
+    """SURVEY 8(e) in the host language of the reference: run_OF_INT_seq over 66 pairs (a chunk size that does not divide the
+    share: the last chunk is short) writes, pair for pair, the BYTES the single-pair run_OF_INT writes (exact contract: the
+    chunk context runs other kernel mappings than the one-pair context, same bits); the split over two shares (--devices 0,0:
+    both on the one GPU of the test box, two host threads, two contexts) and another chunk size give the same files."""
+    w, h, n = 320, 192, 66
+    pairs = _write_pairs(tmp_path, n, w, h)
+    single = []
+    for k, (fa, fb) in enumerate(pairs):
+        fo = str(tmp_path / f"single{k:03d}.flo")
+        r = subprocess.run([EXE[1], fa, fb, fo] + "5 3 12 12 0.05 0.95 0 8 0.40 0 1 0 1 10 10 5 1 3 1.6 0".split(),
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        single.append(open(fo, "rb").read())
+    args = "5 3 12 12 0.05 0.95 0 8 0.40 0 1 0 1 10 10 5 1 3 1.6 1".split()
+    for tag, opts in (("one", ["--chunk", "32"]), ("two", ["--devices", "0,0", "--chunk", "20"])):
+        lst = tmp_path / f"{tag}.txt"
+        lst.write_text("# pairs of the test\n" + "".join(f"{fa} {fb} {tmp_path}/{tag}{k:03d}.flo\n" for k, (fa, fb) in enumerate(pairs)))
+        r = subprocess.run([SEQ[1], str(lst)] + opts + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        assert f"TIME ({n} pairs on {1 if tag == 'one' else 2} device share(s)" in r.stdout
+        for k in range(n):
+            got = open(tmp_path / f"{tag}{k:03d}.flo", "rb").read()
+            assert got == single[k], f"{tag}: pair {k} differs from the single-pair binary's .flo"
+    # and against the oracle's pipeline, so that "the same" is also "right" (first and last pair)
+    p = oppoint(2, w, h).copy(sc_f=5, sc_l=3)
+    for k in (0, n - 1):
+        ia, ib, _ = gen_synth.make_pair(w, h, 500 + k)
+        assert_bits_equal(read_flo(tmp_path / f"one{k:03d}.flo"), _oracle_flo(ia, ib, p, w, h), f"pair {k} vs oracle pipeline")
+
+
+@pytest.mark.gpu
+def test_sequence_driver_rgb_and_unreadable_pairs(gpu, tmp_path):
+    """run_OF_RGB_seq (operating point by number); a pair whose image is missing or has another size is reported, the others
+    are still written, and the exit status says that not everything went through."""
+    w, h, n = 256, 128, 5
+    pairs = _write_pairs(tmp_path, n, w, h, channels=3, seed0=700)
+    ia, ib, _ = gen_synth.make_pair(128, 128, 800, channels=3)
+    gen_synth.write_pgm(str(tmp_path / "odd_a.ppm"), ia[..., ::-1])
+    gen_synth.write_pgm(str(tmp_path / "odd_b.ppm"), ib[..., ::-1])
+    lines = [f"{fa} {fb} {tmp_path}/o{k}.flo" for k, (fa, fb) in enumerate(pairs)]
+    lines.insert(2, f"{tmp_path}/nope.ppm {pairs[0][1]} {tmp_path}/nope.flo")
+    lines.insert(4, f"{tmp_path}/odd_a.ppm {tmp_path}/odd_b.ppm {tmp_path}/odd.flo")
+    lst = tmp_path / "rgb.txt"
+    lst.write_text("\n".join(lines) + "\n")
+    r = subprocess.run([SEQ[3], str(lst), "--chunk", "3", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, (r.stdout, r.stderr)
+    assert "nope.ppm" in r.stderr and "like the first pair" in r.stderr
+    assert not os.path.exists(tmp_path / "nope.flo") and not os.path.exists(tmp_path / "odd.flo")
+    for k, (fa, fb) in enumerate(pairs):
+        fo = str(tmp_path / f"s{k}.flo")
+        r1 = subprocess.run([EXE[3], fa, fb, fo, "3"], capture_output=True, text=True, timeout=120)
+        assert r1.returncode == 0, r1.stderr
+        assert open(fo, "rb").read() == open(tmp_path / f"o{k}.flo", "rb").read(), f"rgb pair {k}"

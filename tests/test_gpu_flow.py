@@ -74,9 +74,13 @@ def test_upsample_crop_on_device(gpu, orc, size, opp):
     b.run()
     low = b.download_all()
     full = b.upsample(w, h)
+    last = b.upsample_frames(1, 1, w, h)  # ofdis_batch_upsample_frames: a frame range of the same result
+    with pytest.raises(gpu.OfdisError):
+        b.upsample_frames(1, 2, w, h)     # range outside the batch
     b.close()
     for k in range(2):
         assert_bits_equal(full[k], orc.upsample_crop(p, low[k], w, h), f"full-resolution flow, frame {k}")
+    assert_bits_equal(last[0], full[1], "upsample_frames(1, 1) == frame 1 of the whole-batch upsample")
 
 
 @pytest.mark.parametrize("mode", [-1, 0, 1])

@@ -201,3 +201,57 @@ def test_beside_a_second_process(gpu, cases):
     finally:
         load.kill()
         load.wait()
+
+
+def test_graph_replay_is_recaptured_after_a_lost_handover(gpu, cases):
+    """ofdis_batch_set_graph(1): the captured launch graph contains the cross-CU kernel.  After a lost hand-over the context
+    must not replay that graph ("run again" has to run WITHOUT the variant): the second pass is exact and reports success,
+    and so is a third one (the re-captured graph)."""
+    cs, refs = cases
+    p = cs[0][0]
+    L = gpu.lib()
+    old = gpu.set_tuning(fused_xcu_max=1 << 30, fused_xcu_spin=1, graph=1)
+    try:
+        b = gpu.Batch(p, 6)
+        _fill(b, cs, 6)
+        gpu.check(L.ofdis_sync(None))
+        b.set_graph(1)
+        b.run()
+        assert L.ofdis_sync(None) == ERR_DEVICE, "the captured pass must report the lost hand-over"
+        for rep in range(2):
+            b.run()
+            assert L.ofdis_sync(None) == 0, f"pass {rep} after the failure replayed a graph that still uses the variant"
+            assert b.status() == 0
+            out = b.download_all()
+            for slot in range(6):
+                assert_bits_equal(out[slot], refs[slot % 2], f"graph mode, pass {rep} after the failure, slot {slot}")
+        b.close()
+    finally:
+        gpu.restore_tuning(old)
+
+
+def test_failure_nobody_polled_is_reported_late_once(gpu, cases):
+    """A pass loses a hand-over, the caller synchronises through HIP directly (no ofdis_* poll) and starts the next pass: the
+    earlier failure must not be swallowed -- the next synchronising route reports it once -- and the pass after that is clean."""
+    cs, refs = cases
+    p = cs[0][0]
+    L = gpu.lib()
+    hip = _hip()
+    old = gpu.set_tuning(fused_xcu_max=1 << 30, fused_xcu_spin=1)
+    try:
+        b = gpu.Batch(p, 4)
+        _fill(b, cs, 4)
+        gpu.check(L.ofdis_sync(None))
+        b.run()
+        assert hip.hipDeviceSynchronize() == 0     # the caller's own synchronisation: nobody asked the library
+        b.run()                                    # the variant is off now; the earlier pass's failure stays latched
+        assert L.ofdis_sync(None) == ERR_DEVICE and b"EARLIER" in L.ofdis_last_error()
+        assert b.status() == 0, "said once"
+        out = b.download_all()                     # ... and this pass's results are the right ones
+        for slot in range(4):
+            assert_bits_equal(out[slot], refs[slot % 2], f"slot {slot}")
+        b.run()
+        assert L.ofdis_sync(None) == 0
+        b.close()
+    finally:
+        gpu.restore_tuning(old)
