@@ -43,11 +43,12 @@ def fused(gpu):
 
 
 def _plain_ref(kind):
-    """The plain (sequential-sum) reference build.  Missing is a failure, not a skip: the tolerance contract has no other
-    anchor (oracle/_ref ships with the repository snapshot; in the authoring container it is built from /root/reference)."""
+    """The plain (sequential-sum) reference build: the only anchor the tolerance contract has, so a missing one FAILS the test
+    (oracle.need_ref already raises where the build is expected -- /root/reference or a shipped oracle/_ref exists; a box that
+    has neither cannot check this contract at all, and saying "passed" or "skipped" there would hide that)."""
     R = oracle.need_ref(kind, False)
-    if R is None:
-        pytest.skip("comparison against the compiled reference skipped: neither /root/reference nor oracle/_ref exists here")
+    assert R is not None, (f"the plain reference build oracle/_ref/libofdis_ref_{kind}.so is not on this machine: the fused "
+                           "contract cannot be checked (build it where /root/reference exists: make -C oracle)")
     return R
 
 
@@ -137,6 +138,41 @@ def test_fused_contract_batch_of_pairs(gpu, orc):
         assert np.array_equal(fu[slot], fu[slot % 4]), "a frame's result depends on its slot"
 
 
+@pytest.mark.parametrize("strip", [1, 2, 4, 8])
+def test_fused_contract_production_mappings_against_the_plain_reference(gpu, orc, strip):
+    """The kernel mappings the HEADLINE runs (bench.py: 16384 pairs as two sub-batches of 8192) forced on a 64-pair batch and
+    compared with the PLAIN reference build itself -- not with another mapping: no small-batch variants (fused_mw_max = 0,
+    fused_xcu_max = 0), the library's throughput rule fused_tp_pipe = 1 (level 3, 56 rows: the iteration-pipelined kernel, a
+    wavefront per fixed-point iteration over strips; levels 4 / 5: one wavefront per strip walking all iterations) and the
+    strip lengths those launches use (8 on level 3, 1-2 on levels 4 / 5 at 8192 pairs; 4 for smaller sub-batches), full
+    strips of distinct frames.  Every one of the 64 frames: mean < 1e-4 px and max < 1e-3 px on the full-resolution flow."""
+    cases = [synth_case(1024, 436, 3500 + k, 1, 2, 1) for k in range(8)]   # a strip of 8 holds 8 different frames
+    p = cases[0][0]
+    R = _plain_ref("int")
+    refs = [_full_res(orc, p, R.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]), 1024, 436) for c in cases]
+    old = gpu.set_tuning(contract=1, fused_tp_pipe=1, fused_mw_max=0, fused_xcu_max=0, fused_strip=strip)
+    try:
+        b = gpu.Batch(p, 64)
+        for slot in range(64):
+            c = cases[(slot + slot // 8) % 8]   # (every strip starts with another frame)
+            b.upload(slot, c[1][0], c[1][1], c[1][2], c[2][0])
+        b.run()
+        out = b.download_all()
+        full = b.upsample(1024, 436)
+        b.close()
+    finally:
+        gpu.restore_tuning(old)
+    worst = (0.0, 0.0)
+    for slot in range(64):
+        k = (slot + slot // 8) % 8
+        st = oracle.epe_stats(full[slot], refs[k])
+        worst = (max(worst[0], st[0]), max(worst[1], st[1]))
+        assert st[0] < MEAN_BAR and st[1] < MAX_BAR, f"strip {strip}, slot {slot} (frame {k}): mean {st[0]:.2e} max {st[1]:.2e} px"
+        # the device's upsample of this context == the oracle's restatement applied to its level flow (the .flo route)
+        assert np.array_equal(full[slot], _full_res(orc, p, out[slot], 1024, 436))
+    print(f"production mappings, strips of {strip}: worst frame mean {worst[0]:.2e} max {worst[1]:.2e} px vs the plain reference")
+
+
 @pytest.mark.parametrize("size,channels,opp,seed", [((1024, 436), 1, 2, 11), ((640, 480), 1, 2, 12), ((333, 251), 1, 1, 13),
                                                     ((320, 240), 3, 3, 14), ((256, 128), 1, 2, 15)])
 def test_fused_contract_block_world(gpu, orc, size, channels, opp, seed):
@@ -187,22 +223,27 @@ def test_fused_contract_rgb(gpu, orc, lpp, cost):
 
 
 @pytest.mark.slow
-def test_fused_contract_config4_tail(gpu, orc):
+@pytest.mark.parametrize("seed", [4242, 4243, 4244])
+def test_fused_contract_config4_tail(gpu, orc, seed):
     """BASELINE configs[3] (run_OF_RGB 1920x1080, L1 cost, 50 iterations, TV on).  Fifty L1 iterations amplify ANY rounding
-    difference -- the exact contract itself differs from the plain reference build by max 0.029 px on this frame (0.6 % of
-    the pixels above 1e-3 px) through the summation order alone -- so here the north star's bar is asserted as stated (mean
-    EPE < 1e-3 px) and the tail of both contracts is reported side by side."""
-    p, pa, pb, _, _ = synth_case(1920, 1080, 4242, 3, 4, 1)
+    difference -- the exact contract itself differs from the plain reference build by max 0.02-0.03 px (0.2-0.6 % of the
+    pixels above 1e-3 px) through the summation order alone -- so the absolute part of the bar is the north star's as stated
+    (mean EPE < 1e-3 px, in fact < 1e-4), and the TAIL of the fused contract is held to the criterion every other chaotic case
+    of this file uses: no more than 3 x the exact contract's own tail against the same plain reference, in the fraction of
+    pixels above 1e-3 px and in the largest error.  Three frames (seeds)."""
+    p, pa, pb, _, _ = synth_case(1920, 1080, seed, 3, 4, 1)
     p = p.copy(costfct=1, max_iter=50, min_iter=50)
     ref = _plain_ref("rgb").flow(p, pa[0], pa[1], pa[2], pb[0])
     ex, fu = _both_contracts(gpu, lambda: gpu.flow(p, pa[0], pa[1], pa[2], pb[0]))
     rf = _full_res(orc, p, ref, 1920, 1080)
     se = oracle.epe_stats(_full_res(orc, p, ex, 1920, 1080), rf)
     sf = oracle.epe_stats(_full_res(orc, p, fu, 1920, 1080), rf)
-    msg = (f"configs[3]: fused mean {sf[0]:.2e} max {sf[1]:.2e} frac>1e-3 {sf[2]:.2e} | exact mean {se[0]:.2e} max {se[1]:.2e} "
-           f"frac>1e-3 {se[2]:.2e}")
+    msg = (f"configs[3] seed {seed}: fused mean {sf[0]:.2e} max {sf[1]:.2e} frac>1e-3 {sf[2]:.2e} | exact mean {se[0]:.2e} "
+           f"max {se[1]:.2e} frac>1e-3 {se[2]:.2e}")
     print(msg)
-    assert sf[0] < 1e-3, msg
+    assert sf[0] < MEAN_BAR and se[0] < MEAN_BAR, msg
+    assert sf[2] < max(1e-3, 3 * se[2]), msg   # fraction of pixels above 1e-3 px: within 3 x the exact contract's
+    assert sf[1] < max(MAX_BAR, 3 * se[1]), msg  # largest error: within 3 x the exact contract's
     assert sf[1] < 0.25, msg   # (no pixel jumps to another local minimum)
 
 

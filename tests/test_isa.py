@@ -161,3 +161,22 @@ def test_lds_budgets(kernels, pattern, blocks_per_cu, what):
     for n in names:
         lds = int(kernels[n]["group_segment_fixed_size"])
         assert lds * blocks_per_cu <= 160 * 1024, (what, n, lds)
+
+
+def test_committed_isa_counts_match_the_build():
+    """profiles/isa_counts.json (bench.py prices the RGB patch search of BASELINE configs[3] against the VALU issue peak with
+    these loop instruction counts) must be what tools/isa_count.py finds in the library that ships."""
+    import json
+    import sys
+    if _llvm_bin() is None:
+        pytest.skip("ROCm LLVM tools not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import isa_count
+    if not os.path.exists(B.lib_path()):
+        B.build()
+    now = isa_count.profile_counts(os.path.dirname(B.lib_path()))
+    committed = json.load(open(os.path.join(root, "profiles", "isa_counts.json")))
+    assert set(now) == set(isa_count.PROFILE_KERNELS), sorted(now)
+    for key, c in now.items():
+        assert committed[key] == c, (key, committed[key], c, "refresh with: python tools/isa_count.py --write-profile")

@@ -98,7 +98,7 @@ def valu_class(op, args, nbytes):
     return "plain"
 
 
-def summarize(name, body):
+def summarize(name, body, quiet=False):
     ins = [p for p in (parse(l) for l in body) if p]
     addr = {a: i for i, (_, _, a, _) in enumerate(ins)}
     best = None
@@ -115,9 +115,16 @@ def summarize(name, body):
                     if best is None or span[1] - span[0] > best[1] - best[0]:
                         best = span
     if best is None:
-        print(name, ": no loop found,", len(ins), "instructions")
-        return
+        if not quiet:
+            print(name, ": no loop found,", len(ins), "instructions")
+        return None
     loop = ins[best[0]:best[1] + 1]
+    if quiet:
+        c = {}
+        for op, args, a, n in loop:
+            c[classify(op)] = c.get(classify(op), 0) + 1
+        return {"loop_instructions": len(loop), "loop_valu": c.get("valu", 0), "loop_vmem": c.get("vmem", 0),
+                "loop_lds": c.get("lds", 0), "loop_salu": c.get("salu", 0)}
     c = {}
     v8 = dpp = trans = 0
     ops = {}
@@ -148,7 +155,41 @@ def summarize(name, body):
           f"; paired-issue lower bound {est:.0f} clocks per loop pass")
 
 
+# the kernels whose iteration loops bench.py prices against the VALU issue peak (static counts of the SHIPPED objects):
+# key -> (object file, kernel name as disassembled, patches per wavefront)
+PROFILE_KERNELS = {
+    "patch_optimize_rgb12_fused": ("ofdis_dis.fused.o", "ofdis::fused::patch_optimize_rgb12_kernel<1>(", 4),
+    "patch_optimize_rgb12_exact": ("ofdis_dis.o", "ofdis::exact::patch_optimize_rgb12x_kernel<1>(", 4),
+    "patch_optimize_gray8_fused": ("ofdis_dis.fused.o", "ofdis::fused::patch_optimize_gray8_kernel<0>(", 16),
+    "patch_optimize_gray8_exact": ("ofdis_dis.o", "ofdis::exact::patch_optimize_gray8_kernel<0>(", 16),
+}
+
+
+def profile_counts(libdir):
+    """{key: {kernel, patches_per_wavefront, loop_instructions, ...}} for PROFILE_KERNELS (profiles/isa_counts.json)."""
+    out, cache = {}, {}
+    for key, (obj, kname, ppw) in PROFILE_KERNELS.items():
+        if obj not in cache:
+            cache[obj] = list(kernels(disasm(code_object(os.path.join(libdir, obj)))))
+        for name, body in cache[obj]:
+            if kname in name:
+                c = summarize(name, body, quiet=True)
+                if c:
+                    out[key] = dict(kernel=name.split("(")[0].replace("void ", ""), patches_per_wavefront=ppw, **c)
+    return out
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--write-profile":  # python tools/isa_count.py --write-profile  ->  profiles/isa_counts.json
+        import json
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        d = profile_counts(os.path.join(root, "of_dis_amd", "lib"))
+        d["sustained_clock_ghz"] = 2.157  # profiles/traffic_fused.json: GRBM_GUI_ACTIVE / dispatch duration under this load
+        d["what"] = ("instructions of one pass of the iteration loop (largest backward-branch loop) of the shipped code objects, "
+                     "tools/isa_count.py; tests/test_isa.py checks that the file matches the build")
+        json.dump(d, open(os.path.join(root, "profiles", "isa_counts.json"), "w"), indent=1, sort_keys=True)
+        print(json.dumps(d, indent=1, sort_keys=True))
+        sys.exit(0)
     co = code_object(sys.argv[1])
     text = disasm(co)
     pats = sys.argv[2:]
