@@ -29,6 +29,7 @@ namespace {
 // launches through its table.
 struct Launchers {
   decltype(&exact::launch_patch_optimize) patch_optimize;
+  decltype(&exact::patch_pixel_weights_supported) patch_pixel_weights_supported;
   decltype(&exact::launch_densify) densify;
   decltype(&exact::launch_patch_p_reference_order) patch_p_reference_order;
   decltype(&exact::launch_warp) warp;
@@ -51,7 +52,7 @@ struct Launchers {
   decltype(&exact::launch_de_update) de_update;
 };
 #define OFDIS_LAUNCHER_TABLE(ns)                                                                                        \
-  {ns::launch_patch_optimize, ns::launch_densify, ns::launch_patch_p_reference_order, ns::launch_warp, ns::launch_derivatives, ns::tv_prep_supported,       \
+  {ns::launch_patch_optimize, ns::patch_pixel_weights_supported, ns::launch_densify, ns::launch_patch_p_reference_order, ns::launch_warp, ns::launch_derivatives, ns::tv_prep_supported,       \
    ns::launch_tv_prep, ns::launch_tv_system, ns::launch_sor, ns::tv_fused_supported, ns::tv_fused_params_ok,            \
    ns::tv_fused_mode, ns::launch_tv_fused, ns::launch_tv_finish_records, ns::launch_to_diag, ns::launch_from_diag,      \
    ns::launch_tv_finish, ns::launch_flow_split, ns::launch_de_system, ns::launch_de_sor, ns::launch_de_update}
@@ -242,6 +243,7 @@ struct ofdis_batch {
   float* initflow_own = nullptr;     // staging buffer of ofdis_batch_upload_initflow
   // scratch, sized for the finest level
   float *pvec = nullptr, *pweight = nullptr;
+  float* pixw = nullptr;             // RGB: compact per-pixel weight denominators (ofdis_dev.h: pixw_row), [B][nop][P*P]
   float *wx = nullptr, *wy = nullptr, *du = nullptr, *dv = nullptr, *mask = nullptr;
   float *w_im2 = nullptr, *derivs = nullptr, *sys = nullptr;
   float *wrec = nullptr, *uv = nullptr;  // fused TV path: the (wx, wy) and (du, dv) records; `derivs` holds the
@@ -674,6 +676,8 @@ int ofdis_batch_create(ofdis_batch** out, const ofdis_params* p, int nframes) {
   for (auto& g : b->geom) nop_max = std::max(nop_max, (size_t)g.nop);
   if (!rc) rc = dalloc(b, &b->pvec, nop_max * 2 * nframes);
   if (!rc) rc = dalloc(b, &b->pweight, nop_max * g0.novals * nframes);
+  if (!rc && p->noc == 3 && !p->usefbcon && p->selectmode != 2)  // (forward-backward merging reads the weights by another shifted rule)
+    rc = dalloc(b, &b->pixw, nop_max * (size_t)g0.P * g0.P * nframes);
   if (!rc && p->usefbcon) rc = dalloc(b, &b->pvec_bw, nop_max * 2 * nframes);
   if (!rc && p->usefbcon) rc = dalloc(b, &b->pweight_bw, nop_max * g0.novals * nframes);
   if (!rc && p->usetvref) {
@@ -865,7 +869,7 @@ ofdis_batch frame_view(const ofdis_batch& b, int f0, int n) {
   size_t nop_max = 0;
   for (auto& g : b.geom) nop_max = std::max(nop_max, (size_t)g.nop);
   auto off = [&](float*& ptr, size_t per_frame) { if (ptr) ptr += (size_t)f0 * per_frame; };
-  off(v.pvec, nop_max * 2); off(v.pweight, nop_max * g0.novals);
+  off(v.pvec, nop_max * 2); off(v.pweight, nop_max * g0.novals); off(v.pixw, nop_max * (size_t)g0.P * g0.P);
   off(v.pvec_bw, nop_max * 2); off(v.pweight_bw, nop_max * g0.novals);
   off(v.wx, npx); off(v.wy, npx); off(v.du, npx); off(v.dv, npx); off(v.mask, npx); off(v.uu, npx);
   off(v.w_im2, npx * b.p.noc); off(v.derivs, npx * 8 * b.p.noc); off(v.sys, npx * 7);
@@ -991,6 +995,7 @@ int run_one_level(ofdis_batch* b, int sl, hipStream_t s) {
     // one snapshot of the TV path per level: densification and refinement must take the same one even if another thread
     // changes the knobs in between
     const bool fused = p.usetvref && p.selectmode != 2 && use_fused(b, g);
+    const float* pixw_used = nullptr;
     {
       KTimer kt(b, OFDIS_K_PATCH, s);
       DisArgs a = dis_args(p, g, b->nframes);
@@ -1001,7 +1006,12 @@ int run_one_level(ofdis_batch* b, int sl, hipStream_t s) {
       a.flow_prev = (sl < p.sc_f) ? b->flow[ii + 1] : b->initflow;  // oflow.cpp:209-220
       a.p_out = b->pvec;
       a.pweight = b->pweight;
+      // RGB 12x12 without forward-backward merging: the patches the densification reads unshifted store one float per pixel
+      // (the denominator of its weight) instead of three |r| -- decided here, once, for the patch kernel AND the densification
+      a.pixw = (b->pixw && !fb && b->k->patch_pixel_weights_supported(a)) ? b->pixw : nullptr;
+      pixw_used = a.pixw;
       HIPCHK(b->k->patch_optimize(a, s));
+      a.pixw = nullptr;
       if (fb) {  // the backward grid: images swapped (oflow.cpp:193-197,214-215,234-235)
         a.im_a = b->in[3][ii];
         a.im_a_dx = b->in[4][ii];
@@ -1026,6 +1036,7 @@ int run_one_level(ofdis_batch* b, int sl, hipStream_t s) {
       d.nframes = b->nframes;
       d.p = dir ? b->pvec_bw : b->pvec;
       d.pweight = dir ? b->pweight_bw : b->pweight;
+      d.pixw = dir ? nullptr : pixw_used;
       d.stereo = p.selectmode == 2;
       if (fb) {
         d.cg_p = dir ? b->pvec : b->pvec_bw;

@@ -14,7 +14,9 @@ namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled fo
 // pweight_row); accumulates into we, fu, fv.
 __device__ __forceinline__ void densify_accumulate(const LevelGeom& g, const float* __restrict__ pf,
                                                    const float* __restrict__ pwf, int x, int y, float& we, float& fu,
-                                                   float& fv) {
+                                                   float& fv, const float* __restrict__ pxf = nullptr) {
+  // pxf: this frame's compact per-pixel weight denominators of the RGB patches that are read unshifted (ofdis_dev.h: pixw_row;
+  // written by the patch kernel INSTEAD of their pweight), or null
   const int P = g.P, lb = -P / 2, ub = P / 2 - 1, st = g.steps, noc = g.noc;
   // rx + lb <= x <= rx + ub, rx = gx*st + offw
   // floor(n / steps) for 0 <= n < 65536 as a multiply-high with ceil(2^32 / steps): exact because the rounding
@@ -47,6 +49,14 @@ __device__ __forceinline__ void densify_accumulate(const LevelGeom& g, const flo
         const int left_out = max(0, -(rxi + lb)), right_out = max(0, rxi + ub - (g.w - 1));
         const int top_out = max(0, -(ryi + lb));
         float pw0, pw1, pw2;
+        if ((left_out | right_out | top_out) == 0 && pxf) {
+          // (the patch kernel already added max(2,|r_0|) + max(2,|r_1|) + max(2,|r_2|) of this pixel, same order)
+          absw = div_rn(1.0f, pxf[pixw_row(g, gx, gy, ky) + kx]);
+          we += absw;
+          fu += pf[2 * ip] * absw;
+          fv += pf[2 * ip + 1] * absw;
+          continue;
+        }
         if ((left_out | right_out | top_out) == 0) {  // the patch lies inside the image: the pointer is (ky * P + kx) * 3
           const float* pw = pwf + pweight_row(g, gx, gy, ky) + kx * 3;
           pw0 = pw[0]; pw1 = pw[1]; pw2 = pw[2];

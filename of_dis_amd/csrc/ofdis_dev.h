@@ -197,6 +197,22 @@ __host__ __device__ __forceinline__ size_t pweight_entry(const LevelGeom& g, int
   return pweight_row(g, gx, gy, r) + (size_t)(k - r * rowlen);
 }
 
+// RGB patches (noc = 3) that lie inside the image on the left, right and top also have a COMPACT weight array (round 5):
+//   pixw    [gy][patch row r][gx][P]          one float per patch PIXEL: max(2,|r_0|) + max(2,|r_1|) + max(2,|r_2|), the
+// denominator of the pixel's densification weight (patchgrid.cpp:256-259) -- all the densification ever uses of the three
+// channel errors of such a patch; a third of the bytes.  Patches that overlap the left / right / top border keep the full
+// pweight vector: the reference's running pointer shifts their entries (patchgrid.cpp:242,256-257; ofdis_densify.h).
+__host__ __device__ __forceinline__ size_t pixw_row(const LevelGeom& g, int gx, int gy, int r) {
+  return ((size_t)(gy * g.P + r) * g.nopw + gx) * (size_t)g.P;
+}
+// does the reference's running pweight pointer reach every pixel of patch (gx, gy) unshifted?  (no patch pixel outside the
+// image to the left, to the right or above; rows below the image come after everything that is read)
+__host__ __device__ __forceinline__ bool patch_weights_unshifted(const LevelGeom& g, int gx, int gy) {
+  const int lb = -g.P / 2, ub = g.P / 2 - 1;
+  const int rxi = gx * g.steps + g.offw, ryi = gy * g.steps + g.offh;
+  return (rxi + lb >= 0) & (rxi + ub <= g.w - 1) & (ryi + lb >= 0);
+}
+
 // "diag" plane layout used for the SOR solver's operands (7 system planes, du, dv): pixel (x,y) of a
 // w x h plane lives at ((x+y) mod w)*h + y, i.e. wrapped anti-diagonal d = (x+y) mod w is ONE
 // contiguous row of h floats (a bijection onto w*h, no padding).  The wavefront SOR reads/writes

@@ -773,7 +773,27 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
   // (internal layout, ofdis_dev.h: pweight_row -- patch rows are nopw * 36 floats apart)
   float* const pwout = a.pweight + (size_t)frame * g.nop * NV + pweight_row(g, gx, gy, 3 * rg) + 9 * cg;
   const int pwstride = g.nopw * 36;
+  // A patch whose weights the densification reads unshifted (ofdis_dev.h: patch_weights_unshifted -- all but the patches on
+  // the left / right / top border) stores ONE float per pixel, the denominator max(2,|r_0|) + max(2,|r_1|) + max(2,|r_2|) of
+  // the pixel's weight (patchgrid.cpp:256-259, the same three operations in the same order), instead of its 432 |r|: the lane
+  // holds the three channels of each of its nine pixels.  108 instead of 324 bytes per lane.
+  const bool compact = a.pixw != nullptr && patch_weights_unshifted(g, gx, gy);
+  float* const pxout = a.pixw ? a.pixw + (size_t)frame * g.nop * 144 + pixw_row(g, gx, gy, 3 * rg) + 3 * cg : nullptr;
+  const int pxstride = g.nopw * 12;
   auto store_pw = [&](const float (&v)[NE], bool zero) {
+    if (compact) {
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int xx = 0; xx < 3; ++xx) {
+          const int e = rr * 9 + xx * 3;
+          float sden = fmaxf(2.0f, fabsf(v[e]));
+          sden += fmaxf(2.0f, fabsf(v[e + 1]));
+          sden += fmaxf(2.0f, fabsf(v[e + 2]));
+          pxout[rr * pxstride + xx] = zero ? 6.0f : sden;  // (never evaluated: |r| = 0 three times)
+        }
+      return;
+    }
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
@@ -1025,7 +1045,33 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const Dis
   int cnt = 0;
   bool converged = false;
   float* const pwf = a.pweight + (size_t)frame * g.nop * NV;
+  // (see patch_optimize_rgb12_kernel: one float per pixel for the patches the densification reads unshifted.  The residual
+  // lives in layout B here, a pixel's three channels in three lanes: |r| goes through the hand-over vector once more and is
+  // read back by pixel blocks, layout A)
+  const bool compact = a.pixw != nullptr && patch_weights_unshifted(g, gx, gy);
+  float* const pxout = a.pixw ? a.pixw + (size_t)frame * g.nop * 144 + pixw_row(g, gx, gy, 3 * rg) + 3 * cg : nullptr;
+  const int pxstride = g.nopw * 12;
   auto store_pw = [&](const float (&v)[28], bool zero) {  // |residual| of this lane's entries (layout B)
+    if (compact) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < (c == 3 ? 6 : 7); ++m) xp[kB(c, m)] = zero ? 0.0f : fabsf(v[c * 7 + m]);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int xx = 0; xx < 3; ++xx) {
+          const float* e = xp + (3 * rg + rr) * 36 + 9 * cg + 3 * xx;
+          float sden = fmaxf(2.0f, e[0]);
+          sden += fmaxf(2.0f, e[1]);
+          sden += fmaxf(2.0f, e[2]);
+          pxout[rr * pxstride + xx] = sden;
+        }
+      __builtin_amdgcn_wave_barrier();  // (a later evaluation of the wavefront's other patches does not touch this vector)
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -1151,6 +1197,14 @@ hipError_t launch_patch_optimize_rgb12(const DisArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Does launch_patch_optimize run a kernel that honours DisArgs::pixw for these arguments?  (The 16-lanes-per-patch RGB 12x12
+// kernels of either contract; the caller passes pixw to the patch kernel and to the densification only then.)
+bool patch_pixel_weights_supported(const DisArgs& a) {
+  const ofdis_tuning tn = tuning();
+  const int rgb12_lpp = tn.rgb12_lpp == 0 ? 16 : tn.rgb12_lpp;
+  return a.g.novals == 432 && a.g.P == 12 && !a.stereo && (a.costfct == 0 || a.costfct == 1) && tn.rgb12 && rgb12_lpp == 16;
+}
+
 hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   const int M = (a.g.novals + 63) / 64;
   const bool full = a.g.novals == 64 * M;
@@ -1165,6 +1219,7 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
   const bool rgb12 = a.g.novals == 432 && !a.stereo && (a.costfct == 0 || a.costfct == 1) && tn.rgb12;
   // RGB 12x12 has its own mapping (16 lanes per patch, four patches per wavefront: ofdis_tuning::rgb12_lpp = 16, the default)
   if (rgb12 && rgb12_lpp == 16) return launch_patch_optimize_rgb12<kFusedContract>(a, s);
+  if (a.pixw) return hipErrorInvalidValue;  // (only the kernels above write the compact weights)
   const int lpp = (M <= 1) ? (gray8 ? 4 : 8) : ((rgb12 && rgb12_lpp == 32) ? 32 : 64);  // lanes per patch
   const int ppw = 64 / lpp;                           // patches per wavefront
   const int wpf = (a.g.nop + ppw - 1) / ppw;          // wavefronts per frame
@@ -1242,10 +1297,11 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
   if (active) {
     const float* pf = a.p + (size_t)frame * g.nop * 2;
     const float* pwf = a.pweight + (size_t)frame * g.nop * g.novals;
+    const float* pxf = a.pixw ? a.pixw + (size_t)frame * g.nop * g.P * g.P : nullptr;
     if (g.noc == 1 && g.P <= 2 * g.steps)  // at most 2 x 2 covering patches (uniform)
       densify_accumulate_gray<2>(g, pf, pwf, x, y, we, fu, fv);
     else
-      densify_accumulate(g, pf, pwf, x, y, we, fu, fv);
+      densify_accumulate(g, pf, pwf, x, y, we, fu, fv, pxf);
   }
   if (fb) {  // block-uniform
     __shared__ FbCand cand[256];

@@ -25,6 +25,8 @@ struct DisArgs {
   const float* flow_prev;  // AoS [B][h/2][w/2][2] or nullptr
   float* p_out;            // [B][nop][2]       both in the internal grid-row-major layout (ofdis_dev.h: patch_slot,
   float* pweight;          // [B][nop][novals]  pweight_row): the densify kernels read them, nobody else
+  float* pixw;             // [B][nop][P*P] or nullptr: RGB 12x12 only (patch_pixel_weights_supported): patches whose weights
+                           // the densification reads unshifted store one float per pixel here INSTEAD of pweight (ofdis_dev.h)
 };
 // snapshot of the kernel-selection knobs (include/ofdis.h: ofdis_tuning; ofdis_capi.hip); *epoch counts the changes
 ofdis_tuning tuning(unsigned* epoch = nullptr);
@@ -34,6 +36,7 @@ struct DensifyArgs {
   int nframes;
   const float* p;        // [B][nop][2]       (internal layout, as the patch kernels write them)
   const float* pweight;  // [B][nop][novals]
+  const float* pixw;     // [B][nop][P*P] or nullptr: what the patch kernel was given as DisArgs::pixw
   float* flow_aos;       // if non-null: AoS output
   float* wx;             // else planar outputs (row-major)
   float* wy;
