@@ -115,10 +115,11 @@ void run_share(const std::vector<Pair>& pairs, const ofdis_params& p0, int width
         if (!rc) rc = ofdis_batch_upsample_frames(b, 0, m, dfull, width_org, height_org, nullptr);
         if (!rc) rc = ofdis_sync(nullptr);
         if (!rc) rc = ofdis_batch_status(b);
-        // a pass that reports itself as failed (a lost hand-over of the cross-CU fused TV variant, small contexts only) is
-        // repeated once: the context no longer uses that variant
-        // (ofdis_batch_status keeps saying so until the next pass starts: that is what tells it from a HIP error)
-        if (rc == OFDIS_ERR_DEVICE && attempt == 0 && ofdis_batch_status(b) != OFDIS_OK) {
+        // A pass that reports itself as failed (a lost hand-over of the cross-CU fused TV variant, small contexts only) is
+        // repeated once: the context no longer uses that variant.  ofdis_sync reports such a failure to whoever synchronises the
+        // stream of the pass -- with several shares on ONE device (--devices 0,0) that may be another share's thread -- so any
+        // OFDIS_ERR_DEVICE gets the one repetition (harmless for a share that was fine; a HIP error proper fails again).
+        if (rc == OFDIS_ERR_DEVICE && attempt == 0) {
           fprintf(stderr, "%s\n", ofdis_last_error());
           rc = OFDIS_OK;
           continue;

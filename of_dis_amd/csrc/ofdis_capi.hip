@@ -221,6 +221,7 @@ struct XcuState {
   std::atomic<bool> missed{false};     // a pass failed and the NEXT pass was started before anybody polled: reported once, late
   std::atomic<bool> rezero{false};     // the granule array may hold stale tags
   std::atomic<hipStream_t> last_stream{nullptr};  // where the last pass was enqueued (ofdis_sync polls the contexts of its stream)
+  std::atomic<int> last_device{-1};               // ... and on which device (the null stream is "the same" stream on every device)
   std::atomic<bool> ran{false};
 };
 
@@ -389,6 +390,11 @@ int xcu_begin_pass(ofdis_batch* b, hipStream_t s) {
   x->failed = false;
   x->told_sync = false;
   x->last_stream = s;
+  {
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    x->last_device = dev;
+  }
   x->ran = true;
   if (x->rezero && b->xbuf) {  // stale tags of the pass that failed
     // (a previous pipelined pass leaves its sub-streams unjoined on purpose; they may still be using the granules)
@@ -1640,10 +1646,12 @@ int ofdis_sync(void* stream) {
   // a lost hand-over of the cross-CU fused TV variant belongs to the context that launched it: report it to whoever
   // synchronises the stream that context's last pass went to (ofdis_batch_status asks one context directly)
   int rc = OFDIS_OK;
+  int dev = -1;
+  (void)hipGetDevice(&dev);  // (one host thread per GPU, each synchronising its own null stream: only this device's contexts)
   std::lock_guard<std::mutex> lock(g_xcu_mutex);
   for (ofdis_batch* b : g_xcu_contexts) {
     XcuState* x = b->xcu;
-    if (!x || !x->ran || x->last_stream != (hipStream_t)stream || x->told_sync) continue;
+    if (!x || !x->ran || x->last_stream != (hipStream_t)stream || x->last_device != dev || x->told_sync) continue;
     if (xcu_poll(b) != OFDIS_OK) {  // (reported here once; ofdis_batch_status / _download keep reporting it until the next pass)
       x->told_sync = true;
       rc = OFDIS_ERR_DEVICE;

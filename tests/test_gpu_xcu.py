@@ -255,3 +255,33 @@ def test_failure_nobody_polled_is_reported_late_once(gpu, cases):
         b.close()
     finally:
         gpu.restore_tuning(old)
+
+
+def test_sequence_driver_repeats_a_failed_pass(gpu, tmp_path):
+    """run_OF_INT_seq (one resident context per share, chunks of the list): with the wait forced to expire in every pass that
+    uses the variant it must notice (ofdis_sync / ofdis_batch_status), repeat the chunk's pass and write the bytes of a normal
+    run -- also with two shares on the one device, where ofdis_sync may hand one share's failure to the other share's thread."""
+    import gen_synth
+    from of_dis_amd import build
+    n, w, h = 10, 320, 192
+    lines = []
+    for k in range(n):
+        ia, ib, _ = gen_synth.make_pair(w, h, 900 + k)
+        fa, fb = str(tmp_path / f"a{k}.pgm"), str(tmp_path / f"b{k}.pgm")
+        gen_synth.write_pgm(fa, ia)
+        gen_synth.write_pgm(fb, ib)
+        lines.append((fa, fb))
+    exe = os.path.join(os.path.dirname(build.lib_path()), "run_OF_INT_seq")
+    args = "5 3 12 12 0.05 0.95 0 8 0.40 0 1 0 1 10 10 5 1 3 1.6 0".split()
+    outs = {}
+    for name, env, opts in (("normal", {}, ["--chunk", "4"]),
+                            ("forced", {"OFDIS_FUSED_XCU_SPIN": "1", "OFDIS_FUSED_XCU_MAX": "1073741824"}, ["--chunk", "4"]),
+                            ("forced2", {"OFDIS_FUSED_XCU_SPIN": "1", "OFDIS_FUSED_XCU_MAX": "1073741824"}, ["--devices", "0,0", "--chunk", "3"])):
+        lst = tmp_path / f"{name}.txt"
+        lst.write_text("".join(f"{fa} {fb} {tmp_path}/{name}{k}.flo\n" for k, (fa, fb) in enumerate(lines)))
+        r = subprocess.run([exe, str(lst)] + opts + args, env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (name, r.stdout, r.stderr)
+        if name != "normal":
+            assert "hand-over" in r.stderr, "the driver must have noticed the failed pass"
+        outs[name] = [open(tmp_path / f"{name}{k}.flo", "rb").read() for k in range(n)]
+    assert outs["forced"] == outs["normal"] and outs["forced2"] == outs["normal"]
