@@ -1,7 +1,7 @@
 // run_OF_INT_seq / run_OF_RGB_seq -- the reference's run_OF_* main (run_dense.cpp:185-431) over MANY frame pairs and
 // several GPUs of one node, in the host language of the reference, on top of the C ABI (include/ofdis.h).
 //
-//   run_OF_INT_seq pairs.txt [--gpus N | --devices d0,d1,..] [--chunk C] [oppoint 1-4 | p1 .. p20]
+//   run_OF_INT_seq pairs.txt [--gpus N | --devices d0,d1,..] [--chunk C] [--dry-run 1] [oppoint 1-4 | p1 .. p20]
 //
 // pairs.txt: one pair per line, "img1 img2 out.flo" (blank lines and lines starting with # are skipped); all images of one
 // size.  The parameter block after the options is the single-pair binaries' (README.md:48-88).
@@ -18,6 +18,8 @@
 // the number of GPUs (tests/test_cli.py::test_sequence_driver_*).
 //
 // --devices 0,0 puts two shares on one device (how the two-GPU split is tested on a one-GPU box).
+// --dry-run 1 prints the partition ("share r: device d pairs lo..hi") and exits without touching a device or a file
+// (tests/test_cli.py checks it against of_dis_amd.shard.frame_range on the CPU).
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -153,7 +155,7 @@ void run_share(const std::vector<Pair>& pairs, const ofdis_params& p0, int width
 int main(int argc, char** argv) {
   const double t_start = now_ms();
   if (argc < 2) {
-    fprintf(stderr, "usage: %s pairs.txt [--gpus N | --devices d0,d1,..] [--chunk C] [oppoint 1-4 | lv_f lv_l maxiter miniter "
+    fprintf(stderr, "usage: %s pairs.txt [--gpus N | --devices d0,d1,..] [--chunk C] [--dry-run 1] [oppoint 1-4 | lv_f lv_l maxiter miniter "
                     "mindprate mindrrate minimgerr patchsz poverl usefbcon patnorm costfct usetvref tv_alpha tv_gamma tv_delta "
                     "tv_innerit tv_solverit tv_sor verbosity]\n  pairs.txt: one \"img1 img2 out.flo\" per line\n", argv[0]);
     return 2;
@@ -182,6 +184,7 @@ int main(int argc, char** argv) {
     return 1;
   }
   int k = 2, chunk = 256;
+  bool dry_run = false;
   std::vector<int> devices;
   while (k < argc && argv[k][0] == '-' && argv[k][1] == '-') {
     const std::string opt = argv[k];
@@ -200,6 +203,8 @@ int main(int argc, char** argv) {
       while (std::getline(ss, tok, ',')) devices.push_back(atoi(tok.c_str()));
     } else if (opt == "--chunk") {
       chunk = atoi(val);
+    } else if (opt == "--dry-run") {
+      dry_run = atoi(val) != 0;
     } else {
       fprintf(stderr, "unknown option %s\n", opt.c_str());
       return 2;
@@ -207,6 +212,14 @@ int main(int argc, char** argv) {
     k += 2;
   }
   if (devices.empty()) devices.push_back(0);
+  if (dry_run) {  // the partition only
+    for (int r = 0; r < (int)devices.size(); ++r) {
+      int lo, hi;
+      frame_range((int)pairs.size(), r, (int)devices.size(), &lo, &hi);
+      printf("share %d: device %d pairs %d..%d\n", r, devices[r], lo, hi - 1);
+    }
+    return 0;
+  }
   const int ndev = ofdis_device_count();
   for (int d : devices)
     if (d < 0 || d >= ndev) {

@@ -216,6 +216,26 @@ def test_sequence_driver_usage_and_bad_lists(tmp_path):
     assert r.returncode == 1 and "cannot read" in r.stderr
 
 
+@pytest.mark.parametrize("total,shares", [(512, 8), (513, 8), (7, 8), (66, 2), (100, 3), (1, 1)])
+def test_sequence_driver_partition_is_frame_range(tmp_path, total, shares):
+    """the C++ driver cuts its list exactly as of_dis_amd.shard.frame_range cuts bench.py's batch (contiguous
+    shares, sizes differing by at most one, earlier shares take the remainder) -- checked without a GPU (--dry-run)."""
+    from of_dis_amd.shard import frame_range
+    lst = tmp_path / "pairs.txt"
+    lst.write_text("".join(f"a{k}.pgm b{k}.pgm o{k}.flo\n" for k in range(total)))
+    r = subprocess.run([SEQ[1], str(lst), "--gpus", str(shares), "--dry-run", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = [tuple(map(int, __import__("re").match(r"share (\d+): device (\d+) pairs (-?\d+)\.\.(-?\d+)", l).groups()))
+           for l in r.stdout.splitlines()]
+    assert len(got) == shares
+    covered = []
+    for rank, (sr, dev, lo, hi) in enumerate(got):
+        assert (sr, dev) == (rank, rank)
+        assert (lo, hi + 1) == frame_range(total, rank, shares)
+        covered += list(range(lo, hi + 1))
+    assert covered == list(range(total))
+
+
 def _write_pairs(tmp_path, n, w, h, channels=1, seed0=500):
     pairs = []
     for k in range(n):
