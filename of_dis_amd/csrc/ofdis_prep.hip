@@ -93,10 +93,13 @@ __device__ __forceinline__ float h5r(float m2, float m1, float s0, float p1, flo
 // byte offsets, the per-frame strip bases: ~9 instead of ~30 instructions per piece, no scalar divisions per flush -- measured
 // 1.83-2.03 against 1.86 ms on level 3 of the headline, 105 instead of 72 VGPRs: no gain, not kept.  Like the test-free
 // interior loop body of round 3, it removes instructions the kernel was not waiting for.)
-constexpr int PREP_KD = 2;  // rows of derivative records staged before a flush (runs of KD * 32 bytes)
+constexpr int PREP_KD = 4;  // rows of derivative records staged before a flush (runs of KD * 32 bytes)
 constexpr int PREP_KW = 8;  // rows of (wx, wy) records staged before a flush (runs of KW * 8 bytes)
-// (measured at 4096 pairs, ms per step of this kernel: KD = 1 / 2 / 4: 1.17 / 0.79 / 0.76, KW = 4 / 8: 0.79 / 0.70 --
-// the run length of the stores is what it is most sensitive to; profiles/README.md r03_b)
+// (measured at 4096 pairs, ms per step of this kernel, round 3: KD = 1 / 2 / 4: 1.17 / 0.79 / 0.76, KW = 4 / 8: 0.79 / 0.70 --
+// the run length of the stores is what it is most sensitive to; profiles/README.md r03_b.  Round 5, 16384 pairs, same box:
+// KD = 2 / 4 / 8: 2.46-2.47 / 2.22-2.29 / 3.05 ms, KD = 4 with KW = 16: 2.63 -- a run of KD = 4 records is exactly one
+// 128-byte cache line (h is a multiple of 4 on the benchmarked levels 3 and 4), and the larger staging area costs nothing: the
+// kernel does not care whether 2.5 or 4 wavefronts share a SIMD (profiles/r05_b_variants.txt), which is what had kept KD at 2)
 
 // LDS per block, in floats.  WPF = wavefronts per frame (= per block): 1 (w <= 64; up to four frames in the wavefront) or 2.
 template <int WPF>
