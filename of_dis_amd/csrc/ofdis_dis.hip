@@ -1427,6 +1427,7 @@ __global__ __launch_bounds__(256) void densify_quad_kernel(const DensifyArgs a, 
     pp[c] = *reinterpret_cast<const float2*>(pf + 2 * patch_slot(g, gxc, gyc));
   }
   float2* out = reinterpret_cast<float2*>(a.flow_aos) + ((size_t)frame * h + y) * w;
+  float2 res[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     float we = 0.0f, fu = 0.0f, fv = 0.0f;
@@ -1443,8 +1444,21 @@ __global__ __launch_bounds__(256) void densify_quad_kernel(const DensifyArgs a, 
       fu /= we;
       fv /= we;
     }
-    const int x = x0 + t;
-    if (x >= 0 && x < w) out[x] = make_float2(fu, fv);
+    res[t] = make_float2(fu, fv);
+  }
+  // a quad inside the image goes out as 32 contiguous bytes in two stores (consecutive threads: consecutive 32-byte pieces);
+  // the quads that straddle the left / right border pixel by pixel
+  if (x0 >= 0 && x0 + 3 < w) {
+    typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+    f4a8* o4 = reinterpret_cast<f4a8*>(out + x0);
+    o4[0] = f4a8{res[0].x, res[0].y, res[1].x, res[1].y};
+    o4[1] = f4a8{res[2].x, res[2].y, res[3].x, res[3].y};
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int x = x0 + t;
+      if (x >= 0 && x < w) out[x] = res[t];
+    }
   }
 }
 
