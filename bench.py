@@ -993,8 +993,14 @@ def main():
                             "the number of sub-batches); strictly_compulsory_* = the bytes that must cross the HBM interface once "
                             "per LEVEL (records in, flow out: 48 B per pixel).  traffic / strictly compulsory = how many times the "
                             "records are re-fetched.  See roofline_valu and DESIGN.md section 4"}
+        if strict:
+            sgbs = strict / (dom_ms * 1e-3) / 1e9
+            roofline["strictly_compulsory_MB_per_step"] = round(strict / 1e6, 2)
+            roofline["strictly_compulsory_frac"] = round(sgbs / HBM_PEAK_GBS, 4)
         if tr and strict:
             roofline["traffic_over_strictly_compulsory"] = round(tr / strict, 2)
+        if traffic_note:  # why no PMC traffic is attached to this run
+            roofline["traffic_note"] = traffic_note
         # VALU-side roofline of the same kernel: wave64 VALU instructions issued per step (PMC SQ_INSTS_VALU,
         # profiles/traffic.json) / its measured time, against SIMDs x clock / 2 (a wave64 VALU op occupies a
         # gfx950 SIMD for two clocks, MI355X_MICROARCH.md); the clock is the sustained one observed under this load
