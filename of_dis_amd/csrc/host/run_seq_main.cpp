@@ -10,7 +10,8 @@
 // is always null, run_dense.cpp:395), so the list is cut into contiguous shares (sizes differ by at most one, earlier
 // shares take the remainder -- the partition of of_dis_amd/shard.py: frame_range), one host thread per share, each bound to
 // its GPU (ofdis_set_device), with nothing shared on the data path.  A thread streams its share through ONE resident batch
-// context of C pairs (default 256): read C pairs -> upload the 8-bit frames -> padding, pyramid, Sobel on the device
+// context of C pairs (default 64), three stages on three threads (decode | device | .flo files) over rotating chunk buffers:
+// read C pairs -> upload the 8-bit frames -> padding, pyramid, Sobel on the device
 // (ofdis_batch_build_pyramids_u8: run_dense.cpp:130-178,298-344) -> the hot path (ofdis_batch_run: OFClass::OFClass,
 // oflow.cpp:184-337) -> x 2^lv_l, bilinear upsample, crop on the device (ofdis_batch_upsample_frames: run_dense.cpp:406-414)
 // -> download -> one Middlebury .flo per pair (run_dense.cpp:16-57).  Under the library's default (exact) arithmetic
@@ -27,7 +28,12 @@
 #include <sys/time.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <fstream>
+#include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -67,6 +73,38 @@ void frame_range(int total, int rank, int world, int* lo, int* hi) {  // of_dis_
   *hi = *lo + base + (rank < rem ? 1 : 0);
 }
 
+// One chunk of a share on its way through the three stages: decode (reader thread) -> device (the share's thread) -> .flo
+// files (writer thread).  Three buffers rotate, so that a chunk is being decoded and another written while the device works
+// on a third: the device stage never waits for the file system unless the file system is the slower side (it is: DESIGN.md 6).
+struct Chunk {
+  int c0 = 0, m = 0;                // first pair of the chunk (index into the list), pairs in it; m = 0: end of the share
+  // [C][h][w][noc] 8-bit frames; slots of unreadable pairs / of a short last chunk keep what the buffer held before (valid
+  // images, results never used).  The buffers are not zero-filled up front -- a gigabyte of page faults for nothing -- only the
+  // slots that would otherwise go to the device undefined are (init_upto: slots below it have been written at least once)
+  std::unique_ptr<uint8_t[]> ha, hb;
+  int init_upto = 0;
+  std::unique_ptr<float[]> full;    // [C][h][w][2] full-resolution flows
+  std::vector<char> ok;
+};
+class ChunkQueue {  // a blocking FIFO of chunk pointers
+ public:
+  void push(Chunk* c) {
+    { std::lock_guard<std::mutex> l(m_); q_.push_back(c); }
+    cv_.notify_one();
+  }
+  Chunk* pop() {
+    std::unique_lock<std::mutex> l(m_);
+    cv_.wait(l, [&] { return !q_.empty(); });
+    Chunk* c = q_.front();
+    q_.pop_front();
+    return c;
+  }
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<Chunk*> q_;
+};
+
 void run_share(const std::vector<Pair>& pairs, const ofdis_params& p0, int width_org, int height_org, int chunk, Share* sh) {
   const int n_share = sh->hi - sh->lo;
   if (n_share < 1) return;
@@ -82,35 +120,89 @@ void run_share(const std::vector<Pair>& pairs, const ofdis_params& p0, int width
   void* da = ofdis_dev_alloc(img_bytes * C);
   void* db = ofdis_dev_alloc(img_bytes * C);
   float* dfull = (float*)ofdis_dev_alloc(flo_floats * sizeof(float) * C);
-  // host staging of one chunk; slots of a short last chunk keep the frames of the chunk before (valid images, results unused)
-  std::vector<uint8_t> ha(img_bytes * C, 0), hb(img_bytes * C, 0);
-  std::vector<float> full(flo_floats * C);
-  std::vector<char> ok(C);
   if (!da || !db || !dfull) {
     bail("ofdis_dev_alloc");
   } else {
-    for (int c0 = sh->lo; c0 < sh->hi; c0 += C) {
-      const int m = std::min(C, sh->hi - c0);
-      for (int k = 0; k < m; ++k) {  // decode (cv::imread in the reference, run_dense.cpp:208-209)
-        const Pair& pr = pairs[c0 + k];
-        ofdis_host::Image8 ia, ib;
-        std::string err;
-        ok[k] = ofdis_host::read_image(pr.a, OFDIS_NOC, &ia, &err) && ofdis_host::read_image(pr.b, OFDIS_NOC, &ib, &err);
-        if (ok[k] && (ia.width != width_org || ia.height != height_org || ib.width != width_org || ib.height != height_org)) {
-          ok[k] = 0;
-          err = pr.a + " / " + pr.b + ": not " + std::to_string(width_org) + "x" + std::to_string(height_org) + " like the first pair";
+    Chunk bufs[3];
+    ChunkQueue free_q, ready_q, done_q;
+    for (Chunk& c : bufs) {
+      c.ha.reset(new uint8_t[img_bytes * C]);
+      c.hb.reset(new uint8_t[img_bytes * C]);
+      c.full.reset(new float[flo_floats * C]);
+      c.ok.assign(C, 0);
+      free_q.push(&c);
+    }
+    std::atomic<int> failed{0};
+    std::atomic<bool> stop{false};  // the device stage gave up: the reader stops feeding it
+    std::thread reader([&] {  // decode (cv::imread in the reference, run_dense.cpp:208-209)
+      for (int c0 = sh->lo; c0 < sh->hi && !stop; c0 += C) {
+        Chunk* c = free_q.pop();
+        c->c0 = c0;
+        c->m = std::min(C, sh->hi - c0);
+        for (int k = 0; k < c->m; ++k) {
+          const Pair& pr = pairs[c0 + k];
+          ofdis_host::Image8 ia, ib;
+          std::string err;
+          c->ok[k] = ofdis_host::read_image(pr.a, OFDIS_NOC, &ia, &err) && ofdis_host::read_image(pr.b, OFDIS_NOC, &ib, &err);
+          if (c->ok[k] && (ia.width != width_org || ia.height != height_org || ib.width != width_org || ib.height != height_org)) {
+            c->ok[k] = 0;
+            err = pr.a + " / " + pr.b + ": not " + std::to_string(width_org) + "x" + std::to_string(height_org) + " like the first pair";
+          }
+          if (!c->ok[k]) {
+            fprintf(stderr, "%s\n", err.c_str());
+            ++failed;
+            if (k >= c->init_upto) {  // never written: a defined (black) frame; otherwise the slot keeps its previous content
+              memset(c->ha.get() + k * img_bytes, 0, img_bytes);
+              memset(c->hb.get() + k * img_bytes, 0, img_bytes);
+            }
+            continue;
+          }
+          memcpy(c->ha.get() + k * img_bytes, ia.data.data(), img_bytes);
+          memcpy(c->hb.get() + k * img_bytes, ib.data.data(), img_bytes);
         }
-        if (!ok[k]) {
-          fprintf(stderr, "%s\n", err.c_str());
-          ++sh->failed;
-          continue;  // the slot keeps its previous content
+        if (c->init_upto < C) {  // the slots of a short chunk that were never written
+          const int from = std::max(c->init_upto, c->m);
+          if (from < C) {
+            memset(c->ha.get() + from * img_bytes, 0, (C - from) * img_bytes);
+            memset(c->hb.get() + from * img_bytes, 0, (C - from) * img_bytes);
+          }
+          c->init_upto = C;
         }
-        memcpy(ha.data() + k * img_bytes, ia.data.data(), img_bytes);
-        memcpy(hb.data() + k * img_bytes, ib.data.data(), img_bytes);
+        ready_q.push(c);
       }
+      Chunk* end = free_q.pop();
+      end->m = 0;
+      ready_q.push(end);
+    });
+    std::thread writer([&] {  // one Middlebury .flo per pair (run_dense.cpp:16-57)
+      for (;;) {
+        Chunk* c = done_q.pop();
+        if (c->m == 0) break;
+        for (int k = 0; k < c->m; ++k) {
+          if (!c->ok[k]) continue;
+          std::string err;
+          if (!ofdis_host::write_flo(pairs[c->c0 + k].out, c->full.get() + k * flo_floats, width_org, height_org, &err)) {
+            fprintf(stderr, "%s\n", err.c_str());
+            ++failed;
+          }
+        }
+        free_q.push(c);
+      }
+    });
+    for (;;) {  // the device stage, on this thread (the one bound to the GPU)
+      Chunk* c = ready_q.pop();
+      if (c->m == 0) {
+        done_q.push(c);
+        break;
+      }
+      if (stop) {  // (drain what the reader had already queued)
+        free_q.push(c);
+        continue;
+      }
+      const int m = c->m;
       const double t0 = now_ms();
-      int rc = ofdis_memcpy_h2d(da, ha.data(), img_bytes * C);
-      if (!rc) rc = ofdis_memcpy_h2d(db, hb.data(), img_bytes * C);
+      int rc = ofdis_memcpy_h2d(da, c->ha.get(), img_bytes * C);
+      if (!rc) rc = ofdis_memcpy_h2d(db, c->hb.get(), img_bytes * C);
       if (!rc) rc = ofdis_batch_build_pyramids_u8(b, (const uint8_t*)da, (const uint8_t*)db, width_org, height_org, nullptr);
       for (int attempt = 0; !rc && attempt < 2; ++attempt) {
         rc = ofdis_batch_run(b, nullptr);
@@ -128,21 +220,20 @@ void run_share(const std::vector<Pair>& pairs, const ofdis_params& p0, int width
         }
         break;
       }
-      if (!rc) rc = ofdis_memcpy_d2h(full.data(), dfull, flo_floats * sizeof(float) * m);
+      if (!rc) rc = ofdis_memcpy_d2h(c->full.get(), dfull, flo_floats * sizeof(float) * m);
       sh->ms_compute += now_ms() - t0;
       if (rc) {
-        bail("chunk");
-        break;
+        sh->error = std::string("chunk: ") + ofdis_last_error();
+        failed += sh->hi - c->c0;  // this chunk and everything after it
+        stop = true;
+        free_q.push(c);
+        continue;
       }
-      for (int k = 0; k < m; ++k) {
-        if (!ok[k]) continue;
-        std::string err;
-        if (!ofdis_host::write_flo(pairs[c0 + k].out, full.data() + k * flo_floats, width_org, height_org, &err)) {
-          fprintf(stderr, "%s\n", err.c_str());
-          ++sh->failed;
-        }
-      }
+      done_q.push(c);
     }
+    reader.join();
+    writer.join();
+    sh->failed = failed;
   }
   if (dfull) ofdis_dev_free(dfull);
   if (da) ofdis_dev_free(da);
@@ -183,7 +274,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "%s lists no pairs\n", argv[1]);
     return 1;
   }
-  int k = 2, chunk = 256;
+  int k = 2, chunk = 64;  // (measured: the file system sets the pace; 64-pair chunks keep the three stages busy from the start)
   bool dry_run = false;
   std::vector<int> devices;
   while (k < argc && argv[k][0] == '-' && argv[k][1] == '-') {
