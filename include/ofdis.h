@@ -36,9 +36,12 @@ extern "C" {
 #endif
 
 /* ABI version.  2 (round 5): ofdis_tuning grew to 16 ints (fused_tp_pipe, fused_xcu_spin, contract were appended in round 4
- * without a bump), ofdis_batch_status and ofdis_batch_upsample_frames were added.  A caller checks ofdis_version() ==
+ * without a bump), ofdis_batch_status and ofdis_batch_upsample_frames were added.  3 (round 6): streams, pinned host memory
+ * asynchronous copies and events (ofdis_stream_create, ofdis_host_alloc, ofdis_memcpy_h2d_async / _d2h_async,
+ * ofdis_event_*), ofdis_build_id; ofdis_tuning grew to
+ * 18 ints (fused_xcu_drop, prep_densify) and fused_xcu_spin became a time in microseconds.  A caller checks ofdis_version() ==
  * OFDIS_VERSION before passing structs (of_dis_amd/capi.py does at load). */
-#define OFDIS_VERSION 2
+#define OFDIS_VERSION 3
 
 /* status codes (the reference reports nothing and has UB on bad input; we return a status) */
 enum {
@@ -82,6 +85,10 @@ int ofdis_params_oppoint(ofdis_params* p, int op_point, int width_org, int noc);
 
 const char* ofdis_last_error(void);
 int ofdis_version(void);
+/* Identity of the kernels in this library: a hash over the kernel sources and compiler flags it was built from
+ * (of_dis_amd/build.py: source_id).  Counter-derived measurements (profiles/traffic_*.json) carry the id of the library
+ * they were collected on; bench.py attaches them only to a library with the same id. */
+const char* ofdis_build_id(void);
 /* number of HIP devices visible / select one (one process per GPU: call once at start) */
 int ofdis_device_count(void);
 int ofdis_set_device(int device);
@@ -173,7 +180,8 @@ const float* ofdis_batch_flow(const ofdis_batch* b);
 /* After the caller has synchronised the stream(s) of the context's last pass by its own means: OFDIS_OK, or
  * OFDIS_ERR_DEVICE when that pass's results are invalid.  The one kernel that can report this is the cross-CU variant of the
  * fused TV kernel (contexts of <= 768 frames; ofdis_tuning::fused_xcu_max): its workgroups hand rows to each other through
- * memory and wait, bounded, for workgroups the dispatcher started earlier; a wait that expires marks the pass as failed.
+ * memory and wait, bounded (ofdis_tuning::fused_xcu_spin: 50 ms), for workgroups the dispatcher started earlier; a wait that
+ * expires marks the pass as failed.
  * The failure stays with the context until its next ofdis_batch_run, which no longer uses the variant: run again.
  * ofdis_batch_download, ofdis_flow (which repeats the pass itself) and ofdis_sync on the stream of the pass report the same
  * condition; callers that synchronise through HIP directly call this. */
@@ -234,14 +242,23 @@ typedef struct ofdis_tuning {
                        * iterations of a strip on one compute unit share the derivative records through the L2) instead of
                        * one wavefront per strip walking all iterations.  0 = never, 1 = where it is faster (levels of
                        * more than 32 rows under the fused contract), 2 = always                    OFDIS_FUSED_TP_PIPE */
-  int fused_xcu_spin; /* re-reads (~1 us each) a workgroup of that variant waits for a hand-over row before it reports the
-                       * pass as failed; 0 = the default, 2^22 (seconds)                          OFDIS_FUSED_XCU_SPIN */
+  int fused_xcu_spin; /* microseconds a workgroup of that variant waits for a hand-over row (device wall clock) before it
+                       * reports the pass as failed and carries on without waiting; 0 = the default, 50 000 (50 ms: a
+                       * thousand times the longest healthy wait, and the most a drop-in call can lose before its pass is
+                       * repeated on the other mapping); 1 forces the failure                     OFDIS_FUSED_XCU_SPIN */
   int contract;       /* ARITHMETIC CONTRACT -- the one knob that changes bits.  0 = exact (default) and 1 = fused, both
                        * stated at the top of this file: exact is bit-identical to the reference build, fused the tolerance contract of the
                        * north star (flow within 1e-3 px of the reference): every kernel compiled a second time with
                        * multiply-adds contracted to v_fma_f32 and the hardware's 1-ulp reciprocal / square root in place
                        * of the correctly rounded ones -- same algorithm, same control flow, fewer instructions.  A context
                        * fixes it at creation, like fused_tv.                                OFDIS_CONTRACT=fused -> 1 */
+  int fused_xcu_drop; /* TEST HOOK, 0 in production: 1 = the first fixed-point iteration of the cross-CU variant withholds its
+                       * hand-over rows, so that the iteration behind it really waits out fused_xcu_spin (what a dispatcher
+                       * that broke the variant's ordering assumption would cause): tests/test_gpu_xcu.py measures what
+                       * the failure protocol costs at the DEFAULT bound with it                  OFDIS_FUSED_XCU_DROP */
+  int prep_densify;   /* 1: on the fused TV path (gray 8x8 patches, step-4 grid) the warp + derivatives kernel densifies the
+                       * flow from the patch results itself (PatGridClass::AggregateFlowDense inside tv_prep_kernel): no
+                       * densification launch, no round trip of the dense flow; 0: separate kernel  OFDIS_NO_PREP_DENSIFY -> 0 */
 } ofdis_tuning;
 int ofdis_get_tuning(ofdis_tuning* out);
 int ofdis_set_tuning(const ofdis_tuning* in);
@@ -285,7 +302,43 @@ void ofdis_dev_free(void* p);
 int ofdis_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int ofdis_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int ofdis_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+/* Waits for `stream` (NULL = the calling thread's current device's default stream).  Also reports -- once, as
+ * OFDIS_ERR_DEVICE -- a lost hand-over of the cross-CU fused TV variant (ofdis_batch_status) of every context whose last
+ * pass was enqueued on that stream; for the NULL stream, which exists once per device, only the contexts of the calling
+ * thread's current device. */
 int ofdis_sync(void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Streams, pinned host memory and asynchronous copies (version 3): what a host loop needs to keep the link and the GPU
+ * busy at the same time -- the reference's per-pair upload / download (run_dense.cpp:326-344 convertTo + pyramid on the
+ * host, :406-421 resize + crop + .flo) becomes: pinned 8-bit frames -> ofdis_memcpy_h2d_async -> ofdis_batch_build_pyramids_u8
+ * -> ofdis_batch_run -> ofdis_batch_upsample_frames -> ofdis_memcpy_d2h_async, all enqueued on ONE stream per slot, with
+ * two or more slots (context + stream + buffers) in flight so that one slot's download overlaps the next slot's upload
+ * and kernels (host/run_seq_main.cpp).  Several small passes in flight on several streams is also how a share of a few
+ * dozen pairs per GPU (BASELINE configs[4] at 8 GPUs) keeps the chip busy: DESIGN.md 6, bench.py `small_batch.depth`.
+ * ------------------------------------------------------------------------------------------- */
+/* a non-blocking stream on the calling thread's current device; NULL on failure (ofdis_last_error) */
+void* ofdis_stream_create(void);
+void ofdis_stream_destroy(void* stream);
+/* page-locked host memory, usable with every visible device (hipHostMallocPortable); NULL on failure */
+void* ofdis_host_alloc(size_t bytes);
+void ofdis_host_free(void* p);
+/* enqueue a copy on `stream`; the host buffer must stay valid until the stream has been synchronised.  With memory from
+ * ofdis_host_alloc the copy is a DMA that overlaps kernels and copies of other streams; with pageable memory it still
+ * works, staged and partly synchronous, like hipMemcpyAsync */
+int ofdis_memcpy_h2d_async(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int ofdis_memcpy_d2h_async(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+/* Events order work across streams without the host.  Why a host loop wants them: uploads share the link's one direction
+ * and downloads the other, so the copies of consecutive chunks belong on ONE upload stream and ONE download stream (each
+ * in order) beside the compute stream(s) -- two chunks that each run upload, kernels, download on a stream of their own fall
+ * into lock step (both upload, then both download) and the two directions never overlap (tools/link_probe.py: 12.2 k
+ * against 15 k pairs/s).  ofdis_event_record marks a point of `stream`; ofdis_stream_wait_event makes `stream` wait for
+ * the last recorded point (a never-recorded event is complete); ofdis_event_sync blocks the host until it is reached. */
+void* ofdis_event_create(void);
+void ofdis_event_destroy(void* event);
+int ofdis_event_record(void* event, void* stream);
+int ofdis_stream_wait_event(void* stream, void* event);
+int ofdis_event_sync(void* event);
 
 #ifdef __cplusplus
 }

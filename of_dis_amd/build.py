@@ -63,6 +63,33 @@ def abi_symbols():
     return sorted(set(re.findall(r"\b(ofdis_[a-z0-9_]+)\s*\(", src)))
 
 
+def source_id(csrc=None, extra_flags=None):
+    """Identity of what the kernels of a build are made of: a hash over every kernel / header source under csrc/ (not the
+    host/ mains), include/ofdis.h and the compiler flags above.  It is compiled into the library (ofdis_build_id()) and
+    stamped into profiles/traffic_*.json when the PMC counters are collected: bench.py attaches counter-derived figures only
+    to a library with the SAME id -- a kernel change without a PMC re-run cannot keep a stale roofline fraction."""
+    import hashlib
+    csrc = csrc or CSRC
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".inc")))
+    for name in names:
+        h.update(name.encode() + b"\0")
+        h.update(open(os.path.join(csrc, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "ofdis.h"), "rb").read())
+    h.update(repr((BASEFLAGS, sorted(CONTRACT_FLAGS.items()), sorted(PER_FILE_FLAGS.items()),
+                   sorted((extra_flags or {}).items()))).encode())
+    return h.hexdigest()[:16]
+
+
+def _build_id_header(csrc, outdir, extra_flags=None):
+    """outdir/ofdis_build_id.h (included by ofdis_capi.hip), rewritten only when the id changes."""
+    path = os.path.join(outdir, "ofdis_build_id.h")
+    text = f'#define OFDIS_BUILD_ID "{source_id(csrc, extra_flags)}"\n'
+    if not os.path.exists(path) or open(path).read() != text:
+        open(path, "w").write(text)
+    return path
+
+
 def _version_script():
     """Linker version script exporting include/ofdis.h and nothing else (kernel handles, inline members of the context
     struct and the runtime's registration symbols stay local)."""
@@ -100,14 +127,18 @@ def compile_units(csrc, outdir, force=False, verbose=False, extra_flags=None):
     headers = [os.path.join(csrc, h) for h in os.listdir(csrc) if h.endswith((".h", ".inc"))]
     headers.append(os.path.join(ROOT, "include", "ofdis.h"))
     headers.append(os.path.abspath(__file__))  # the flags live here
+    build_id_h = _build_id_header(csrc, outdir, extra_flags)  # changes whenever any kernel source or flag does
     objs, jobs = [], []
     units = [(src, c) for c in ("exact", "fused") for src in KERNEL_SOURCES] + [(src, "exact") for src in COMMON_SOURCES]
     for src, contract in units:
         sp = os.path.join(csrc, src)
         suffix = ".o" if contract == "exact" else "." + contract + ".o"
         obj = os.path.join(outdir, src.replace(".hip", suffix))
-        if force or _newer(obj, [sp] + headers):
+        deps = [sp] + headers + ([build_id_h] if src == "ofdis_capi.hip" else [])
+        if force or _newer(obj, deps):
             flags = PER_FILE_FLAGS.get(src, []) + (extra_flags or {}).get(src, [])
+            if src == "ofdis_capi.hip":
+                flags = flags + ["-I", outdir]
             jobs.append([hipcc] + BASEFLAGS + CONTRACT_FLAGS[contract] + flags + ["-c", sp, "-o", obj])
         objs.append(obj)
     if jobs:  # the translation units are independent: compile them side by side

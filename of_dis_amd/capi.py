@@ -33,8 +33,10 @@ ABI_SYMBOLS = [
     "ofdis_varref_level", "ofdis_dev_alloc", "ofdis_dev_free", "ofdis_memcpy_h2d", "ofdis_memcpy_d2h", "ofdis_memcpy_d2d", "ofdis_sync",
     "ofdis_batch_set_graph", "ofdis_batch_status", "ofdis_flow_cache_clear", "ofdis_get_tuning", "ofdis_set_tuning", "ofdis_batch_kernel_times", "ofdis_device_pci_bus_id",
     "ofdis_batch_upsample_frames",
+    "ofdis_build_id", "ofdis_stream_create", "ofdis_stream_destroy", "ofdis_host_alloc", "ofdis_host_free", "ofdis_memcpy_h2d_async", "ofdis_memcpy_d2h_async",
+    "ofdis_event_create", "ofdis_event_destroy", "ofdis_event_record", "ofdis_stream_wait_event", "ofdis_event_sync",
 ]
-OFDIS_VERSION = 2  # include/ofdis.h: the struct layouts below (OfdisTuning: 16 ints) belong to this ABI version
+OFDIS_VERSION = 3  # include/ofdis.h: the struct layouts below (OfdisTuning: 18 ints) belong to this ABI version
 
 
 class OfdisTuning(C.Structure):
@@ -42,7 +44,7 @@ class OfdisTuning(C.Structure):
     (0 = exact arithmetic, 1 = the FMA / fast-reciprocal tolerance contract)."""
     _fields_ = [(n, C.c_int) for n in ("gray8", "rgb12", "rgb12_lpp", "fused_tv", "fused_mw_max", "fused_split",
                                        "finish_fusion", "fused_strip", "prep_band_rows", "graph", "flow_dma", "flow_whole",
-                                       "fused_xcu_max", "fused_tp_pipe", "fused_xcu_spin", "contract")]
+                                       "fused_xcu_max", "fused_tp_pipe", "fused_xcu_spin", "contract", "fused_xcu_drop", "prep_densify")]
 
 
 class OfdisError(RuntimeError):
@@ -63,12 +65,30 @@ def lib():
             raise OfdisError(f"{LIB_PATH} has ABI version {L.ofdis_version()}, this binding expects {OFDIS_VERSION}: "
                              "rebuild with `python -m of_dis_amd.build`")
         L.ofdis_last_error.restype = C.c_char_p
+        L.ofdis_build_id.restype = C.c_char_p
         L.ofdis_dev_alloc.restype = VP
         L.ofdis_dev_alloc.argtypes = [C.c_size_t]
         L.ofdis_dev_free.argtypes = [VP]
         L.ofdis_memcpy_h2d.argtypes = [VP, VP, C.c_size_t]
         L.ofdis_memcpy_d2h.argtypes = [VP, VP, C.c_size_t]
         L.ofdis_sync.argtypes = [VP]
+        L.ofdis_stream_create.restype = VP
+        L.ofdis_stream_create.argtypes = []
+        L.ofdis_stream_destroy.restype = None
+        L.ofdis_stream_destroy.argtypes = [VP]
+        L.ofdis_host_alloc.restype = VP
+        L.ofdis_host_alloc.argtypes = [C.c_size_t]
+        L.ofdis_host_free.restype = None
+        L.ofdis_host_free.argtypes = [VP]
+        L.ofdis_memcpy_h2d_async.argtypes = [VP, VP, C.c_size_t, VP]
+        L.ofdis_memcpy_d2h_async.argtypes = [VP, VP, C.c_size_t, VP]
+        L.ofdis_event_create.restype = VP
+        L.ofdis_event_create.argtypes = []
+        L.ofdis_event_destroy.restype = None
+        L.ofdis_event_destroy.argtypes = [VP]
+        L.ofdis_event_record.argtypes = [VP, VP]
+        L.ofdis_stream_wait_event.argtypes = [VP, VP]
+        L.ofdis_event_sync.argtypes = [VP]
         L.ofdis_memcpy_d2d.argtypes = [VP, VP, C.c_size_t, VP]
         L.ofdis_batch_create.argtypes = [C.POINTER(VP), C.POINTER(OfdisParams), C.c_int]
         L.ofdis_batch_destroy.argtypes = [VP]
@@ -117,6 +137,11 @@ def lib():
 def check(rc):
     if rc != 0:
         raise OfdisError(f"ofdis status {rc}: {lib().ofdis_last_error().decode()}")
+
+
+def build_id():
+    """ofdis_build_id(): the hash of the kernel sources + flags the loaded library was built from."""
+    return lib().ofdis_build_id().decode()
 
 
 def device_pci_bus_id(device):
@@ -171,6 +196,83 @@ class Dev:
     def free(self):
         if self.ptr:
             lib().ofdis_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Stream:
+    """A non-blocking HIP stream owned through ofdis_stream_create / ofdis_stream_destroy (`.ptr` goes wherever the ABI takes
+    a `stream`)."""
+
+    def __init__(self):
+        self.ptr = lib().ofdis_stream_create()
+        if not self.ptr:
+            raise OfdisError(f"ofdis_stream_create: {lib().ofdis_last_error().decode()}")
+
+    def sync(self):
+        check(lib().ofdis_sync(self.ptr))
+
+    def close(self):
+        if self.ptr:
+            lib().ofdis_stream_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Event:
+    """A HIP event owned through ofdis_event_create / ofdis_event_destroy: orders work across streams without the host."""
+
+    def __init__(self):
+        self.ptr = lib().ofdis_event_create()
+        if not self.ptr:
+            raise OfdisError(f"ofdis_event_create: {lib().ofdis_last_error().decode()}")
+
+    def record(self, stream):
+        check(lib().ofdis_event_record(self.ptr, stream.ptr if isinstance(stream, Stream) else stream))
+
+    def wait(self, stream):
+        """make `stream` wait for the last recorded point"""
+        check(lib().ofdis_stream_wait_event(stream.ptr if isinstance(stream, Stream) else stream, self.ptr))
+
+    def sync(self):
+        check(lib().ofdis_event_sync(self.ptr))
+
+    def close(self):
+        if self.ptr:
+            lib().ofdis_event_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HostBuf:
+    """Page-locked host memory (ofdis_host_alloc) seen as a numpy array: the source / destination of the asynchronous copies."""
+
+    def __init__(self, shape, dtype=_f32):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = lib().ofdis_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise OfdisError(f"ofdis_host_alloc: {lib().ofdis_last_error().decode()}")
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), shape=(self.nbytes,)).view(dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().ofdis_host_free(self.ptr)
             self.ptr = None
 
     def __del__(self):

@@ -1199,16 +1199,16 @@ hipError_t launch_patch_optimize_rgb12(const DisArgs& a, hipStream_t s) {
 
 // Does launch_patch_optimize run a kernel that honours DisArgs::pixw for these arguments?  (The 16-lanes-per-patch RGB 12x12
 // kernels of either contract; the caller passes pixw to the patch kernel and to the densification only then.)
-bool patch_pixel_weights_supported(const DisArgs& a) {
-  const ofdis_tuning tn = tuning();
+bool patch_pixel_weights_supported(const DisArgs& a, const ofdis_tuning* tnp) {
+  const ofdis_tuning tn = tnp ? *tnp : tuning();
   const int rgb12_lpp = tn.rgb12_lpp == 0 ? 16 : tn.rgb12_lpp;
   return a.g.novals == 432 && a.g.P == 12 && !a.stereo && (a.costfct == 0 || a.costfct == 1) && tn.rgb12 && rgb12_lpp == 16;
 }
 
-hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s) {
+hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s, const ofdis_tuning* tnp) {
   const int M = (a.g.novals + 63) / 64;
   const bool full = a.g.novals == 64 * M;
-  const ofdis_tuning tn = tuning();
+  const ofdis_tuning tn = tnp ? *tnp : tuning();
   const bool gray8 = a.g.noc == 1 && a.g.P == 8 && !a.stereo && tn.gray8;
   // RGB 12x12 (operating points 3 and 4, BASELINE configs[3]): 432 entries, 6 full groups of 64 + 48.  ofdis_tuning::rgb12_lpp = 32:
   // two patches per wavefront (the scalar solve, predicates and every reduction instruction shared by two patches:

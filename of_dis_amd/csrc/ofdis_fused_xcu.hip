@@ -38,20 +38,23 @@ namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled fo
 // Tag 0 = not yet written: the array is zeroed when it is allocated, and the fetch wave puts every granule it has taken
 // back to zero, so a launch leaves the array as it found it (no memset per launch).  Block index = iteration * G8 +
 // group with G8 a multiple of 8: an iteration only waits for a LOWER block index, and the iterations of a group share an
-// XCD under the observed round-robin placement (speed only).  A wait that exceeds the spin limit (default XC_SPIN_LIMIT
-// re-reads of ~1 us: seconds; ofdis_tuning::fused_xcu_spin) sets the context's error word and the wavefront carries on
-// without waiting: the pass is reported as failed, nothing hangs.
+// XCD under the observed round-robin placement (speed only).  A wait that lasts longer than the bound (device wall clock;
+// default XC_WAIT_US = 50 ms, a thousand times the longest healthy wait: a predecessor that IS running gains a row every
+// 0.4 us, a few times that with several passes sharing the CU; ofdis_tuning::fused_xcu_spin) sets the context's error word and
+// the wavefront carries on without waiting: the pass is reported as failed, nothing hangs, and a drop-in call loses at most
+// that bound before its pass is repeated on another mapping (round 6; the bound used to be a count of re-reads worth seconds).
 constexpr int XC_AHEAD = 3;  // steps a row is requested before the fetch wave takes it (= requests in flight; 3 x 0.4 us = the latency)
 constexpr int XC_LEAD = 1;   // rows the fetch wave lets the predecessor gain, beyond its requests, before it (re)starts
 constexpr int XC_SD = 1;     // rows between consecutive SOR sweeps in the solve wave
 constexpr int XC_RING = 4;   // rows of the LDS du/dv ring (a power of two > 2)
 constexpr unsigned XC_TAG = 1u;
-constexpr unsigned XC_SPIN_LIMIT = 1u << 22;  // re-reads of one row (~1 us each) before the wavefront gives up
+constexpr unsigned XC_WAIT_US = 50000;  // microseconds a wavefront waits for one row before it gives up
+constexpr unsigned XC_FLAG_DROP = 1u;   // test hook (ofdis_tuning::fused_xcu_drop): iteration 0 withholds its hand-over rows
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NS, bool BRIGHT>
 __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, const int R, const int G8, float* const xbuf,
-                                                            int* const err, const unsigned spin_limit) {
+                                                            int* const err, const unsigned wait_ticks, const unsigned flags) {
   constexpr int U = 6;
   constexpr int PDW = 5, PDD = 3, PDU = 3;  // (du/dv of row t+3 are read from the ring in the step that first uses them)
   static_assert(XC_SD * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
@@ -262,14 +265,22 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
       auto request = [&](int drow) { return __builtin_amdgcn_raw_buffer_load_b128(rsX, vo4, drow * h * 16, 16 /* sc1 */); };
       auto inrange = [&](int tau) { const int x = tau - j; return (x >= 0) & (x < rw); };  // this lane's pixel of row tau exists
       auto ready = [&](const u32x4& q, bool inr) { return !inr | ((q[1] == XC_TAG) & (q[3] == XC_TAG)); };
-      // re-reads row tau until every existing pixel's granules carry their tag (bounded)
+      // re-reads row tau until every existing pixel's granules carry their tag; bounded by the device's constant-rate wall
+      // clock (wait_ticks = 0: gives up at the first re-read -- how the tests force the failure)
       auto wait_row = [&](int tau) {
         const int drow = wrap_row(tau);
         const bool inr = inrange(tau);
         u32x4 g = request(drow);
-        unsigned spins = 0;
+        unsigned long long t0 = 0;
+        bool started = false;
         while (!dead && __builtin_amdgcn_ballot_w64(!ready(g, inr)) != 0) {
-          if (++spins >= spin_limit) {
+          const unsigned long long now = wall_clock64();
+          if (!started) { t0 = now; started = true; }
+          // (a pass is several launches: once one of them has given up -- the context's error word says so -- the others do
+          // not wait out the whole bound again: after 1/64 of it, ~0.8 ms, a waiting wavefront looks at the word)
+          const unsigned long long el = now - t0;
+          if (el >= (unsigned long long)wait_ticks ||
+              (el >= (unsigned long long)(wait_ticks >> 6) && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
             dead = true;
             if (lane == 0) atomicExch(err, 1);
             break;
@@ -419,7 +430,8 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
           const bool on = row_ok & (ig >= 0) & (ig < rw);
           if (it < n_iters - 1) {  // hand the finished row to the next iteration's workgroup: one write-through granule pair
             const u32x4 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), XC_TAG, __builtin_bit_cast(unsigned, nv[NS - 1]), XC_TAG};
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsX, on ? vo4 : 0x7ffffff0, srow * h * 16, 16 /* sc1 */);
+            const bool hand = on & !((flags & XC_FLAG_DROP) != 0 && it == 0);  // (test hook: iteration 0 never hands over)
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsX, hand ? vo4 : 0x7ffffff0, srow * h * 16, 16 /* sc1 */);
           } else if (a.flow_out) {  // last iteration: the refined flow itself, AoS (refine_variational.cpp:209-221, 92-99)
             const int frow = taut - 1 - XC_SD * (NS - 1);  // the row the last sweep finishes now
             const float* q = wring + ((frow & 15) * 2) * 64 + lane;
@@ -444,13 +456,22 @@ __global__ __launch_bounds__(256) void tv_fused_xcu_kernel(const FusedArgs a, co
 hipError_t launch_tv_fused_xcu(const FusedArgs& a, const FusedXcu& x, int waves, int R, hipStream_t s) {
   const int G8 = (waves + 7) & ~7;  // workgroups per fixed-point iteration
   if (!x.xbuf || !x.err) return hipErrorInvalidValue;  // never without an error word: a lost hand-over must be reportable
-  const unsigned spin = x.spin_limit ? x.spin_limit : XC_SPIN_LIMIT;
+  // the bound in ticks of the device's constant-rate wall clock (wall_clock64: 100 MHz on this chip; asked, not assumed);
+  // 1 us = "give up at the first re-read" (the tests' forced failure)
+  static const int clock_khz = [] {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    return khz;
+  }();
+  const unsigned us = x.wait_us ? x.wait_us : XC_WAIT_US;
+  const unsigned spin = us <= 1 ? 0u : (unsigned)std::min<unsigned long long>(0xffffffffull, (unsigned long long)us * clock_khz / 1000);
+  const unsigned flags = x.drop ? XC_FLAG_DROP : 0u;
   const bool bright = a.half_delta_over3 != 0.0f;
 #define OFDIS_XCU_LAUNCH(NS)                                                                                           \
   if (bright)                                                                                                          \
-    hipLaunchKernelGGL((tv_fused_xcu_kernel<NS, true>), dim3(a.n_inner * G8), dim3(256), 0, s, a, R, G8, x.xbuf, x.err, spin); \
+    hipLaunchKernelGGL((tv_fused_xcu_kernel<NS, true>), dim3(a.n_inner * G8), dim3(256), 0, s, a, R, G8, x.xbuf, x.err, spin, flags); \
   else                                                                                                                 \
-    hipLaunchKernelGGL((tv_fused_xcu_kernel<NS, false>), dim3(a.n_inner * G8), dim3(256), 0, s, a, R, G8, x.xbuf, x.err, spin)
+    hipLaunchKernelGGL((tv_fused_xcu_kernel<NS, false>), dim3(a.n_inner * G8), dim3(256), 0, s, a, R, G8, x.xbuf, x.err, spin, flags)
   switch (a.iterations) {
     case 1: OFDIS_XCU_LAUNCH(1); break;
     case 2: OFDIS_XCU_LAUNCH(2); break;

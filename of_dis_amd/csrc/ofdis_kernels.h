@@ -84,6 +84,12 @@ struct PrepArgs {
   float* wrec;        // [records][2] = wx, wy
   int S;              // frames per strip
   int band_rows;      // output rows per wavefront (0 = chosen by the launcher from the batch size)
+  // round 6, optional: densification inside this kernel (tv_prep_densifies).  With dens_p the dense flow is computed from the
+  // patch results -- [B][nop][2] displacements and [B][nop][64] weights in the internal grid-row-major layout (ofdis_dev.h:
+  // patch_slot, pweight_row), exactly what launch_densify would read -- and `flow` is not read.
+  const float* dens_p = nullptr;
+  const float* dens_pweight = nullptr;
+  int dens_nopw = 0, dens_noph = 0, dens_offw = 0, dens_offh = 0;
 };
 
 // compute_smoothness + compute_data + sub_laplacian x2 -> sys [B][7][w*h] in DIAG layout (ofdis_dev.h)
@@ -141,7 +147,8 @@ struct FusedXcu {
   int max_groups = 0;      // frame groups up to which the variant is launched (0 = never)
   int* err = nullptr;      // device-visible word, set to 1 when a hand-over row never arrived (results invalid); the variant
                            // is only launched with one
-  unsigned spin_limit = 0; // re-reads of one row (~1 us each) before a workgroup gives up; 0 = the default (2^22, seconds)
+  unsigned wait_us = 0;    // microseconds a workgroup waits for one row before it gives up; 0 = the default (50 ms), 1 = not at all
+  int drop = 0;            // test hook: the first iteration withholds its hand-over rows (ofdis_tuning::fused_xcu_drop)
 };
 
 

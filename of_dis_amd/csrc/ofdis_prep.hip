@@ -122,7 +122,13 @@ __device__ __forceinline__ void prep_sync() {
   else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int WPF>
+// DENS (round 6): the flow a row is warped with is not read from the densified AoS flow but DENSIFIED HERE from the patch
+// results (PatGridClass::AggregateFlowDense, patchgrid.cpp:213-275, for gray 8x8 patches on a step-4 grid: at most 2 x 2
+// patches cover a pixel; the arithmetic and candidate order of densify_quad_kernel, ofdis_dis.hip -- same bits): the
+// densification kernel, its launch and the round trip of the dense flow through HBM (8 bytes per pixel out and in again) go
+// away.  With lane = column and the grid-row-major weight layout (ofdis_dev.h: pweight_row) a wavefront's weight loads of
+// one image row are two contiguous runs per covering grid row, and every weight is read by exactly one lane.
+template <int WPF, bool DENS>
 __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, const int lpf_shift, const int nbands) {
   constexpr int C = 1;  // columns per lane
   using L = PrepLds<WPF>;
@@ -184,6 +190,28 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
     voI[k] = (flc * plane + a.pad * a.tmp_w + a.pad + xc[k]) * 4;
   }
   auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
+  // DENS: the (at most) 2 x 2 patches that cover pixel (x, y): grid columns bx - 1 and bx, where x is patch column 4 + tx and
+  // tx; grid rows by - 1 and by, where y is patch row 4 + ty and ty (densify_quad_kernel).  The column part is a per-lane
+  // constant, the row part wave-uniform: weights and displacements come through buffer resources based at the wavefront's
+  // first frame with a per-lane byte offset per grid column and a scalar offset per grid row.
+  const int nopw = a.dens_nopw, noph = a.dens_noph, nop = nopw * noph;
+  __amdgpu_buffer_rsrc_t rsPW = rsF, rsP = rsF;
+  int voPW[2] = {0, 0}, voP[2] = {0, 0};
+  bool okx[2] = {false, false};
+  if constexpr (DENS) {
+    static_assert(C == 1, "one column per lane");
+    rsPW = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dens_pweight + (size_t)f0 * nop * 64), 0, nfr * nop * 256, 0x00020000);
+    rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dens_p + (size_t)f0 * nop * 2), 0, nfr * nop * 8, 0x00020000);
+    const int xs = xc[0] - a.dens_offw + 4, bx = xs >> 2, tx = xs & 3;  // xs >= 1: offw < 4
+#pragma unroll
+    for (int col = 0; col < 2; ++col) {
+      const int gx = bx - 1 + col;
+      okx[col] = (gx >= 0) & (gx < nopw);
+      const int gxc = clampi(gx, 0, nopw - 1);
+      voPW[col] = (flc * nop * 64 + gxc * 8 + (col ? tx : 4 + tx)) * 4;
+      voP[col] = (flc * nop * 2 + gxc * 2) * 4;
+    }
+  }
 
   // Flush of a staged block (rows y0 .. y0+K-1 of every frame of this wavefront): the block's records sit in LDS as
   // [q][k] with q = x + k (mod w when S = 1: the diag rows of a frame wrap onto themselves), i.e. in diag order, so piece e
@@ -261,14 +289,60 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
   WarpTaps tp[C];          // fractions / mask of row r
   float t11[C], t12[C], t21[C], t22[C];  // taps of row r
   unsigned lf0[C], lf1[C], li1[C];       // raw flow / image values of the row requested last (row r+2 after the request)
+  unsigned dpw[4], dp0[4], dp1[4];       // DENS: weight and displacement of candidate c = 2 * (grid column) + (grid row)
   auto request_row = [&](int row) {      // flow + first image of `row`
     const int rr = min(row, h - 1);
+    if constexpr (DENS) {
+      const int ys = rr - a.dens_offh + 4, by = ys >> 2, ty = ys & 3;  // ys >= 1: offh < 4
+#pragma unroll
+      for (int rsel = 0; rsel < 2; ++rsel) {
+        const int gyc = clampi(by - 1 + rsel, 0, noph - 1), ky = rsel ? ty : 4 + ty;
+        const int soPW = (gyc * 8 + ky) * nopw * 32, soP = gyc * nopw * 8;
+#pragma unroll
+        for (int col = 0; col < 2; ++col) {
+          dpw[2 * col + rsel] = __builtin_amdgcn_raw_buffer_load_b32(rsPW, voPW[col], soPW, 0);
+          const auto pp = __builtin_amdgcn_raw_buffer_load_b64(rsP, voP[col], soP, 0);
+          const unsigned q0 = pp[0], q1 = pp[1];
+          dp0[2 * col + rsel] = q0; dp1[2 * col + rsel] = q1;
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < C; ++k) {
-      const auto f = __builtin_amdgcn_raw_buffer_load_b64(rsF, voF[k], rr * w * 8, 0);
-      const unsigned q0 = f[0], q1 = f[1];
-      lf0[k] = q0; lf1[k] = q1;
+      if constexpr (!DENS) {
+        const auto f = __builtin_amdgcn_raw_buffer_load_b64(rsF, voF[k], rr * w * 8, 0);
+        const unsigned q0 = f[0], q1 = f[1];
+        lf0[k] = q0; lf1[k] = q1;
+      }
       li1[k] = __builtin_amdgcn_raw_buffer_load_b32(rsI, voI[k], rr * a.tmp_w * 4, 0);
+    }
+  };
+  // the row requested last has arrived: its flow (DENS: the densification of pixel (x, row): candidates in the reference's
+  // order -- grid column ascending, then grid row --, the additions and quotients of densify_quad_kernel) and image value
+  auto take_row = [&](int row) {
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      if constexpr (DENS) {
+        const int ys = min(row, h - 1) - a.dens_offh + 4, by = ys >> 2;
+        const bool okr[2] = {by >= 1 && by - 1 < noph, by < noph};
+        float we = 0.0f, fu = 0.0f, fv = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool ok = okx[c >> 1] & okr[c & 1];
+          const float absw = div_rn(1.0f, fmaxf(2.0f, asf(dpw[c])));  // == 1.0f / x: numerator 1, denominator >= 2 (ofdis_dev.h)
+          const float nwe = we + absw, nfu = fu + asf(dp0[c]) * absw, nfv = fv + asf(dp1[c]) * absw;
+          we = ok ? nwe : we;
+          fu = ok ? nfu : fu;
+          fv = ok ? nfv : fv;
+        }
+        if (we > 0) {
+          fu /= we;
+          fv /= we;
+        }
+        nxt[k] = Pend{fu, fv, asf(li1[k])};
+      } else {
+        nxt[k] = Pend{asf(lf0[k]), asf(lf1[k]), asf(li1[k])};
+      }
     }
   };
   auto request_taps = [&](int row) {  // from nxt (row `row`): tap addresses, fractions, mask; the four loads
@@ -287,8 +361,7 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
   };
   // prologue: row r_begin's taps and row r_begin+1's flow in flight
   request_row(r_begin);
-#pragma unroll
-  for (int k = 0; k < C; ++k) nxt[k] = Pend{asf(lf0[k]), asf(lf1[k]), asf(li1[k])};
+  take_row(r_begin);
   request_taps(r_begin);
 #pragma unroll
   for (int k = 0; k < C; ++k) cur[k] = nxt[k];
@@ -311,8 +384,7 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
           Z[u][k] = i2 - cur[k].i1;
         }
         // the flow of row r+1 has arrived: its taps; then the flow of row r+2
-#pragma unroll
-        for (int k = 0; k < C; ++k) nxt[k] = Pend{asf(lf0[k]), asf(lf1[k]), asf(li1[k])};
+        take_row(r + 1);
         request_taps(r + 1);
 #pragma unroll
         for (int k = 0; k < C; ++k) cur[k] = nxt[k];
@@ -416,6 +488,9 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
 }
 
 bool tv_prep_supported(const TvGeom& t) { return t.noc == 1 && t.w >= 16 && t.w <= 128 && t.h >= 4 && t.h <= 64; }
+// Can launch_tv_prep densify the flow itself for this patch grid (PrepArgs::dens_*)?  The geometry of densify_quad_kernel:
+// gray 8x8 patches on a step-4 grid (operating point 2), at most 2 x 2 patches per pixel.
+bool tv_prep_densifies(const LevelGeom& g) { return g.noc == 1 && g.P == 8 && g.steps == 4 && g.offw < 4 && g.offh < 4; }
 
 hipError_t launch_tv_prep(const PrepArgs& a_in, hipStream_t s) {
   if (!tv_prep_supported(a_in.t) || a_in.S < 1) return hipErrorInvalidValue;
@@ -436,8 +511,15 @@ hipError_t launch_tv_prep(const PrepArgs& a_in, hipStream_t s) {
   }
   nbands = (h + a.band_rows - 1) / a.band_rows;
   const long long units = (long long)fgroups * nbands;
-  if (w > 64) hipLaunchKernelGGL(tv_prep_kernel<2>, dim3((unsigned)units), dim3(128), 0, s, a, lpf_shift, nbands);
-  else hipLaunchKernelGGL(tv_prep_kernel<1>, dim3((unsigned)units), dim3(64), 0, s, a, lpf_shift, nbands);
+  if (a.dens_p) {  // densification inside this kernel (tv_prep_densifies): patch results in, no dense flow read
+    if (!a.dens_pweight || a.dens_offw < 0 || a.dens_offw > 3 || a.dens_offh < 0 || a.dens_offh > 3 || a.dens_nopw < 1 || a.dens_noph < 1)
+      return hipErrorInvalidValue;
+    if (w > 64) hipLaunchKernelGGL((tv_prep_kernel<2, true>), dim3((unsigned)units), dim3(128), 0, s, a, lpf_shift, nbands);
+    else hipLaunchKernelGGL((tv_prep_kernel<1, true>), dim3((unsigned)units), dim3(64), 0, s, a, lpf_shift, nbands);
+    return hipGetLastError();
+  }
+  if (w > 64) hipLaunchKernelGGL((tv_prep_kernel<2, false>), dim3((unsigned)units), dim3(128), 0, s, a, lpf_shift, nbands);
+  else hipLaunchKernelGGL((tv_prep_kernel<1, false>), dim3((unsigned)units), dim3(64), 0, s, a, lpf_shift, nbands);
   return hipGetLastError();
 }
 

@@ -252,8 +252,11 @@ def _write_pairs(tmp_path, n, w, h, channels=1, seed0=500):
 def test_sequence_driver_matches_the_single_pair_binary(gpu, tmp_path):
     """SURVEY 8(e) in the host language of the reference: run_OF_INT_seq over 66 pairs (a chunk size that does not divide the
     share: the last chunk is short) writes, pair for pair, the BYTES the single-pair run_OF_INT writes (exact contract: the
-    chunk context runs other kernel mappings than the one-pair context, same bits); the split over two shares (--devices 0,0:
-    both on the one GPU of the test box, two host threads, two contexts) and another chunk size give the same files."""
+    chunk context runs other kernel mappings than the one-pair context, same bits); the split over two shares (two host
+    threads, two sets of contexts: on DISTINCT devices whenever the box has two -- the shares' PCI bus ids must then differ --
+    else --devices 0,0, both on the one GPU of the test box), another chunk size and other numbers of chunks in flight
+    (--depth 1 / 2 / 3: the device stage's slots, include/ofdis.h version 3) give the same files."""
+    import re
     w, h, n = 320, 192, 66
     pairs = _write_pairs(tmp_path, n, w, h)
     single = []
@@ -264,12 +267,19 @@ def test_sequence_driver_matches_the_single_pair_binary(gpu, tmp_path):
         assert r.returncode == 0, r.stderr
         single.append(open(fo, "rb").read())
     args = "5 3 12 12 0.05 0.95 0 8 0.40 0 1 0 1 10 10 5 1 3 1.6 1".split()
-    for tag, opts in (("one", ["--chunk", "32"]), ("two", ["--devices", "0,0", "--chunk", "20"])):
+    two_gpus = gpu.lib().ofdis_device_count() >= 2
+    devs = "0,1" if two_gpus else "0,0"
+    for tag, opts in (("one", ["--chunk", "32"]), ("two", ["--devices", devs, "--chunk", "20", "--depth", "3"]),
+                      ("d1", ["--chunk", "16", "--depth", "1"])):
         lst = tmp_path / f"{tag}.txt"
         lst.write_text("# pairs of the test\n" + "".join(f"{fa} {fb} {tmp_path}/{tag}{k:03d}.flo\n" for k, (fa, fb) in enumerate(pairs)))
-        r = subprocess.run([SEQ[1], str(lst)] + opts + args, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([SEQ[1], str(lst)] + opts + args[:-1] + ["2"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (r.stdout, r.stderr)
-        assert f"TIME ({n} pairs on {1 if tag == 'one' else 2} device share(s)" in r.stdout
+        assert f"TIME ({n} pairs on {2 if tag == 'two' else 1} device share(s)" in r.stdout
+        ids = re.findall(r"TIME \(share \d+: device \d+ \[([0-9a-fA-F:.]+)\]", r.stdout)
+        assert len(ids) == (2 if tag == "two" else 1), r.stdout
+        if tag == "two" and two_gpus:  # one GPU per share, really
+            assert len(set(ids)) == 2, f"two shares on {ids}: not two devices"
         for k in range(n):
             got = open(tmp_path / f"{tag}{k:03d}.flo", "rb").read()
             assert got == single[k], f"{tag}: pair {k} differs from the single-pair binary's .flo"
@@ -296,10 +306,22 @@ def test_sequence_driver_rgb_and_unreadable_pairs(gpu, tmp_path):
     lst.write_text("\n".join(lines) + "\n")
     r = subprocess.run([SEQ[3], str(lst), "--chunk", "3", "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1, (r.stdout, r.stderr)
-    assert "nope.ppm" in r.stderr and "like the first pair" in r.stderr
+    assert "nope.ppm" in r.stderr and "like the first readable pair" in r.stderr
     assert not os.path.exists(tmp_path / "nope.flo") and not os.path.exists(tmp_path / "odd.flo")
     for k, (fa, fb) in enumerate(pairs):
         fo = str(tmp_path / f"s{k}.flo")
         r1 = subprocess.run([EXE[3], fa, fb, fo, "3"], capture_output=True, text=True, timeout=120)
         assert r1.returncode == 0, r1.stderr
         assert open(fo, "rb").read() == open(tmp_path / f"o{k}.flo", "rb").read(), f"rgb pair {k}"
+    # an unreadable FIRST pair does not end the run (the geometry comes from the first readable image, or from --size), and
+    # the count of failed pairs is the number of .flo files that were not written
+    for k in range(n):
+        os.remove(tmp_path / f"o{k}.flo")
+    for extra in ([], ["--size", str(w), str(h)]):
+        lst.write_text("\n".join([lines[2]] + lines[:2] + lines[3:]) + "\n")
+        r = subprocess.run([SEQ[3], str(lst), "--chunk", "3"] + extra + ["3"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 1, (r.stdout, r.stderr)
+        assert "nope.ppm" in r.stderr
+        for k in range(n):
+            assert open(tmp_path / f"s{k}.flo", "rb").read() == open(tmp_path / f"o{k}.flo", "rb").read(), f"rgb pair {k} ({extra})"
+            os.remove(tmp_path / f"o{k}.flo")

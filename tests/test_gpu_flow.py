@@ -526,11 +526,12 @@ def test_kernel_selection_does_not_change_results(gpu, orc, nfr):
     b.close()
 
 
-@pytest.mark.parametrize("knob", ["gray8", "fused_tv", "finish_fusion"])
+@pytest.mark.parametrize("knob", ["gray8", "fused_tv", "finish_fusion", "prep_densify"])
 def test_fallback_kernels_at_the_benchmark_geometry(gpu, orc, knob):
     """The generic patch kernel (8 lanes per patch), the unfused TV path (tiled warp / derivatives / system kernels +
-    wavefront SOR) and the separate finish kernel after a multi-wave fused TV launch must give the same bits as the kernels
-    they stand in for (ofdis_tuning, include/ofdis.h)."""
+    wavefront SOR), the separate finish kernel after a multi-wave fused TV launch and the separate densification kernel
+    (round 6: the warp + derivatives kernel densifies by itself) must give the same bits as the kernels they stand in for
+    (ofdis_tuning, include/ofdis.h)."""
     old = gpu.set_tuning(**{knob: 0})
     p, pa, pb, _, _ = synth_case(1024, 436, 1600, 1, 2, 1)
     try:
@@ -563,6 +564,35 @@ def test_fused_tv_strips(gpu, orc, nfr, strip, size, pipe):
         out = b.download_all()
         for s in range(nfr):
             assert_bits_equal(out[s], refs[(s * s + s // 3) % 3], f"{nfr} frames, strips of {strip}, slot {s}")
+        b.close()
+    finally:
+        gpu.restore_tuning(old)
+
+
+@pytest.mark.parametrize("dens", [0, 1])
+@pytest.mark.parametrize("size,nfr", [((1024, 436), 3), ((1000, 436), 2), ((520, 264), 5), ((264, 200), 9), ((776, 392), 2),
+                                      ((1024, 436), 70)])
+def test_densification_inside_the_warp_kernel(gpu, orc, size, nfr, dens):
+    """PatGridClass::AggregateFlowDense inside tv_prep_kernel (ofdis_tuning::prep_densify, the default) against the separate
+    densification kernel: same bits as the oracle either way, for grids whose offsets (offw, offh), widths (one or two
+    wavefronts per row, several frames per wavefront) and borders differ, in batches that take the small- and the
+    large-batch mappings of the kernels around it."""
+    w, h = size
+    cases = [synth_case(w, h, 3100 + k, 1, 2, 1) for k in range(2)]
+    p = cases[0][0]
+    refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
+    old = gpu.set_tuning(prep_densify=dens)
+    try:
+        b = gpu.Batch(p, nfr)
+        for l in range(p.sc_l, p.sc_f + 1):
+            for kind in range(4):
+                planes = [c[1][kind][l] if kind < 3 else c[2][0][l] for c in cases]
+                b.set_input(l, kind, np.stack([planes[(s * s) % 2] for s in range(nfr)]))
+        for rep in range(2):
+            b.run()
+            out = b.download_all()
+            for s in range(nfr):
+                assert_bits_equal(out[s], refs[(s * s) % 2], f"{w}x{h}, {nfr} frames, prep_densify={dens}, pass {rep}, slot {s}")
         b.close()
     finally:
         gpu.restore_tuning(old)

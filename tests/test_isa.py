@@ -103,8 +103,10 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     ("tv_fused_kernelILi3ELb1ELi1EE", 168, "tv_fused_kernel<3, true, 1>, iteration-pipelined mapping: three wavefronts per SIMD (three workgroups of four iterations per CU)"),
     ("densify_kernelILb1EE", 64, "densify_kernel<true>: eight wavefronts per SIMD"),
     ("densify_quad_kernel", 64, "densify_quad_kernel: eight wavefronts per SIMD"),
-    ("tv_prep_kernelILi2EE", 84, "tv_prep_kernel<2> (two wavefronts per 128-column row): six wavefronts per SIMD by registers"),
-    ("tv_prep_kernelILi1EE", 84, "tv_prep_kernel<1>: six wavefronts per SIMD by registers"),
+    ("tv_prep_kernelILi2ELb0EE", 84, "tv_prep_kernel<2, false> (two wavefronts per 128-column row): six wavefronts per SIMD by registers"),
+    ("tv_prep_kernelILi1ELb0EE", 84, "tv_prep_kernel<1, false>: six wavefronts per SIMD by registers"),
+    ("tv_prep_kernelILi2ELb1EE", 96, "tv_prep_kernel<2, true> (densification inside: twelve pending registers instead of two): five wavefronts per SIMD by registers"),
+    ("tv_prep_kernelILi1ELb1EE", 96, "tv_prep_kernel<1, true>: five wavefronts per SIMD by registers"),
 ])
 def test_register_budgets(kernels, pattern, max_vgprs, what):
     hits = [(n, m) for n, m in kernels.items() if pattern in n]

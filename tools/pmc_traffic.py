@@ -25,15 +25,36 @@ CLASS = {"warp": "warp", "derivatives": "derivatives", "tv_prep": "derivatives",
          "tv_fused": "tv_fused", "patch_optimize": "patch_optimize", "densify": "densify", "tv_finish": "tv_finish"}
 
 
+NLEVELS = 3  # operating point 2 at 1024x436: levels 5, 4, 3 -- a pass launches every class once per level, coarsest first
+SC_F = 5
+LEVELS = {}   # counter -> class -> level -> value summed over the passes
+
+
 def collect(path, counter, scale):
+    """Sum of `counter` per kernel class; also per pyramid LEVEL (LEVELS[counter]): the dispatches of a class in dispatch
+    order are level 5, 4, 3, 5, 4, 3, ... (classes launched exactly once per level and pass)."""
     acc = defaultdict(float)
-    for r in csv.DictReader(open(path)):
+    per = defaultdict(dict)  # class -> dispatch id -> [sum over the rows of that dispatch, kernel name]
+    for n_row, r in enumerate(csv.DictReader(open(path))):
         if r["Counter_Name"] != counter:
             continue
         name = r.get("Kernel_Name", "")
         for key, cls in CLASS.items():
             if any(("ofdis::" + ns + key) in name for ns in ("", "exact::", "fused::")):
-                acc[cls] += float(r["Counter_Value"]) * scale
+                v = float(r["Counter_Value"]) * scale
+                acc[cls] += v
+                e = per[cls].setdefault(int(r.get("Dispatch_Id") or n_row), [0.0, name.split("(")[0].replace("void ", "")])
+                e[0] += v
+    lv = {}
+    for cls, by_id in per.items():
+        rows = [(i, v, k) for i, (v, k) in sorted(by_id.items())]
+        if len(rows) % NLEVELS:
+            continue
+        lv[cls] = {}
+        for i, (_, v, kname) in enumerate(rows):
+            e = lv[cls].setdefault(str(SC_F - i % NLEVELS), {"sum": 0.0, "kernel": kname})
+            e["sum"] += v
+    LEVELS[counter] = lv
     return acc
 
 
@@ -42,16 +63,30 @@ write = collect(sys.argv[2], "WRITE_SIZE", 1024.0)
 batch, tv, nsteps = int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
 sq_file = sys.argv[6] if len(sys.argv) > 6 and sys.argv[6] not in ("", "-") else None
 contract = sys.argv[7] if len(sys.argv) > 7 else "exact"
-out = {"batch": batch, "tv": tv, "contract": contract,
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from of_dis_amd import capi  # noqa: E402  (the library the counters were collected on: its build id goes into the file)
+
+out = {"batch": batch, "tv": tv, "contract": contract, "build_id": capi.build_id(),
        "what": "one un-pipelined pass over `batch` pairs = ONE sub-batch of the headline run (bench.py --batch 2*batch --pipeline 2): "
                "same kernel selection and strip lengths; bench.py multiplies by the number of sub-batches",
        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 (calibrated)",
        "bytes_per_step": {k: (fetch[k] + write[k]) / nsteps for k in sorted(set(fetch) | set(write))},
        "read_bytes_per_step": {k: fetch[k] / nsteps for k in sorted(fetch)},
        "write_bytes_per_step": {k: write[k] / nsteps for k in sorted(write)}}
+# the same per pyramid level (the classes launched once per level): bytes and, below, VALU instructions
+per_level = {}
+for cls in sorted(set(LEVELS.get("FETCH_SIZE", {})) & set(LEVELS.get("WRITE_SIZE", {}))):
+    per_level[cls] = {l: {"kernel": LEVELS["FETCH_SIZE"][cls][l]["kernel"],
+                          "bytes_per_step": (LEVELS["FETCH_SIZE"][cls][l]["sum"] + LEVELS["WRITE_SIZE"][cls][l]["sum"]) / nsteps}
+                      for l in LEVELS["FETCH_SIZE"][cls] if l in LEVELS["WRITE_SIZE"][cls]}
+out["per_level"] = per_level
 if sq_file:
     valu = collect(sq_file, "SQ_INSTS_VALU", 1.0)
     out["valu_insts_per_step"] = {k: valu[k] / nsteps for k in sorted(valu)}
+    for cls, lv in LEVELS.get("SQ_INSTS_VALU", {}).items():
+        for l, e in lv.items():
+            if cls in per_level and l in per_level[cls]:
+                per_level[cls][l]["valu_insts_per_step"] = e["sum"] / nsteps
     # sustained shader clock under the dominant kernel: busy cycles / duration of the same dispatches
     cyc, dur = defaultdict(float), defaultdict(float)
     for r in csv.DictReader(open(sq_file)):
