@@ -110,9 +110,11 @@ def synth_frames_range(lo, hi, w, h, base_seed, device, channels=1):
     return torch.cat(out_a).contiguous(), torch.cat(out_b).contiguous()
 
 
-def algorithmic_bytes(p, nframes, fused_tv=True):
+def algorithmic_bytes(p, nframes, fused_tv=True, prep_densify=True):
     """ALGORITHMIC (compulsory) HBM bytes of ONE step per kernel class, summed over its launches
-    (SURVEY.md 8d per-pixel figures; fused kernels: inputs read once + outputs written once)."""
+    (SURVEY.md 8d per-pixel figures; fused kernels: inputs read once + outputs written once).  prep_densify: the warp +
+    derivatives kernel of the fused TV path densifies the flow itself (ofdis_tuning::prep_densify): it reads the patch
+    results instead of the dense flow, and the densification kernel is not launched."""
     noc = p.noc
     out = {k: 0.0 for k in ("warp", "derivatives", "tv_system", "sor", "tv_finish", "patch_optimize", "densify", "tv_fused")}
     launches = dict.fromkeys(out, 0)
@@ -127,14 +129,18 @@ def algorithmic_bytes(p, nframes, fused_tv=True):
                                             + nop * 8 + nop * nv * 4)
         launches["patch_optimize"] += 1
         fused = p.usetvref and fused_tv and noc == 1 and 4 <= h <= 64 and 16 <= w <= 128 and p.tv_solverit <= 3
-        out["densify"] += nframes * (nop * 8 + nop * nv * 4) + 8 * npx       # p, pweight in; wx, wy out
-        launches["densify"] += 1
+        n_inner = p.tv_innerit * (l + 1)
+        steps = max(1, int(p.p_samp_s * (1.0 - p.patove)))
+        dens_in_prep = (fused and prep_densify and n_inner > 0 and not p.usefbcon and p.p_samp_s == 8 and steps == 4)
+        if not dens_in_prep:
+            out["densify"] += nframes * (nop * 8 + nop * nv * 4) + 8 * npx       # p, pweight in; wx, wy out
+            launches["densify"] += 1
         if p.usetvref:
-            n_inner = p.tv_innerit * (l + 1)
             if fused:
                 # image_warp + get_derivatives in one kernel (ofdis_prep.hip): flow + both images in; the derivative
-                # record (32 B, zero where the warp mask is zero) and the (wx, wy) record (8 B) out
-                out["derivatives"] += (8 + 4 + 4 + 32 + 8) * npx
+                # record (32 B, zero where the warp mask is zero) and the (wx, wy) record (8 B) out.  With the densification
+                # inside: the patch displacements and weights in instead of the dense flow
+                out["derivatives"] += (4 + 4 + 32 + 8) * npx + (nframes * (nop * 8 + nop * nv * 4) if dens_in_prep else 8 * npx)
                 # system + SOR, all iterations in one kernel: the three records in, (du, dv) out, per iteration
                 out["tv_fused"] += n_inner * (32 + 8 + 8 + 8) * npx
                 launches["tv_fused"] += 1
@@ -333,7 +339,8 @@ def kernel_table(capi, torch, batch, p, B, stream, nrep=3):
     for _ in range(nrep):
         batch.run(stream)
     torch.cuda.synchronize()
-    abytes, _ = algorithmic_bytes(p, B, fused_tv=bool(capi.get_tuning().fused_tv))
+    tn = capi.get_tuning()
+    abytes, _ = algorithmic_bytes(p, B, fused_tv=bool(tn.fused_tv), prep_densify=bool(tn.prep_densify and tn.finish_fusion))
     kernels = {}
     for k, name in enumerate(capi.K_NAMES):
         ms, n = batch.kernel_time(k)

@@ -294,6 +294,9 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
     const int rr = min(row, h - 1);
     if constexpr (DENS) {
       const int ys = rr - a.dens_offh + 4, by = ys >> 2, ty = ys & 3;  // ys >= 1: offh < 4
+      // (the displacements change only with the grid row, every fourth image row -- but loading them under a wave-uniform
+      // branch was measured 0.8 ms SLOWER per 16384 pairs, 3.55 against 2.75 ms: a conditional load leaves the compiler without
+      // an exact count of the loads in flight, and it waits for all of them; profiles/r06_variants.txt)
 #pragma unroll
       for (int rsel = 0; rsel < 2; ++rsel) {
         const int gyc = clampi(by - 1 + rsel, 0, noph - 1), ky = rsel ? ty : 4 + ty;
@@ -336,8 +339,14 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
           fv = ok ? nfv : fv;
         }
         if (we > 0) {
-          fu /= we;
-          fv /= we;
+          if constexpr (kFusedContract) {  // one hardware reciprocal shared by the two quotients (ofdis_dev.h)
+            const float rwe = rcp_refined(we);
+            fu *= rwe;
+            fv *= rwe;
+          } else {
+            fu /= we;
+            fv /= we;
+          }
         }
         nxt[k] = Pend{fu, fv, asf(li1[k])};
       } else {
