@@ -12,6 +12,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $R
+# PMC passes FIRST (HBM traffic, VALU issue -> profiles/traffic_<contract>.json, stamped with the library's build id): bench.py
+# attaches counter-derived figures only when the file's build id is the loaded library's (tools/pmc_round.sh: separate runs, no
+# torch in the profiled process)
+bash tools/pmc_round.sh $TAG $PMC_BATCH $CONTRACT
+cp $R/gpurun_out/pmc_$TAG/traffic_$CONTRACT.json $OUT/traffic_$CONTRACT.json 2>/dev/null
 if [ "$SKIP_BENCH" != "1" ]; then
 timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 300 $OUT/bench.json; echo
@@ -27,8 +32,5 @@ rm -rf $OUT/kt
 OFDIS_BENCH_CONFIG4_PAIRS=96 OFDIS_BENCH_BLOCKS=config4 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt4 -- python $R/bench.py --batch 64 --steps 1 --warmup 0 --cpu-seconds 0 --no-parity --contract $CONTRACT > $OUT/kt4.log 2>&1
 f=$(find $OUT/kt4 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/prof_summary.py $f > $OUT/config4_kernel_levels.csv
 rm -rf $OUT/kt4
-# PMC passes (HBM traffic, VALU issue) -> profiles/traffic.json: tools/pmc_round.sh (separate runs, no torch in the profiled process)
 cd $R
-bash tools/pmc_round.sh $TAG $PMC_BATCH $CONTRACT
-cp $R/gpurun_out/pmc_$TAG/traffic.json $OUT/traffic.json 2>/dev/null
 ls -la $OUT
