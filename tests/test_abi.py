@@ -32,6 +32,22 @@ def test_library_exports_every_declared_symbol():
     assert L.ofdis_version() == capi.OFDIS_VERSION == int(re.search(r"#define OFDIS_VERSION (\d+)", hdr).group(1))
 
 
+def test_build_id_is_the_hash_of_the_sources():
+    """ofdis_build_id(): the library says which kernel sources + compiler flags it was built from (of_dis_amd.build.source_id);
+    profiles/traffic_*.json carries the id of the library its counters were collected on and bench.py attaches it only to that
+    library.  Here: the built library's id is the id of the tree it sits in (i.e. the build is not stale), and an id changes
+    when a flag does."""
+    from of_dis_amd import build
+    assert capi.build_id() == build.source_id(), "libofdis_hip.so is stale: python -m of_dis_amd.build"
+    assert build.source_id(extra_flags={"ofdis_dis.hip": ["-DX"]}) != build.source_id()
+    import json
+    for name in ("traffic_fused.json", "traffic_exact.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            tj = json.load(open(path))
+            assert "bytes_per_step" in tj and isinstance(tj.get("build_id", ""), str)
+
+
 def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
     """The struct layouts of the binding belong to one ABI version: a stale libofdis_hip.so must not be handed our structs."""
     monkeypatch.setattr(capi, "_lib", None)

@@ -311,3 +311,41 @@ def test_random_patchgrid_levels(gpu, orc, seed):
     gp, gflow = gpu.patchgrid_level(p, 0, pa[0][0][None], pa[1][0][None], pa[2][0][None], pb[0][0][None], prev[None])
     assert_bits_equal(gp[0], rp, f"seed {seed}: patch displacements {w}x{h} P={P} noc={noc}")
     assert_bits_equal(gflow[0], rflow, f"seed {seed}: dense flow")
+
+
+def test_streams_events_and_page_locked_copies(gpu):
+    """include/ofdis.h version 3: asynchronous copies between page-locked host memory and the device on streams created through
+    the ABI, ordered across streams by events -- the pieces of the sequence driver's upload | kernels | download pipeline."""
+    L = gpu.lib()
+    n = 1 << 22
+    rng = np.random.default_rng(7)
+    src = gpu.HostBuf((n,), np.float32)
+    dst = gpu.HostBuf((n,), np.float32)
+    src.array[:] = rng.standard_normal(n).astype(np.float32)
+    dst.array[:] = 0
+    d0, d1 = gpu.Dev(nbytes=4 * n), gpu.Dev(nbytes=4 * n)
+    s_in, s_k, s_out = gpu.Stream(), gpu.Stream(), gpu.Stream()
+    up, done = gpu.Event(), gpu.Event()
+    for rep in range(3):
+        gpu.check(L.ofdis_memcpy_h2d_async(d0.ptr, src.ptr, 4 * n, s_in.ptr))
+        up.record(s_in)
+        up.wait(s_k)                                                   # the "kernel" stream waits for the upload ...
+        gpu.check(L.ofdis_memcpy_d2d(d1.ptr, d0.ptr, 4 * n, s_k.ptr))
+        done.record(s_k)
+        done.wait(s_out)                                               # ... the download stream for the kernel stream
+        gpu.check(L.ofdis_memcpy_d2h_async(dst.ptr, d1.ptr, 4 * n, s_out.ptr))
+        down = gpu.Event()
+        down.record(s_out)
+        down.sync()
+        assert np.array_equal(dst.array, src.array), f"round {rep}"
+        src.array[:] = src.array[::-1].copy()
+        down.close()
+    never = gpu.Event()                                                # a never-recorded event is complete
+    never.wait(s_k)
+    never.sync()
+    s_k.sync()
+    assert L.ofdis_event_record(None, s_k.ptr) != 0 and L.ofdis_memcpy_h2d_async(None, src.ptr, 4, s_in.ptr) != 0
+    for o in (up, done, never, s_in, s_k, s_out):
+        o.close()
+    src.free()
+    dst.free()

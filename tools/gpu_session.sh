@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6: the whole GPU test-suite, then the evidence of the round on the same box (PMC -> bench -> kernel traces)
+# One GPU session: the whole GPU test-suite and smoke(), then the evidence of a round on the same box (PMC -> bench -> kernel traces):
+#   gpurun --timeout 3000 -- "bash tools/gpu_session.sh TAG"   ->  gpurun_out/TAG/{pytest.log,smoke.log}, gpurun_out/prof_TAG/, gpurun_out/pmc_TAG/
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/${1:-r6f}; mkdir -p $OUT; cd $R
 timeout 1500 python -m pytest tests -m gpu -x -q --durations=5 > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -9 $OUT/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
