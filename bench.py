@@ -1132,10 +1132,13 @@ def main():
                             "per LEVEL (records in, flow out: 48 B per pixel).  traffic / strictly compulsory = how many times the "
                             "records are re-fetched.  See roofline_valu and DESIGN.md section 4"}
         # Level by level (the launches of this class differ: coarse levels run another kernel mapping than the finest): time of
-        # THIS run (HIP events) against the PMC traffic and VALU instructions of the same build's launches.  `bound` per level:
-        # "hbm" when the launch moves its bytes at >= 0.6 of the peak (streaming launches of these shapes reach 0.66-0.72:
-        # tools/probes/copy_bw.hip), else "issue/latency" -- neither roofline reached: dependent-issue latency at the occupancy
-        # the registers allow.  The top-level `bound` stays the roofline `frac` is quoted against.
+        # THIS run (HIP events) against the PMC traffic and VALU instructions of the same build's launches, on BOTH rooflines.
+        # `bound` per level = the practical ceiling the launch is closer to: HBM traffic against 0.70 of the peak (what streaming
+        # launches of these shapes reach: 5.3-5.8 TB/s, tools/probes/copy_bw.hip) or VALU instructions against 0.50 of the nominal
+        # issue peak (one instruction per ~4 clocks and SIMD is what the kernels of this path get with memory, scalar and wait
+        # instructions in the stream: DESIGN.md section 4) -- "issue/latency" means dependent-issue latency at the occupancy the
+        # registers allow, neither roofline reached.  The top-level `bound` stays the roofline `frac` is quoted against.
+        STREAM_WALL, ISSUE_CEIL = 0.70, 0.50
         lv_ms = kernels[dom].get("ms_per_level") or {}
         if per_level_pmc.get(dom) and lv_ms:
             clk = tj.get("sustained_clock_ghz") or 2.4
@@ -1148,7 +1151,10 @@ def main():
                 ent = {"kernel": e.get("kernel"), "ms": lv_ms[l], "traffic": e["bytes_per_step"], "hbm_frac": round(hb, 4)}
                 if e.get("valu_insts_per_step"):
                     ent["valu_frac"] = round(e["valu_insts_per_step"] / sec / 1e9 / (1024 * clk / 2.0), 4)
-                ent["bound"] = "hbm" if hb >= 0.6 else "issue/latency"
+                ent["of_streaming_wall"] = round(hb / STREAM_WALL, 3)
+                if "valu_frac" in ent:
+                    ent["of_practical_issue_rate"] = round(ent["valu_frac"] / ISSUE_CEIL, 3)
+                ent["bound"] = "hbm" if hb / STREAM_WALL >= ent.get("valu_frac", 0.0) / ISSUE_CEIL else "issue/latency"
                 levels[l] = ent
             if levels:
                 roofline["levels"] = levels
