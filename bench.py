@@ -995,7 +995,8 @@ def main():
         # nothing orders two steps): whole-job frames/s between two barriers, max over ranks, per D.
         if total // world < 1024:
             by_depth = {"1": {"ms_per_step": out["ms_per_step"], "frames_per_s": out["value"]}}
-            for D in (2, 4, 8):
+            # (developer mode with every rank on ONE GPU -- the multi-rank control-flow tests -- : one depth is enough)
+            for D in ((2,) if os.environ.get("OFDIS_BENCH_SHARE_GPU") else (2, 4, 8)):
                 streams = [capi.Stream() for _ in range(D)]
                 ctx = []
                 for k in range(D):
