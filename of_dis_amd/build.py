@@ -19,7 +19,7 @@ ROOT = os.path.dirname(HERE)
 # Kernel files: compiled once per ARITHMETIC CONTRACT (csrc/ofdis_dev.h) from the same source, into ofdis::exact and
 # ofdis::fused; the pyramid (exact by construction for 8-bit input) and the C ABI are compiled once.
 KERNEL_SOURCES = ["ofdis_dis.hip", "ofdis_tv.hip", "ofdis_prep.hip", "ofdis_sor.hip", "ofdis_fused.hip", "ofdis_fused_xcu.hip",
-                  "ofdis_de.hip"]
+                  "ofdis_fused_tall.hip", "ofdis_de.hip"]
 COMMON_SOURCES = ["ofdis_pyr.hip", "ofdis_capi.hip"]
 HIP_SOURCES = KERNEL_SOURCES + COMMON_SOURCES
 # -fvisibility=hidden: the shared library exports the C ABI of include/ofdis.h (marked in ofdis_capi.hip) and nothing else.
@@ -37,7 +37,7 @@ HIPFLAGS = BASEFLAGS + CONTRACT_FLAGS["exact"]
 # moves that assemble register pairs are pure overhead; in ofdis_dis.hip it also splits the DPP reduction chains.
 _NO_SLP = ["-fno-slp-vectorize"]
 PER_FILE_FLAGS = {"ofdis_dis.hip": _NO_SLP, "ofdis_tv.hip": _NO_SLP, "ofdis_prep.hip": _NO_SLP, "ofdis_fused.hip": _NO_SLP,
-                  "ofdis_fused_xcu.hip": _NO_SLP,
+                  "ofdis_fused_xcu.hip": _NO_SLP, "ofdis_fused_tall.hip": _NO_SLP,
                   "ofdis_sor.hip": _NO_SLP}
 
 

@@ -84,6 +84,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // Launch of the cross-CU variant (ofdis_fused_xcu.hip); waves = frame groups, R = lanes per frame of a group
 hipError_t launch_tv_fused_xcu(const FusedArgs& a, const FusedXcu& x, int waves, int R, hipStream_t s);
+// Levels of 65 ... 128 rows: two wavefronts per strip (ofdis_fused_tall.hip)
+bool tv_fused_tall_supported(const TvGeom& t, int iterations);
+hipError_t launch_tv_fused_tall(const FusedArgs& a, hipStream_t s);
 
 }  // namespace OFDIS_KNS
 }  // namespace ofdis

@@ -598,6 +598,29 @@ def test_densification_inside_the_warp_kernel(gpu, orc, size, nfr, dens):
         gpu.restore_tuning(old)
 
 
+@pytest.mark.parametrize("size,nfr", [((1920, 1080), 3), ((1920, 1080), 40), ((1700, 1050), 2)])
+def test_hd_gray_pairs_take_the_two_wavefront_fused_kernel(gpu, orc, size, nfr):
+    """1920x1080 gray at operating point 2: levels 30x17, 60x34 and 120x68 -- the finest one is four rows taller than a
+    wavefront.  The whole path (ofdis_flow and a batch) against the oracle, bit for bit."""
+    w, h = size
+    cases = [synth_case(w, h, 3300 + k, 1, 2, 1) for k in range(2)]
+    p = cases[0][0]
+    assert p.level_size(p.sc_l)[1] > 64
+    refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
+    assert_bits_equal(gpu.flow(p, cases[0][1][0], cases[0][1][1], cases[0][1][2], cases[0][2][0]), refs[0], "ofdis_flow")
+    b = gpu.Batch(p, nfr)
+    for l in range(p.sc_l, p.sc_f + 1):
+        for kind in range(4):
+            planes = [c[1][kind][l] if kind < 3 else c[2][0][l] for c in cases]
+            b.set_input(l, kind, np.stack([planes[(s * s) % 2] for s in range(nfr)]))
+    for rep in range(2):
+        b.run()
+        out = b.download_all()
+        for s in range(nfr):
+            assert_bits_equal(out[s], refs[(s * s) % 2], f"{w}x{h}, {nfr} frames, pass {rep}, slot {s}")
+    b.close()
+
+
 @pytest.mark.parametrize("band", [2, 4, 6, 8, 11, 64])
 def test_prep_kernel_row_bands(gpu, orc, band):
     """The warp + derivatives kernel cut into row bands (small batches: more wavefronts; each band recomputes its margins)

@@ -259,6 +259,36 @@ def test_varref_square_and_near_square_levels(gpu, orc, w, h, tv_variant):
         assert_bits_equal(got[0], ref, f"varref {w}x{h} innerit={innerit} solverit={solverit}")
 
 
+@pytest.mark.parametrize("knobs", [{}, {"finish_fusion": 0}, {"fused_strip": 2}, {"prep_band_rows": 6}])
+@pytest.mark.parametrize("w,h", [(120, 68), (128, 128), (16, 65), (100, 127), (64, 96), (17, 70), (128, 66), (96, 100)])
+def test_varref_levels_of_65_to_128_rows(gpu, orc, w, h, knobs):
+    """Levels taller than a wavefront has lanes (the finest level of a 1080p / 4K gray pair at operating point 2 is 120 x 68):
+    the fused TV kernel with TWO wavefronts per strip (ofdis_fused_tall.hip) -- rows 0..63 and 64..h-1, every lane shift at the
+    boundary bridged by an LDS mailbox -- and the row-marching warp + derivatives kernel in front of it must give the bits of
+    the reference, for one / two / three sweeps, with and without the brightness term, for several frames (strips), with the
+    separate finish kernel, and with the warp kernel cut into row bands."""
+    import gen_synth
+    from of_dis_amd.params import oppoint
+    rng = np.random.default_rng(w * 1000 + h)
+    nfr = 4
+    pairs = [gen_synth.make_pair(w, h, 300 + k, 1) for k in range(2)]
+    old = gpu.set_tuning(**knobs)
+    try:
+        for innerit, solverit, delta in ((1, 3, 5.0), (2, 1, 0.0), (3, 2, 5.0)):
+            p = oppoint(2, w, h).copy(sc_f=0, sc_l=0, p_samp_s=4, imgpadding=4, tv_innerit=innerit, tv_solverit=solverit, tv_delta=delta)
+            p.width, p.height = w, h
+            pyr = [(orc.build_pyramid(p, ia), orc.build_pyramid(p, ib)) for ia, ib, _ in pairs]
+            flows = [rand_planes(rng, h, w, 2, scale=sc) for sc in (1.5, 0.3, 5.0, 1.0)]
+            flows[2][h - 1, w - 1] = (2.5 * w, -2.5 * h)  # far outside the image: mask 0, clamped taps
+            refs = [orc.varref_level(p, 0, pyr[f % 2][0][0][0], pyr[f % 2][1][0][0], flows[f]) for f in range(nfr)]
+            got = gpu.varref_level(p, 0, np.stack([pyr[f % 2][0][0][0] for f in range(nfr)]),
+                                   np.stack([pyr[f % 2][1][0][0] for f in range(nfr)]), np.stack(flows))
+            for f in range(nfr):
+                assert_bits_equal(got[f], refs[f], f"{w}x{h} innerit={innerit} solverit={solverit} delta={delta} {knobs} frame {f}")
+    finally:
+        gpu.restore_tuning(old)
+
+
 @pytest.mark.parametrize("seed", range(48))
 def test_random_varref_levels(gpu, orc, seed, tv_variant):
     """Random level geometry (mostly in the fused kernel's range: gray, 2 <= h <= 64, w >= 16; some outside it and some
