@@ -2,7 +2,7 @@
 //     image_warp        opticalflow_aux.c:18-60
 //     get_derivatives   opticalflow_aux.c:65-116 (+ image.c:401-434, 466-502)
 //
-// A wavefront owns whole image rows of its frame(s): lane = column (two wavefronts side by side when 64 < w <= 128, sharing
+// A wavefront owns whole image rows of its frame(s): lane = column (two, three or four wavefronts side by side when 64 < w <= 128 / 192 / 256, sharing
 // the exchanged rows and the staging area; two / four frames per wavefront when w <= 32 / 16) and marches down the rows.
 // Per row r it
 //   stage 0   warps the second image at (x, r) with the densified flow, forms avg = 0.5 (I2w + I1) and Iz = I2w - I1,
@@ -101,15 +101,16 @@ constexpr int PREP_KW = 8;  // rows of (wx, wy) records staged before a flush (r
 // 128-byte cache line (h is a multiple of 4 on the benchmarked levels 3 and 4), and the larger staging area costs nothing: the
 // kernel does not care whether 2.5 or 4 wavefronts share a SIMD (profiles/r05_b_variants.txt), which is what had kept KD at 2)
 
-// LDS per block, in floats.  WPF = wavefronts per frame (= per block): 1 (w <= 64; up to four frames in the wavefront) or 2.
+// LDS per block, in floats.  WPF = wavefronts per frame (= per block): 1 (w <= 64; up to four frames in the wavefront), 2
+// (w <= 128), 3 or 4 (round 6: w <= 192 / 256 -- the finest level of a 1242 x 375 KITTI pair at operating point 2 is 156 x 48).
 template <int WPF>
 struct PrepLds {
   static constexpr int ROW = 64 * WPF + 32;  // one exchanged row: the block's columns + 4 pads + 4 dummies per frame segment (<= 4)
   // staging: per frame (lpf + K - 1) diag rows x K records; the worst case over 1 / 2 / 4 frames per wavefront
   static constexpr int nq(int lpf, int K) { return lpf + K - 1; }
   // (+ one dummy record at the end of each array: where the lanes beyond the image write)
-  static constexpr int STD = (WPF == 2 ? nq(128, PREP_KD) * PREP_KD : 4 * nq(16, PREP_KD) * PREP_KD) * 8 + 8;
-  static constexpr int STW = (WPF == 2 ? nq(128, PREP_KW) * PREP_KW : 4 * nq(16, PREP_KW) * PREP_KW) * 2 + 2;
+  static constexpr int STD = (WPF >= 2 ? nq(64 * WPF, PREP_KD) * PREP_KD : 4 * nq(16, PREP_KD) * PREP_KD) * 8 + 8;
+  static constexpr int STW = (WPF >= 2 ? nq(64 * WPF, PREP_KW) * PREP_KW : 4 * nq(16, PREP_KW) * PREP_KW) * 2 + 2;
   static constexpr int TOTAL = 3 * ROW + STD + STW;
 };
 
@@ -135,11 +136,11 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
   __shared__ __attribute__((aligned(16))) float lds[L::TOTAL];
   const int lane = threadIdx.x;       // lane of the block
   const int w = a.t.w, h = a.t.h, S = a.S;
-  const int lpf = 1 << lpf_shift;     // lanes per frame: 128 (WPF = 2), else 64 / 32 / 16
-  const int fpw = WPF == 2 ? 1 : (64 >> lpf_shift);  // frames per block
+  const int lpf = WPF >= 2 ? 64 * WPF : (1 << lpf_shift);  // lanes per frame: the whole block (WPF >= 2), else 64 / 32 / 16
+  const int fpw = WPF >= 2 ? 1 : (64 >> lpf_shift);        // frames per block
   const int unit = blockIdx.x;
   const int fg = unit / nbands, band = unit - fg * nbands;
-  const int fl = lane >> lpf_shift, li = lane & (lpf - 1);
+  const int fl = WPF >= 2 ? 0 : lane >> lpf_shift, li = WPF >= 2 ? lane : lane & (lpf - 1);
   int frame = fg * fpw + fl;
   const bool fok = frame < a.t.nframes;
   if (!fok) frame = a.t.nframes - 1;  // idle lane group: shadows the last frame, never flushed
@@ -498,7 +499,8 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
 
 // (rows: the kernel marches down any number of them; 128 is what the consumers of its records handle -- one wavefront per strip
 // up to 64 rows, two up to 128: ofdis_fused.hip, ofdis_fused_tall.hip)
-bool tv_prep_supported(const TvGeom& t) { return t.noc == 1 && t.w >= 16 && t.w <= 128 && t.h >= 4 && t.h <= 128; }
+// (columns: one lane each, up to four wavefronts side by side)
+bool tv_prep_supported(const TvGeom& t) { return t.noc == 1 && t.w >= 16 && t.w <= 256 && t.h >= 4 && t.h <= 128; }
 // Can launch_tv_prep densify the flow itself for this patch grid (PrepArgs::dens_*)?  The geometry of densify_quad_kernel:
 // gray 8x8 patches on a step-4 grid (operating point 2), at most 2 x 2 patches per pixel.
 bool tv_prep_densifies(const LevelGeom& g) { return g.noc == 1 && g.P == 8 && g.steps == 4 && g.offw < 4 && g.offh < 4; }
@@ -507,7 +509,7 @@ hipError_t launch_tv_prep(const PrepArgs& a_in, hipStream_t s) {
   if (!tv_prep_supported(a_in.t) || a_in.S < 1) return hipErrorInvalidValue;
   PrepArgs a = a_in;
   const int w = a.t.w, h = a.t.h;
-  const int lpf_shift = w > 64 ? 7 : (w > 32 ? 6 : (w > 16 ? 5 : 4));
+  const int lpf_shift = w > 64 ? 7 : (w > 32 ? 6 : (w > 16 ? 5 : 4));  // (w > 64: not used, the block is the frame)
   const int fpw = w > 64 ? 1 : (64 >> lpf_shift);
   const int fgroups = (a.t.nframes + fpw - 1) / fpw;
   // bands: enough wavefronts for ~2 per SIMD (1024 SIMDs); from 8 output rows on a multiple of the staging blocks
@@ -525,11 +527,15 @@ hipError_t launch_tv_prep(const PrepArgs& a_in, hipStream_t s) {
   if (a.dens_p) {  // densification inside this kernel (tv_prep_densifies): patch results in, no dense flow read
     if (!a.dens_pweight || a.dens_offw < 0 || a.dens_offw > 3 || a.dens_offh < 0 || a.dens_offh > 3 || a.dens_nopw < 1 || a.dens_noph < 1)
       return hipErrorInvalidValue;
-    if (w > 64) hipLaunchKernelGGL((tv_prep_kernel<2, true>), dim3((unsigned)units), dim3(128), 0, s, a, lpf_shift, nbands);
+    if (w > 192) hipLaunchKernelGGL((tv_prep_kernel<4, true>), dim3((unsigned)units), dim3(256), 0, s, a, lpf_shift, nbands);
+    else if (w > 128) hipLaunchKernelGGL((tv_prep_kernel<3, true>), dim3((unsigned)units), dim3(192), 0, s, a, lpf_shift, nbands);
+    else if (w > 64) hipLaunchKernelGGL((tv_prep_kernel<2, true>), dim3((unsigned)units), dim3(128), 0, s, a, lpf_shift, nbands);
     else hipLaunchKernelGGL((tv_prep_kernel<1, true>), dim3((unsigned)units), dim3(64), 0, s, a, lpf_shift, nbands);
     return hipGetLastError();
   }
-  if (w > 64) hipLaunchKernelGGL((tv_prep_kernel<2, false>), dim3((unsigned)units), dim3(128), 0, s, a, lpf_shift, nbands);
+  if (w > 192) hipLaunchKernelGGL((tv_prep_kernel<4, false>), dim3((unsigned)units), dim3(256), 0, s, a, lpf_shift, nbands);
+  else if (w > 128) hipLaunchKernelGGL((tv_prep_kernel<3, false>), dim3((unsigned)units), dim3(192), 0, s, a, lpf_shift, nbands);
+  else if (w > 64) hipLaunchKernelGGL((tv_prep_kernel<2, false>), dim3((unsigned)units), dim3(128), 0, s, a, lpf_shift, nbands);
   else hipLaunchKernelGGL((tv_prep_kernel<1, false>), dim3((unsigned)units), dim3(64), 0, s, a, lpf_shift, nbands);
   return hipGetLastError();
 }

@@ -598,14 +598,16 @@ def test_densification_inside_the_warp_kernel(gpu, orc, size, nfr, dens):
         gpu.restore_tuning(old)
 
 
-@pytest.mark.parametrize("size,nfr", [((1920, 1080), 3), ((1920, 1080), 40), ((1700, 1050), 2)])
+@pytest.mark.parametrize("size,nfr", [((1920, 1080), 3), ((1920, 1080), 40), ((1700, 1050), 2), ((1242, 375), 3), ((1242, 375), 70),
+                                      ((1242, 560), 2)])
 def test_hd_gray_pairs_take_the_two_wavefront_fused_kernel(gpu, orc, size, nfr):
     """1920x1080 gray at operating point 2: levels 30x17, 60x34 and 120x68 -- the finest one is four rows taller than a
-    wavefront.  The whole path (ofdis_flow and a batch) against the oracle, bit for bit."""
+    wavefront; 1242x375 (KITTI): levels 39x12, 78x24 and 156x48 -- the finest one wider than two wavefronts.  The whole path
+    (ofdis_flow and a batch) against the oracle, bit for bit."""
     w, h = size
     cases = [synth_case(w, h, 3300 + k, 1, 2, 1) for k in range(2)]
     p = cases[0][0]
-    assert p.level_size(p.sc_l)[1] > 64
+    assert p.level_size(p.sc_l)[1] > 64 or p.level_size(p.sc_l)[0] > 128
     refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
     assert_bits_equal(gpu.flow(p, cases[0][1][0], cases[0][1][1], cases[0][1][2], cases[0][2][0]), refs[0], "ofdis_flow")
     b = gpu.Batch(p, nfr)
