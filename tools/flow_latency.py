@@ -1,14 +1,19 @@
-"""Latency of the drop-in call ofdis_flow() (host pyramids in, host flow out), one pair at a time."""
+"""Latency of the drop-in call ofdis_flow() (host pyramids in, host flow out), one pair at a time.
+    python tools/flow_latency.py [W H] [contract=exact]     (default 1024 436; the library's default contract)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from common import synth_case
 from of_dis_amd import capi
-p, pa, pb, _, _ = synth_case(1024, 436, 1234, 1, 2, 1)
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 436)
+contract = sys.argv[3] if len(sys.argv) > 3 else "exact"
+capi.set_tuning(contract=1 if contract == "fused" else 0)
+p, pa, pb, _, _ = synth_case(W, H, 1234, 1, 2, 1)
 for _ in range(3):
     capi.flow(p, pa[0], pa[1], pa[2], pb[0])
 n = 50
 t0 = time.perf_counter()
 for _ in range(n):
     capi.flow(p, pa[0], pa[1], pa[2], pb[0])
-print(f"ofdis_flow 1024x436 op-2: {(time.perf_counter() - t0) / n * 1e3:.3f} ms per call (incl. ~0.3 ms of ctypes marshalling)")
+print(f"ofdis_flow {W}x{H} op-2, {contract} contract, levels {[p.level_size(l) for l in range(p.sc_l, p.sc_f + 1)]}: "
+      f"{(time.perf_counter() - t0) / n * 1e3:.3f} ms per call (incl. the ctypes marshalling of the binding)")
