@@ -128,7 +128,7 @@ def algorithmic_bytes(p, nframes, fused_tv=True, prep_densify=True):
         out["patch_optimize"] += nframes * (4 * th * tw * noc * 4 + (2 * (w // 2) * (h // 2) * 4 if l < p.sc_f else 0)
                                             + nop * 8 + nop * nv * 4)
         launches["patch_optimize"] += 1
-        fused = p.usetvref and fused_tv and noc == 1 and 4 <= h <= 128 and 16 <= w <= 256 and p.tv_solverit <= 3
+        fused = p.usetvref and fused_tv and noc == 1 and 4 <= h <= 256 and 16 <= w <= 256 and p.tv_solverit <= 3
         n_inner = p.tv_innerit * (l + 1)
         steps = max(1, int(p.p_samp_s * (1.0 - p.patove)))
         dens_in_prep = (fused and prep_densify and n_inner > 0 and not p.usefbcon and p.p_samp_s == 8 and steps == 4)

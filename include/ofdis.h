@@ -226,7 +226,8 @@ typedef struct ofdis_tuning {
                        * 16 = four (a 3x3 pixel block per lane for the taps; the exact contract moves the interpolated
                        * values through LDS into the entry order its documented summation needs, the fused contract sums
                        * block-wise)                                                                  OFDIS_RGB12_LPP */
-  int fused_tv;       /* 1: gray levels of <= 64 rows take the fused TV path (prep + fused kernel)   OFDIS_NO_FUSED -> 0 */
+  int fused_tv;       /* 1: gray levels of <= 256 rows and <= 256 columns take the fused TV path (warp + derivatives kernel,
+                       * fused system + SOR kernel)                                                   OFDIS_NO_FUSED -> 0 */
   int fused_mw_max;   /* frame groups up to which the multi-wave fused TV kernels are launched       OFDIS_FUSED_MW_MAX
                        * (default 512 and at most 1024 frames per batch; 0 = never; >= 2^30 = always) */
   int fused_split;    /* 1: multi-wave kernel with producer + solver wavefronts per iteration  OFDIS_FUSED_NO_SPLIT -> 0 */

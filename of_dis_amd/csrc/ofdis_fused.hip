@@ -479,7 +479,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(con
 }
 
 bool tv_fused_supported(const TvGeom& t, int iterations) {
-  // (65 ... 128 rows: the two-wavefront form of the throughput mapping, ofdis_fused_tall.hip)
+  // (65 ... 256 rows: the two- to four-wavefront form of the throughput mapping, ofdis_fused_tall.hip)
   return (t.noc == 1 && t.h >= 2 && t.h <= 64 && t.w >= 16 && iterations >= 1 && iterations <= 3) || tv_fused_tall_supported(t, iterations);
 }
 
@@ -500,7 +500,7 @@ constexpr int MW_MAX_BATCH_FRAMES = 1024;
 
 int tv_fused_mode(const FusedArgs& a, const FusedXcu* x) {
   const int h = a.t.h;
-  if (h > 64) return 0;  // two wavefronts per strip (ofdis_fused_tall.hip): the throughput mapping only, whatever the batch
+  if (h > 64) return 0;  // two to four wavefronts per strip (ofdis_fused_tall.hip): the throughput mapping only, whatever the batch
   const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
   const int groups = (a.t.nframes + 64 / R - 1) / (64 / R);
   const int total = a.total_frames > 0 ? a.total_frames : a.t.nframes;
@@ -518,7 +518,7 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow, 
       !tv_fused_params_ok(a.quarter_alpha, a.half_delta_over3, a.half_gamma_over3))
     return hipErrorInvalidValue;
   const int h = a.t.h;
-  if (h > 64) {  // 65 ... 128 rows
+  if (h > 64) {  // 65 ... 256 rows
     if (wrote_flow) *wrote_flow = a.flow_out != nullptr;
     return launch_tv_fused_tall(a, s);
   }

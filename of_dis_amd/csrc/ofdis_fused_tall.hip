@@ -1,5 +1,5 @@
-// ofdis_fused_tall.hip -- the fused TV kernel of ofdis_fused.hip (throughput mapping, MODE 0) for levels of 65 ... 128 rows:
-// TWO wavefronts per strip.  Same arithmetic in the same order: bit-identical results.
+// ofdis_fused_tall.hip -- the fused TV kernel of ofdis_fused.hip (throughput mapping, MODE 0) for levels of 65 ... 256 rows:
+// TWO to FOUR wavefronts per strip.  Same arithmetic in the same order: bit-identical results.
 //
 // Why it exists.  The reference pads a frame to a multiple of 2^sc_f, which puts the finest level of a 1920x1080 or 3840x2160
 // gray pair at operating point 2 at 120 x 68 pixels -- four rows more than a wavefront has lanes.  The fused kernel maps
@@ -7,6 +7,8 @@
 // (tv_system + block SOR per fixed-point iteration: 2.1 of the 2.97 ms per 1024 pairs at 1080p, tools/size_probe.py).  An
 // anti-diagonal of a 120 x 68 level has up to 68 independent pixels: two wavefronts, wave 0 = rows 0..63, wave 1 = rows
 // 64..h-1, both at the same step t (lane's column = t - row), 53 % of the lanes busy at h = 68, all of them at h = 128.
+// Taller levels (portrait frames: 1080 x 1920 gives 135 x 240) take three or four wavefronts the same way: wave q = rows
+// 64 q .. 64 q + 63, a mailbox at each of the NW - 1 boundaries, a middle wavefront publishing in both directions.
 //
 // What crosses the wavefront boundary.  In diag coordinates every stencil needs one DPP lane shift (ofdis_fused.hip header);
 // between lane 63 of wave 0 and lane 0 of wave 1 the shift becomes an LDS mailbox.  Per step 21 values cross it (NS = 3):
@@ -26,18 +28,20 @@ namespace ofdis {
 namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
 
 template <int NS, bool BRIGHT>
-__global__ __launch_bounds__(128) void tv_fused_tall_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256) void tv_fused_tall_kernel(const FusedArgs a) {
   constexpr int U = 6;
   constexpr int PDW = 5, PDD = 3;
   constexpr int NDOWN = 5 + 2 * NS, NUP = 6 + 2 * (NS - 1), NMB = 12;  // mailbox words per direction (padded to 16-byte reads)
   static_assert(NDOWN <= NMB && NUP <= NMB, "mailbox too small");
   static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
-  __shared__ __attribute__((aligned(16))) float mbA[2][2][NMB];  // [step parity][0 = down, 1 = up][value]
-  __shared__ float mbB;                                           // smoothness of row t+2, wave 1 lane 0 -> wave 0 lane 63
+  constexpr int NB = 3;  // boundaries between the (at most four) wavefronts of a strip
+  __shared__ __attribute__((aligned(16))) float mbA[2][2][NB][NMB];  // [step parity][0 = down, 1 = up][boundary][value]
+  __shared__ float mbB[NB];  // smoothness of row t+2, lane 0 of the wavefront below a boundary -> lane 63 of the one above
   const int w = a.t.w, h = a.t.h;
   const int rw = a.S * w;  // diag rows of a strip = its columns
   const int lane = threadIdx.x & 63;
-  const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0: rows 0 .. 63, 1: rows 64 .. h-1
+  const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wavefront q: rows 64 q .. 64 q + 63
+  const int nw = (int)(blockDim.x >> 6);                            // wavefronts per strip: ceil(h / 64)
   const int nstrips = a.t.nframes / a.S;
   const int s0 = blockIdx.x;  // one strip per workgroup
   if (s0 >= nstrips) return;
@@ -45,8 +49,9 @@ __global__ __launch_bounds__(128) void tv_fused_tall_kernel(const FusedArgs a) {
   const bool row_ok = jr < h;
   const int j = jr < h ? jr : h - 1;  // lanes beyond the image shadow the last row (real data, results never stored)
   const bool has_top = j > 0, has_bot = j < h - 1;
-  const bool lo_edge = q == 1 && lane == 0;   // its "previous lane" is wave 0's lane 63
-  const bool hi_edge = q == 0 && lane == 63;  // its "next lane" is wave 1's lane 0
+  const bool has_up = q > 0, has_dn = q + 1 < nw;  // (wave-uniform) a boundary above / below this wavefront
+  const bool lo_edge = has_up && lane == 0;   // its "previous lane" is lane 63 of the wavefront above
+  const bool hi_edge = has_dn && lane == 63;  // its "next lane" is lane 0 of the wavefront below
   const float omega = a.omega, qa = a.quarter_alpha, hd3 = a.half_delta_over3, hg3 = a.half_gamma_over3;
 
   const size_t strip_recs = (size_t)rw * h;
@@ -167,18 +172,20 @@ __global__ __launch_bounds__(128) void tv_fused_tall_kernel(const FusedArgs a) {
       // ---- phase A: the boundary lane of each wavefront publishes what the other wavefront's boundary lane will take in
       //      place of a DPP lane shift during this step (everything but the smoothness of row t+2, which does not exist yet)
       {
-        float* const mw = &mbA[par][q][0];  // wave 0 writes "down", wave 1 "up"
-        if (q == 0) {
+        if (has_dn) {  // lane 63 publishes "down" at the boundary below this wavefront
+          float* const mw = &mbA[par][0][q][0];
           if (lane == 63) {
-            mw[0] = uu[(u + 1) % 3]; mw[1] = vv[(u + 1) % 3];          // row t+1: ut, vt of row 64
+            mw[0] = uu[(u + 1) % 3]; mw[1] = vv[(u + 1) % 3];          // row t+1: ut, vt of the row below
             mw[2] = W[u % 6].wx; mw[3] = W[u % 6].wy;                  // row t: wx_u, wy_u
             mw[4] = slot[u % 6].sv;                                    // sv_t
 #pragma unroll
             for (int s = 0; s < NS; ++s) { mw[5 + s] = ru[s]; mw[5 + NS + s] = rv[s]; }  // tu, tv of sweep s
           }
-        } else {
+        }
+        if (has_up) {  // lane 0 publishes "up" at the boundary above
+          float* const mw = &mbA[par][1][q - 1][0];
           if (lane == 0) {
-            mw[0] = uu[u % 3]; mw[1] = vv[u % 3];                      // row t+3: ub, vb of row 63
+            mw[0] = uu[u % 3]; mw[1] = vv[u % 3];                      // row t+3: ub, vb of the row above
             mw[2] = W[(u + 2) % 6].wx; mw[3] = W[(u + 2) % 6].wy;      // row t+2: wx_d, wy_d
             mw[4] = slot[u % 6].dur; mw[5] = slot[u % 6].dvr;          // bu, bv of sweep 0
 #pragma unroll
@@ -187,18 +194,23 @@ __global__ __launch_bounds__(128) void tv_fused_tall_kernel(const FusedArgs a) {
         }
       }
       mw_step_barrier();
-      float in[NMB];  // what the other wavefront's boundary lane published (wave 1 reads "down", wave 0 "up")
+      // what the neighbouring wavefronts' boundary lanes published: "down" of the boundary above (for lane 0), "up" of the one
+      // below (for lane 63); a wavefront without that boundary reads a mailbox nobody uses (a valid address, value unused)
+      float inD[NMB], inU[NMB];
       {
-        const float4* mr = reinterpret_cast<const float4*>(&mbA[par][1 - q][0]);
+        const float4* md = reinterpret_cast<const float4*>(&mbA[par][0][has_up ? q - 1 : 0][0]);
+        const float4* mu = reinterpret_cast<const float4*>(&mbA[par][1][has_dn ? q : 0][0]);
 #pragma unroll
         for (int k = 0; k < NMB / 4; ++k) {
-          const float4 v = mr[k];
-          in[4 * k] = v.x; in[4 * k + 1] = v.y; in[4 * k + 2] = v.z; in[4 * k + 3] = v.w;
+          const float4 v = md[k];
+          inD[4 * k] = v.x; inD[4 * k + 1] = v.y; inD[4 * k + 2] = v.z; inD[4 * k + 3] = v.w;
+          const float4 x = mu[k];
+          inU[4 * k] = x.x; inU[4 * k + 1] = x.y; inU[4 * k + 2] = x.z; inU[4 * k + 3] = x.w;
         }
       }
-      // the lane shifts of ofdis_fused.hip with the wavefront boundary bridged (kd / ku: index in the down / up mailbox)
-      auto from_prev = [&](float x, int kd) { const float r = wave_from_prev(x); return lo_edge ? in[kd] : r; };
-      auto from_next = [&](float x, int ku) { const float r = wave_from_next(x); return hi_edge ? in[ku] : r; };
+      // the lane shifts of ofdis_fused.hip with the wavefront boundaries bridged (kd / ku: index in the down / up mailbox)
+      auto from_prev = [&](float x, int kd) { const float r = wave_from_prev(x); return lo_edge ? inD[kd] : r; };
+      auto from_next = [&](float x, int ku) { const float r = wave_from_next(x); return hi_edge ? inU[ku] : r; };
       // ---- (3) smoothness of row t+2 (opticalflow_aux.c:128-140)
       const bool x2_last = (x2 == w - 1);
       {
@@ -214,16 +226,16 @@ __global__ __launch_bounds__(128) void tv_fused_tall_kernel(const FusedArgs a) {
         const float ex = ur - ul, fx = vr - vl, ey = ub - ut, fy = vb - vt;
         sm[(u + 2) % 3] = fdiv_by_sqrt(qa, 0.25f * (ex * ex + ey * ey + fx * fx + fy * fy) + EPS_SMOOTH);
       }
-      // ---- phase B: the smoothness of row t+2 of row 64, for row 63's vertical edge weight
-      if (lo_edge) mbB = sm[(u + 2) % 3];
+      // ---- phase B: the smoothness of row t+2 of a wavefront's first row, for the vertical edge weight of the row above it
+      if (lo_edge) mbB[q - 1] = sm[(u + 2) % 3];
       mw_step_barrier();
       // ---- (4) system of pixel row tau = t+1 (opticalflow_aux.c:150-163, 172-199, 342-427)
       {
         const float sc = sm[(u + 1) % 3];
         const float s_r = sm[(u + 2) % 3];
         float s_d = wave_from_next(sm[(u + 2) % 3]);
-        if (q == 0) {  // (wave-uniform: only wave 0 has a lane whose lower neighbour lives in the other wavefront)
-          const float sb = mbB;
+        if (has_dn) {  // (wave-uniform: lane 63's lower neighbour lives in the next wavefront)
+          const float sb = mbB[q];
           s_d = hi_edge ? sb : s_d;
         }
         const float sh_c = x1_last ? 0.0f : sc + s_r;
@@ -312,16 +324,17 @@ __global__ __launch_bounds__(128) void tv_fused_tall_kernel(const FusedArgs a) {
 }
 
 bool tv_fused_tall_supported(const TvGeom& t, int iterations) {
-  return t.noc == 1 && t.h > 64 && t.h <= 128 && t.w >= 16 && iterations >= 1 && iterations <= 3;
+  return t.noc == 1 && t.h > 64 && t.h <= 256 && t.w >= 16 && iterations >= 1 && iterations <= 3;
 }
 
 hipError_t launch_tv_fused_tall(const FusedArgs& a, hipStream_t s) {
   if (!tv_fused_tall_supported(a.t, a.iterations) || a.n_inner < 1 || a.S < 1 || a.t.nframes % a.S != 0) return hipErrorInvalidValue;
   const int nstrips = a.t.nframes / a.S;
   const bool bright = a.half_delta_over3 != 0.0f;
+  const dim3 bd(64 * ((a.t.h + 63) / 64));  // two to four wavefronts per strip
 #define OFDIS_TALL_LAUNCH(NS)                                                                             \
-  if (bright) hipLaunchKernelGGL((tv_fused_tall_kernel<NS, true>), dim3(nstrips), dim3(128), 0, s, a);     \
-  else hipLaunchKernelGGL((tv_fused_tall_kernel<NS, false>), dim3(nstrips), dim3(128), 0, s, a)
+  if (bright) hipLaunchKernelGGL((tv_fused_tall_kernel<NS, true>), dim3(nstrips), bd, 0, s, a);            \
+  else hipLaunchKernelGGL((tv_fused_tall_kernel<NS, false>), dim3(nstrips), bd, 0, s, a)
   switch (a.iterations) {
     case 1: OFDIS_TALL_LAUNCH(1); break;
     case 2: OFDIS_TALL_LAUNCH(2); break;

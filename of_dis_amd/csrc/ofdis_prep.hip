@@ -497,10 +497,10 @@ __global__ __launch_bounds__(64 * WPF) void tv_prep_kernel(const PrepArgs a, con
   }
 }
 
-// (rows: the kernel marches down any number of them; 128 is what the consumers of its records handle -- one wavefront per strip
-// up to 64 rows, two up to 128: ofdis_fused.hip, ofdis_fused_tall.hip)
+// (rows: the kernel marches down any number of them; 256 is what the consumers of its records handle -- one wavefront per strip
+// up to 64 rows, two to four up to 256: ofdis_fused.hip, ofdis_fused_tall.hip)
 // (columns: one lane each, up to four wavefronts side by side)
-bool tv_prep_supported(const TvGeom& t) { return t.noc == 1 && t.w >= 16 && t.w <= 256 && t.h >= 4 && t.h <= 128; }
+bool tv_prep_supported(const TvGeom& t) { return t.noc == 1 && t.w >= 16 && t.w <= 256 && t.h >= 4 && t.h <= 256; }
 // Can launch_tv_prep densify the flow itself for this patch grid (PrepArgs::dens_*)?  The geometry of densify_quad_kernel:
 // gray 8x8 patches on a step-4 grid (operating point 2), at most 2 x 2 patches per pixel.
 bool tv_prep_densifies(const LevelGeom& g) { return g.noc == 1 && g.P == 8 && g.steps == 4 && g.offw < 4 && g.offh < 4; }

@@ -599,7 +599,7 @@ def test_densification_inside_the_warp_kernel(gpu, orc, size, nfr, dens):
 
 
 @pytest.mark.parametrize("size,nfr", [((1920, 1080), 3), ((1920, 1080), 40), ((1700, 1050), 2), ((1242, 375), 3), ((1242, 375), 70),
-                                      ((1242, 560), 2)])
+                                      ((1242, 560), 2), ((1080, 1920), 2)])
 def test_hd_gray_pairs_take_the_two_wavefront_fused_kernel(gpu, orc, size, nfr):
     """1920x1080 gray at operating point 2: levels 30x17, 60x34 and 120x68 -- the finest one is four rows taller than a
     wavefront; 1242x375 (KITTI): levels 39x12, 78x24 and 156x48 -- the finest one wider than two wavefronts.  The whole path

@@ -261,13 +261,15 @@ def test_varref_square_and_near_square_levels(gpu, orc, w, h, tv_variant):
 
 @pytest.mark.parametrize("knobs", [{}, {"finish_fusion": 0}, {"fused_strip": 2}, {"prep_band_rows": 6}])
 @pytest.mark.parametrize("w,h", [(120, 68), (128, 128), (16, 65), (100, 127), (64, 96), (17, 70), (128, 66), (96, 100),
-                                 (156, 48), (192, 64), (129, 30), (256, 16), (200, 100), (193, 65), (255, 128), (160, 5)])
+                                 (156, 48), (192, 64), (129, 30), (256, 16), (200, 100), (193, 65), (255, 128), (160, 5),
+                                 (135, 240), (64, 200), (100, 129), (128, 256), (20, 192), (150, 193)])
 def test_varref_levels_of_65_to_128_rows(gpu, orc, w, h, knobs):
     """Levels wider than two wavefronts (the finest level of a 1242 x 375 KITTI pair at operating point 2 is 156 x 48: the
     row-marching warp + derivatives kernel with three / four wavefronts side by side) and
-    levels taller than a wavefront has lanes (the finest level of a 1080p / 4K gray pair at operating point 2 is 120 x 68):
-    the fused TV kernel with TWO wavefronts per strip (ofdis_fused_tall.hip) -- rows 0..63 and 64..h-1, every lane shift at the
-    boundary bridged by an LDS mailbox -- and the row-marching warp + derivatives kernel in front of it must give the bits of
+    levels taller than a wavefront has lanes (the finest level of a 1080p / 4K gray pair at operating point 2 is 120 x 68; a
+    portrait 1080 x 1920 pair gives 135 x 240):
+    the fused TV kernel with TWO to FOUR wavefronts per strip (ofdis_fused_tall.hip) -- rows 64 q .. 64 q + 63, every lane shift
+    at a wavefront boundary bridged by an LDS mailbox -- and the row-marching warp + derivatives kernel in front of it must give the bits of
     the reference, for one / two / three sweeps, with and without the brightness term, for several frames (strips), with the
     separate finish kernel, and with the warp kernel cut into row bands."""
     import gen_synth
