@@ -39,7 +39,7 @@ extern "C" {
  * without a bump), ofdis_batch_status and ofdis_batch_upsample_frames were added.  3 (round 6): streams, pinned host memory
  * asynchronous copies and events (ofdis_stream_create, ofdis_host_alloc, ofdis_memcpy_h2d_async / _d2h_async,
  * ofdis_event_*), ofdis_build_id; ofdis_tuning grew to
- * 18 ints (fused_xcu_drop, prep_densify) and fused_xcu_spin became a time in microseconds.  A caller checks ofdis_version() ==
+ * 19 ints (fused_xcu_drop, prep_densify, fused_tall_group) and fused_xcu_spin became a time in microseconds.  A caller checks ofdis_version() ==
  * OFDIS_VERSION before passing structs (of_dis_amd/capi.py does at load). */
 #define OFDIS_VERSION 3
 
@@ -260,6 +260,9 @@ typedef struct ofdis_tuning {
   int prep_densify;   /* 1: on the fused TV path (gray 8x8 patches, step-4 grid) the warp + derivatives kernel densifies the
                        * flow from the patch results itself (PatGridClass::AggregateFlowDense inside tv_prep_kernel): no
                        * densification launch, no round trip of the dense flow; 0: separate kernel  OFDIS_NO_PREP_DENSIFY -> 0 */
+  int fused_tall_group; /* levels of 65 ... 96 rows (the finest level of a 1080p / 4K gray pair is 120 x 68): 1 = the fused TV
+                       * kernel takes up to three strips per workgroup, their rows beyond the 64th sharing ONE wavefront
+                       * (2 .. 7: at most that many); 0 = two wavefronts per strip   OFDIS_TALL_GROUP, OFDIS_NO_TALL_GROUP -> 0 */
 } ofdis_tuning;
 int ofdis_get_tuning(ofdis_tuning* out);
 int ofdis_set_tuning(const ofdis_tuning* in);

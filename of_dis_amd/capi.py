@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "ofdis_build_id", "ofdis_stream_create", "ofdis_stream_destroy", "ofdis_host_alloc", "ofdis_host_free", "ofdis_memcpy_h2d_async", "ofdis_memcpy_d2h_async",
     "ofdis_event_create", "ofdis_event_destroy", "ofdis_event_record", "ofdis_stream_wait_event", "ofdis_event_sync",
 ]
-OFDIS_VERSION = 3  # include/ofdis.h: the struct layouts below (OfdisTuning: 18 ints) belong to this ABI version
+OFDIS_VERSION = 3  # include/ofdis.h: the struct layouts below (OfdisTuning: 19 ints) belong to this ABI version
 
 
 class OfdisTuning(C.Structure):
@@ -44,7 +44,7 @@ class OfdisTuning(C.Structure):
     (0 = exact arithmetic, 1 = the FMA / fast-reciprocal tolerance contract)."""
     _fields_ = [(n, C.c_int) for n in ("gray8", "rgb12", "rgb12_lpp", "fused_tv", "fused_mw_max", "fused_split",
                                        "finish_fusion", "fused_strip", "prep_band_rows", "graph", "flow_dma", "flow_whole",
-                                       "fused_xcu_max", "fused_tp_pipe", "fused_xcu_spin", "contract", "fused_xcu_drop", "prep_densify")]
+                                       "fused_xcu_max", "fused_tp_pipe", "fused_xcu_spin", "contract", "fused_xcu_drop", "prep_densify", "fused_tall_group")]
 
 
 class OfdisError(RuntimeError):

@@ -86,7 +86,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 hipError_t launch_tv_fused_xcu(const FusedArgs& a, const FusedXcu& x, int waves, int R, hipStream_t s);
 // Levels of 65 ... 128 rows: two wavefronts per strip (ofdis_fused_tall.hip)
 bool tv_fused_tall_supported(const TvGeom& t, int iterations);
-hipError_t launch_tv_fused_tall(const FusedArgs& a, hipStream_t s);
+hipError_t launch_tv_fused_tall(const FusedArgs& a, hipStream_t s, int group);
 
 }  // namespace OFDIS_KNS
 }  // namespace ofdis

@@ -520,7 +520,7 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow, 
   const int h = a.t.h;
   if (h > 64) {  // 65 ... 256 rows
     if (wrote_flow) *wrote_flow = a.flow_out != nullptr;
-    return launch_tv_fused_tall(a, s);
+    return launch_tv_fused_tall(a, s, a.tall_group);
   }
   const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
   const int G = 64 / R;

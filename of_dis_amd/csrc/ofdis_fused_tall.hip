@@ -22,19 +22,28 @@
 // a second mailbox word and a second barrier (phase B).  Two barriers per step; a wavefront can never be more than one phase
 // ahead of the other, so A needs two buffers (the faster wavefront writes step t+1's while the slower still reads step t's in
 // parts 4 / 5) and B one (it is rewritten only after barrier A of the next step, which the reader has passed by then).
+#include <algorithm>
+
 #include "ofdis_fused.h"
 
 namespace ofdis {
 namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
 
-template <int NS, bool BRIGHT>
-__global__ __launch_bounds__(256) void tv_fused_tall_kernel(const FusedArgs a) {
+// GROUPED (levels of 65 ... 96 rows: the HD / 4K case is 68).  Two wavefronts per strip leave the second one with h - 64 of
+// its 64 lanes busy -- 4 at h = 68.  Here a workgroup takes NH strips: NH "head" wavefronts (rows 0..63 of one strip each) and
+// ONE "tail" wavefront whose lane groups of RT lanes (RT = the power of two >= h - 64) are rows 64..h-1 of those NH strips:
+// NH + 1 wavefronts for NH strips instead of 2 NH (h = 68: 80 % of the lanes busy at NH = 3, 93 % at NH = 7, instead of 53 %).  A boundary is
+// now head i's lane 63 <-> lane RT i of the tail, mailbox i; inside the tail wavefront a DPP shift never crosses into another
+// group's pixels: the first lane of a group takes its upper neighbour from the mailbox, the last row of a strip has no lower
+// neighbour (has_bot = false selects every such value away).  Everything else is the step of the kernel above, unchanged.
+template <int NS, bool BRIGHT, bool GROUPED>
+__global__ __launch_bounds__(GROUPED ? 512 : 256) void tv_fused_tall_kernel(const FusedArgs a, const int RT) {
   constexpr int U = 6;
   constexpr int PDW = 5, PDD = 3;
   constexpr int NDOWN = 5 + 2 * NS, NUP = 6 + 2 * (NS - 1), NMB = 12;  // mailbox words per direction (padded to 16-byte reads)
   static_assert(NDOWN <= NMB && NUP <= NMB, "mailbox too small");
   static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
-  constexpr int NB = 3;  // boundaries between the (at most four) wavefronts of a strip
+  constexpr int NB = GROUPED ? 7 : 3;  // boundaries: between the (at most four) wavefronts of a strip / heads <-> tail groups
   __shared__ __attribute__((aligned(16))) float mbA[2][2][NB][NMB];  // [step parity][0 = down, 1 = up][boundary][value]
   __shared__ float mbB[NB];  // smoothness of row t+2, lane 0 of the wavefront below a boundary -> lane 63 of the one above
   const int w = a.t.w, h = a.t.h;
@@ -43,29 +52,48 @@ __global__ __launch_bounds__(256) void tv_fused_tall_kernel(const FusedArgs a) {
   const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wavefront q: rows 64 q .. 64 q + 63
   const int nw = (int)(blockDim.x >> 6);                            // wavefronts per strip: ceil(h / 64)
   const int nstrips = a.t.nframes / a.S;
-  const int s0 = blockIdx.x;  // one strip per workgroup
+  const int nh = GROUPED ? nw - 1 : 1;                 // strips per workgroup (GROUPED: one head wavefront each)
+  const int s0 = blockIdx.x * nh;                      // first strip of this workgroup
   if (s0 >= nstrips) return;
-  const int jr = 64 * q + lane;
-  const bool row_ok = jr < h;
-  const int j = jr < h ? jr : h - 1;  // lanes beyond the image shadow the last row (real data, results never stored)
+  const int nvalid = min(nh, nstrips - s0);            // (the last workgroup of a launch may hold fewer)
+  const bool tail = GROUPED && q == nh;
+  // this lane's strip within the workgroup and its image row; lanes / wavefronts without a pixel shadow the nearest real one
+  // (real data, results never stored: "Border handling", ofdis_fused.hip)
+  int fl = 0, jr = 64 * q + lane;
+  bool strip_ok = true;
+  if constexpr (GROUPED) {
+    const int g = tail ? lane / RT : q;
+    strip_ok = g < nvalid;
+    fl = min(g, nvalid - 1);
+    jr = tail ? 64 + lane % RT : lane;
+  }
+  const bool row_ok = strip_ok && jr < h;
+  const int j = jr < h ? jr : h - 1;
   const bool has_top = j > 0, has_bot = j < h - 1;
-  const bool has_up = q > 0, has_dn = q + 1 < nw;  // (wave-uniform) a boundary above / below this wavefront
-  const bool lo_edge = has_up && lane == 0;   // its "previous lane" is lane 63 of the wavefront above
-  const bool hi_edge = has_dn && lane == 63;  // its "next lane" is lane 0 of the wavefront below
+  // a boundary above / below this wavefront (wave-uniform); GROUPED: every head has one below, the tail one above every group
+  const bool has_up = GROUPED ? tail : q > 0, has_dn = GROUPED ? !tail : q + 1 < nw;
+  const bool lo_edge = has_up && (GROUPED ? lane % RT == 0 : lane == 0);  // its "previous lane" lives in another wavefront
+  const bool hi_edge = has_dn && lane == 63;                              // its "next lane" lives in another wavefront
+  // the mailbox of that boundary: per lane in the tail wavefront, uniform otherwise.  (GROUPED: the tail's lane groups beyond
+  // the NH-th shadow the last strip and READ the last mailbox -- finite data -- but never publish)
+  const int b_up = GROUPED ? min(lane / RT, nh - 1) : (has_up ? q - 1 : 0);
+  const int b_dn = GROUPED ? min(q, nh - 1) : (has_dn ? q : 0);
+  const bool pub_up = lo_edge && (!GROUPED || lane / RT < nh);
   const float omega = a.omega, qa = a.quarter_alpha, hd3 = a.half_delta_over3, hg3 = a.half_gamma_over3;
 
   const size_t strip_recs = (size_t)rw * h;
   auto rsrc = [&](const float* base, int rec_floats) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)s0 * strip_recs * rec_floats), 0,
-                                             (int)(strip_recs * rec_floats * 4), 0x00020000);
+                                             (int)(nvalid * strip_recs * rec_floats * 4), 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t rsD = rsrc(a.d8, 8), rsW = rsrc(a.wrec, 2), rsU = rsrc(a.uv, 2);
-  const int vo8 = j * 32, vo2 = j * 8;  // this lane's record within diag row 0 of the strip
+  const int vrec = fl * (int)strip_recs + j;  // this lane's record within diag row 0 of its strip
+  const int vo8 = vrec * 32, vo2 = vrec * 8;
   auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
 
   const int npx = w * h;
   float2* const flow_row =
-      a.flow_out ? reinterpret_cast<float2*>(a.flow_out) + ((size_t)s0 * a.S * npx + (size_t)j * w) : nullptr;
+      a.flow_out ? reinterpret_cast<float2*>(a.flow_out) + ((size_t)(s0 + fl) * a.S * npx + (size_t)j * w) : nullptr;
   const bool aos_out = a.flow_out != nullptr;
 
   FRow W[6];
@@ -173,7 +201,7 @@ __global__ __launch_bounds__(256) void tv_fused_tall_kernel(const FusedArgs a) {
       //      place of a DPP lane shift during this step (everything but the smoothness of row t+2, which does not exist yet)
       {
         if (has_dn) {  // lane 63 publishes "down" at the boundary below this wavefront
-          float* const mw = &mbA[par][0][q][0];
+          float* const mw = &mbA[par][0][b_dn][0];
           if (lane == 63) {
             mw[0] = uu[(u + 1) % 3]; mw[1] = vv[(u + 1) % 3];          // row t+1: ut, vt of the row below
             mw[2] = W[u % 6].wx; mw[3] = W[u % 6].wy;                  // row t: wx_u, wy_u
@@ -182,9 +210,9 @@ __global__ __launch_bounds__(256) void tv_fused_tall_kernel(const FusedArgs a) {
             for (int s = 0; s < NS; ++s) { mw[5 + s] = ru[s]; mw[5 + NS + s] = rv[s]; }  // tu, tv of sweep s
           }
         }
-        if (has_up) {  // lane 0 publishes "up" at the boundary above
-          float* const mw = &mbA[par][1][q - 1][0];
-          if (lane == 0) {
+        if (has_up) {  // lane 0 (GROUPED: the first lane of every group) publishes "up" at the boundary above
+          float* const mw = &mbA[par][1][b_up][0];
+          if (pub_up) {
             mw[0] = uu[u % 3]; mw[1] = vv[u % 3];                      // row t+3: ub, vb of the row above
             mw[2] = W[(u + 2) % 6].wx; mw[3] = W[(u + 2) % 6].wy;      // row t+2: wx_d, wy_d
             mw[4] = slot[u % 6].dur; mw[5] = slot[u % 6].dvr;          // bu, bv of sweep 0
@@ -198,8 +226,8 @@ __global__ __launch_bounds__(256) void tv_fused_tall_kernel(const FusedArgs a) {
       // below (for lane 63); a wavefront without that boundary reads a mailbox nobody uses (a valid address, value unused)
       float inD[NMB], inU[NMB];
       {
-        const float4* md = reinterpret_cast<const float4*>(&mbA[par][0][has_up ? q - 1 : 0][0]);
-        const float4* mu = reinterpret_cast<const float4*>(&mbA[par][1][has_dn ? q : 0][0]);
+        const float4* md = reinterpret_cast<const float4*>(&mbA[par][0][b_up][0]);
+        const float4* mu = reinterpret_cast<const float4*>(&mbA[par][1][b_dn][0]);
 #pragma unroll
         for (int k = 0; k < NMB / 4; ++k) {
           const float4 v = md[k];
@@ -227,7 +255,7 @@ __global__ __launch_bounds__(256) void tv_fused_tall_kernel(const FusedArgs a) {
         sm[(u + 2) % 3] = fdiv_by_sqrt(qa, 0.25f * (ex * ex + ey * ey + fx * fx + fy * fy) + EPS_SMOOTH);
       }
       // ---- phase B: the smoothness of row t+2 of a wavefront's first row, for the vertical edge weight of the row above it
-      if (lo_edge) mbB[q - 1] = sm[(u + 2) % 3];
+      if (pub_up) mbB[b_up] = sm[(u + 2) % 3];
       mw_step_barrier();
       // ---- (4) system of pixel row tau = t+1 (opticalflow_aux.c:150-163, 172-199, 342-427)
       {
@@ -235,7 +263,7 @@ __global__ __launch_bounds__(256) void tv_fused_tall_kernel(const FusedArgs a) {
         const float s_r = sm[(u + 2) % 3];
         float s_d = wave_from_next(sm[(u + 2) % 3]);
         if (has_dn) {  // (wave-uniform: lane 63's lower neighbour lives in the next wavefront)
-          const float sb = mbB[q];
+          const float sb = mbB[b_dn];
           s_d = hi_edge ? sb : s_d;
         }
         const float sh_c = x1_last ? 0.0f : sc + s_r;
@@ -327,14 +355,39 @@ bool tv_fused_tall_supported(const TvGeom& t, int iterations) {
   return t.noc == 1 && t.h > 64 && t.h <= 256 && t.w >= 16 && iterations >= 1 && iterations <= 3;
 }
 
-hipError_t launch_tv_fused_tall(const FusedArgs& a, hipStream_t s) {
+// group: the heads + shared tail form (ofdis_tuning::fused_tall_group): 0 = never, 1 = the default, up to THREE strips per
+// workgroup (four wavefronts, two workgroups per compute unit), 2 .. 7 = at most that many.  Measured at 1920x1080 (level
+// 120 x 68), k frames/s at 1024 / 4096 / 8192 pairs: ungrouped 473 / 646 / 683; cap 2: 589 / 685 / 722; 3: 575 / 718 / 739;
+// 4: 567 / 663 / 691; 5: 556 / 686 / 729; 7: 547 / 699 / 747 -- the lanes saved by a wider group are paid back by the lock
+// step of more wavefronts and by coarser rounds of workgroups (profiles/r06_variants.txt)
+hipError_t launch_tv_fused_tall(const FusedArgs& a, hipStream_t s, int group) {
   if (!tv_fused_tall_supported(a.t, a.iterations) || a.n_inner < 1 || a.S < 1 || a.t.nframes % a.S != 0) return hipErrorInvalidValue;
   const int nstrips = a.t.nframes / a.S;
   const bool bright = a.half_delta_over3 != 0.0f;
-  const dim3 bd(64 * ((a.t.h + 63) / 64));  // two to four wavefronts per strip
+  const int h = a.t.h;
+  // 65 ... 96 rows and at least two strips: heads + one shared tail wavefront (GROUPED).  NH = what the tail's lane groups hold,
+  // at most 7 (eight wavefronts = one workgroup per compute unit at two wavefronts per SIMD)
+  int RT = 64;
+  if (h <= 96 && group) RT = h - 64 <= 4 ? 4 : (h - 64 <= 8 ? 8 : (h - 64 <= 16 ? 16 : 32));
+  const int cap = group >= 2 ? std::min(group, 7) : 3;
+  const int nh = RT < 64 ? std::min(std::min(cap, 64 / RT), nstrips) : 1;
+  if (nh >= 2) {
+    const dim3 bd(64 * (nh + 1)), gd((nstrips + nh - 1) / nh);
+#define OFDIS_TALL_LAUNCH_G(NS)                                                                           \
+  if (bright) hipLaunchKernelGGL((tv_fused_tall_kernel<NS, true, true>), gd, bd, 0, s, a, RT);             \
+  else hipLaunchKernelGGL((tv_fused_tall_kernel<NS, false, true>), gd, bd, 0, s, a, RT)
+    switch (a.iterations) {
+      case 1: OFDIS_TALL_LAUNCH_G(1); break;
+      case 2: OFDIS_TALL_LAUNCH_G(2); break;
+      default: OFDIS_TALL_LAUNCH_G(3); break;
+    }
+#undef OFDIS_TALL_LAUNCH_G
+    return hipGetLastError();
+  }
+  const dim3 bd(64 * ((h + 63) / 64));  // two to four wavefronts per strip
 #define OFDIS_TALL_LAUNCH(NS)                                                                             \
-  if (bright) hipLaunchKernelGGL((tv_fused_tall_kernel<NS, true>), dim3(nstrips), bd, 0, s, a);            \
-  else hipLaunchKernelGGL((tv_fused_tall_kernel<NS, false>), dim3(nstrips), bd, 0, s, a)
+  if (bright) hipLaunchKernelGGL((tv_fused_tall_kernel<NS, true, false>), dim3(nstrips), bd, 0, s, a, 64); \
+  else hipLaunchKernelGGL((tv_fused_tall_kernel<NS, false, false>), dim3(nstrips), bd, 0, s, a, 64)
   switch (a.iterations) {
     case 1: OFDIS_TALL_LAUNCH(1); break;
     case 2: OFDIS_TALL_LAUNCH(2); break;

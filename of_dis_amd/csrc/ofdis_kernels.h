@@ -139,6 +139,8 @@ struct FusedArgs {
                       // n_inner wavefronts per strip group, du / dv from iteration to iteration through LDS, the derivative
                       // records of a row read by n_inner wavefronts of ONE compute unit within a few steps (one HBM read, the
                       // others hit the L2) -- 48 instead of 56 n_inner bytes of HBM traffic per pixel and level
+  int tall_group = 0; // levels of 65 ... 96 rows: 1 = several strips per workgroup, their rows beyond 64 in ONE shared wavefront
+                      // (ofdis_fused_tall.hip: GROUPED), 0 = two wavefronts per strip
 };
 // cross-CU variant (one workgroup per fixed-point iteration of a frame group), kept out of FusedArgs so that the other
 // variants' kernel arguments -- and register allocation -- stay what they were

@@ -259,10 +259,11 @@ def test_varref_square_and_near_square_levels(gpu, orc, w, h, tv_variant):
         assert_bits_equal(got[0], ref, f"varref {w}x{h} innerit={innerit} solverit={solverit}")
 
 
-@pytest.mark.parametrize("knobs", [{}, {"finish_fusion": 0}, {"fused_strip": 2}, {"prep_band_rows": 6}])
+@pytest.mark.parametrize("knobs", [{}, {"finish_fusion": 0}, {"fused_strip": 2}, {"prep_band_rows": 6}, {"fused_tall_group": 0}])
 @pytest.mark.parametrize("w,h", [(120, 68), (128, 128), (16, 65), (100, 127), (64, 96), (17, 70), (128, 66), (96, 100),
                                  (156, 48), (192, 64), (129, 30), (256, 16), (200, 100), (193, 65), (255, 128), (160, 5),
-                                 (135, 240), (64, 200), (100, 129), (128, 256), (20, 192), (150, 193)])
+                                 (135, 240), (64, 200), (100, 129), (128, 256), (20, 192), (150, 193),
+                                 (120, 72), (40, 80), (90, 96), (33, 66), (60, 81)])
 def test_varref_levels_of_65_to_128_rows(gpu, orc, w, h, knobs):
     """Levels wider than two wavefronts (the finest level of a 1242 x 375 KITTI pair at operating point 2 is 156 x 48: the
     row-marching warp + derivatives kernel with three / four wavefronts side by side) and
@@ -275,7 +276,8 @@ def test_varref_levels_of_65_to_128_rows(gpu, orc, w, h, knobs):
     import gen_synth
     from of_dis_amd.params import oppoint
     rng = np.random.default_rng(w * 1000 + h)
-    nfr = 4
+    # (65 ... 96 rows: several strips per workgroup with one shared tail wavefront -- 10 frames = a full group of 7 and a short one, or five strips of two)
+    nfr = 10 if 64 < h <= 96 else 4
     pairs = [gen_synth.make_pair(w, h, 300 + k, 1) for k in range(2)]
     old = gpu.set_tuning(**knobs)
     try:
@@ -283,7 +285,7 @@ def test_varref_levels_of_65_to_128_rows(gpu, orc, w, h, knobs):
             p = oppoint(2, w, h).copy(sc_f=0, sc_l=0, p_samp_s=4, imgpadding=4, tv_innerit=innerit, tv_solverit=solverit, tv_delta=delta)
             p.width, p.height = w, h
             pyr = [(orc.build_pyramid(p, ia), orc.build_pyramid(p, ib)) for ia, ib, _ in pairs]
-            flows = [rand_planes(rng, h, w, 2, scale=sc) for sc in (1.5, 0.3, 5.0, 1.0)]
+            flows = [rand_planes(rng, h, w, 2, scale=(1.5, 0.3, 5.0, 1.0)[f % 4]) for f in range(nfr)]
             flows[2][h - 1, w - 1] = (2.5 * w, -2.5 * h)  # far outside the image: mask 0, clamped taps
             refs = [orc.varref_level(p, 0, pyr[f % 2][0][0][0], pyr[f % 2][1][0][0], flows[f]) for f in range(nfr)]
             got = gpu.varref_level(p, 0, np.stack([pyr[f % 2][0][0][0] for f in range(nfr)]),
