@@ -718,7 +718,31 @@ def block_config4(capi, torch, p, batch, ia, ib, stream, dev, args):
     return out
 
 
-BLOCKS = [("small_batch", block_small_batch), ("dropin_latency", block_dropin_latency),
+def block_frame_sizes(capi, torch, p, batch, ia, ib, stream, dev, args):
+    """The same path at other common frame sizes (gray, operating point 2, 4096 resident pairs per step): what their finest
+    levels cost -- 1242x375 (KITTI: 156 x 48, wider than two wavefronts of the warp + derivatives kernel), 1280x720 (80 x 48),
+    1920x1080 (120 x 68: taller than one wavefront of the fused TV kernel).  Round 6 brought all of them onto the fused TV path."""
+    from of_dis_amd.params import oppoint
+    out = {}
+    for (w, h) in ((1242, 375), (1280, 720), (1920, 1080)):
+        n = 4096
+        pq = oppoint(2, w, h, noc=1, usetvref=True, verbosity=0)
+        xa, xb = synth_frames_range(0, 64, w, h, 777, dev)
+        xa, xb = xa.repeat(n // 64, 1, 1).contiguous(), xb.repeat(n // 64, 1, 1).contiguous()
+        bq = capi.Batch(pq, n)
+        bq.set_pipeline(2)
+        torch.cuda.synchronize()
+        bq.build_pyramids_u8(xa.data_ptr(), xb.data_ptr(), w, h, stream)
+        dt = timed_steps(torch, lambda: bq.run(stream), 10, 3)
+        bq.close()
+        del xa, xb
+        out[f"{w}x{h}"] = {"levels": [list(pq.level_size(l)) for l in range(pq.sc_l, pq.sc_f + 1)], "pairs_per_step": n,
+                           "ms_per_step": round(dt * 1e3, 3), "value": round(n / dt, 1), "unit": "frames/s"}
+    return {"workload": "other frame sizes: gray, operating point 2, TV on, 4096 resident pairs per step, two pipelined sub-batches, "
+                        f"{args.contract_used} contract (secondary; the metric's size is 1024x436)", **out}
+
+
+BLOCKS = [("small_batch", block_small_batch), ("frame_sizes", block_frame_sizes), ("dropin_latency", block_dropin_latency),
           ("warp_standalone", block_warp_standalone), ("e2e", block_e2e), ("host_e2e", block_host_e2e),
           ("config4", block_config4)]
 
