@@ -26,7 +26,10 @@ The JSON carries, besides the contract fields:
                     a bounded sample of the same frames, with the end-point error of the HIP flow against it
   tv_off            BASELINE configs[1] (same operating point, refinement off)
   batch512          BASELINE configs[4]: 512 pairs in total, sharded over the ranks of this run
-  small_batch       64 pairs per step on one GPU (the per-GPU share of configs[4] at 8 GPUs)
+  small_batch       64 pairs per step on one GPU (the per-GPU share of configs[4] at 8 GPUs), one pass at a time and with
+                    D passes in flight (`depth`)
+  frame_sizes       the same path at 1242x375 (KITTI), 1280x720 and 1920x1080 (secondary: their finest levels are wider / taller
+                    than the metric's)
   dropin_latency    ofdis_flow(): one pair per call, host pyramids in, host flow out
   e2e               secondary scope: 8-bit frames in HBM -> pyramids -> flow -> full-resolution flow in HBM
   host_e2e          the same from / to HOST memory: pinned 8-bit frames -> upload || compute || download, link-bound
