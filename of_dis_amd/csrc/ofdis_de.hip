@@ -4,27 +4,13 @@
 //     compute_smoothness(uu, 0)  +  compute_data_DE  +  sub_laplacian(b1, wx)     (opticalflow_aux.c:123-199,446-548)
 //     sor_coupled_slow_but_readable_DE                                            (solver.c:428-466)
 //     uu = min|max(wx + du, 0)   by camera side                                   (refine_variational.cpp:299-316)
-// One unknown per pixel.  This mode is outside the benchmarked path: the kernels favour plainness over speed
-// (per-pixel gathers, one launch per solver sweep); the solver keeps the reference's lexicographic Gauss-Seidel
-// order with the same anti-diagonal wavefront as ofdis_sor.hip.
+// One unknown per pixel.  The solver keeps the reference's lexicographic Gauss-Seidel order with the same
+// anti-diagonal wavefront and sweep pipelining as ofdis_sor.hip; the system kernel is tiled like tv_system_kernel.
 #include "ofdis_kernels.h"
 #include "ofdis_tvmath.h"
 
 namespace ofdis {
 namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
-
-// compute_smoothness at one pixel with vv == 0 (its derivative terms are exact zeros): replicate borders
-// horizontally (image.c:436-464), folded coefficients on the first / last row (image.c:376-399)
-__device__ __forceinline__ float de_smooth_at(const float* __restrict__ uu, int x, int y, int w, int h, float qa) {
-  const float* r = uu + (size_t)y * w;
-  const float uc = r[x], ul = r[x > 0 ? x - 1 : 0], ur = r[x < w - 1 ? x + 1 : w - 1];
-  const float ux = D3_C0 * ul + D3_C1 * uc + D3_C2 * ur;
-  float uy;
-  if (y == 0) uy = (D3_C0 + D3_C1) * uc + D3_C2 * r[w + x];
-  else if (y == h - 1) uy = D3_C0 * r[x - w] + (D3_C1 + D3_C2) * uc;
-  else uy = D3_C0 * r[x - w] + D3_C1 * uc + D3_C2 * r[w + x];
-  return qa / sqrtf(ux * ux + uy * uy + EPS_SMOOTH);
-}
 
 // compute_data_DE for one pixel (opticalflow_aux.c:446-548).  D(k,c): derivative plane k, channel c.
 template <typename DF>
@@ -98,91 +84,304 @@ __device__ __forceinline__ void data_term_de(DF D, int noc, float m, float u, fl
 }
 
 // a11, b1, smooth_horiz, smooth_vert of every pixel -> planes 0..3 of `sys` in the solver's diag layout.
-// Inputs row-major: mask, wx, uu [B][h][w], derivs [B][8*noc][h][w]; du in diag layout.
+// Inputs row-major: mask, wx [B][h][w], derivs [B][8*noc][h][w]; du in diag layout.  The flow the smoothness weights
+// are taken of, uu = min|max(wx + du, 0) by camera side (refine_variational.cpp:299-316; plain wx before the first
+// solve, :283), is formed here from wx and du instead of being written by one kernel and read back by the next.
+// One workgroup per 32 x 32 tile: wx and du (halo 2) are staged once, the smoothness weight of every pixel of the
+// tile + halo 1 is computed once (the per-pixel version evaluated five of them per pixel), du comes in and the four
+// planes go out through LDS with the rotated enumeration of tv_system_kernel, so that both sides of the diag layout
+// move as contiguous runs instead of one cache line per lane.
+constexpr int DT = 32;                          // output tile edge
+constexpr int DU_W = DT + 4, DS_W = DT + 2;     // uu tile (halo 2), smoothness / wx tiles (halo 1)
+constexpr int DT_PIX = DT * DT / 256;           // pixels per thread
+
 __global__ __launch_bounds__(256) void de_system_kernel(const DeSystemArgs a) {
+  constexpr int IN_FLOATS = 3 * DU_W * DU_W + DS_W * DS_W;
+  constexpr int OUT_FLOATS = 4 * DT * DT;
+  __shared__ float lds[IN_FLOATS > OUT_FLOATS ? IN_FLOATS : OUT_FLOATS];
+  float* uu_t = lds;                    // halo 2
+  float* wx_t = uu_t + DU_W * DU_W;     // halo 2
+  float* du_t = wx_t + DU_W * DU_W;     // halo 2
+  float* s_t = du_t + DU_W * DU_W;      // halo 1
   const int w = a.t.w, h = a.t.h, noc = a.t.noc;
   const int npx = w * h;
-  const long long gi = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gi >= (long long)npx * a.t.nframes) return;
-  const int frame = (int)(gi / npx);
-  const int i = (int)(gi - (long long)frame * npx);
-  const int y = i / w, x = i - y * w;
+  const int tiles_x = (w + DT - 1) / DT;
+  int frame, tile;
+  xcd_frame_map(blockIdx.x, tiles_x * ((h + DT - 1) / DT), a.t.nframes, frame, tile);
+  if (frame >= a.t.nframes) return;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int x0 = tx * DT, y0 = ty * DT;
+  const int tid = threadIdx.x;
   const size_t fo = (size_t)frame * npx;
-  const float* uu = a.uu + fo;
-  const float* wx = a.wx + fo;
-  const float sc = de_smooth_at(uu, x, y, w, h, a.quarter_alpha);
-  const float sh_c = (x < w - 1) ? sc + de_smooth_at(uu, x + 1, y, w, h, a.quarter_alpha) : 0.0f;  // :150-154
-  const float sv_c = (y < h - 1) ? sc + de_smooth_at(uu, x, y + 1, w, h, a.quarter_alpha) : 0.0f;  // :158-163
-  const size_t dg = fo + diag_index(x, y, w, h);
-  float a11, b1;
-  const float* dbase = a.derivs + (size_t)frame * 8 * noc * npx + i;
-  auto D = [&](int kk, int c) { return dbase[((size_t)kk * noc + c) * npx]; };
-  data_term_de(D, noc, a.mask[fo + i], a.du[dg], a.half_delta_over3, a.half_gamma_over3, a11, b1);
-  // sub_laplacian(b1, wx, smooth_horiz, smooth_vert) in its scatter order: -left, +right, -top, +bottom
-  const float wxc = wx[i];
-  if (x > 0) b1 -= (de_smooth_at(uu, x - 1, y, w, h, a.quarter_alpha) + sc) * (wxc - wx[i - 1]);
-  if (x < w - 1) b1 += sh_c * (wx[i + 1] - wxc);
-  if (y > 0) b1 -= (de_smooth_at(uu, x, y - 1, w, h, a.quarter_alpha) + sc) * (wxc - wx[i - w]);
-  if (y < h - 1) b1 += sv_c * (wx[i + w] - wxc);
-  float* out = a.sys + (size_t)frame * 4 * npx + diag_index(x, y, w, h);
-  out[0] = a11;
-  out[(size_t)npx] = b1;
-  out[(size_t)2 * npx] = sh_c;
-  out[(size_t)3 * npx] = sv_c;
+
+  // stage 0: wx (row-major) and du (diag layout, rotated enumeration) on tile + halo 2 at border-clamped coordinates
+  for (int n = tid; n < DU_W * DU_W; n += 256) {
+    const int qy = n / DU_W, qx = n - qy * DU_W;
+    const int y = clampi(y0 + qy - 2, 0, h - 1), x = clampi(x0 + qx - 2, 0, w - 1);
+    wx_t[n] = a.wx[fo + y * w + x];
+  }
+  for (int n = tid; n < DU_W * DU_W; n += 256) {
+    const int qy = n % DU_W, r = n / DU_W;
+    int qx = r - qy;
+    if (qx < 0) qx += DU_W;
+    const int y = clampi(y0 + qy - 2, 0, h - 1), x = clampi(x0 + qx - 2, 0, w - 1);
+    du_t[qy * DU_W + qx] = a.du[fo + diag_index(x, y, w, h)];
+  }
+  __syncthreads();
+  // uu: SSE minps / maxps of refine_variational.cpp:303-315 (the second operand, zero, is returned for a NaN)
+  for (int n = tid; n < DU_W * DU_W; n += 256) {
+    const float v = wx_t[n] + du_t[n];
+    uu_t[n] = a.clamp < 0 ? wx_t[n] : (a.clamp == 0 ? (v < 0.0f ? v : 0.0f) : (v > 0.0f ? v : 0.0f));
+  }
+  __syncthreads();
+  // stage 1: compute_smoothness with vv == 0 (its derivative terms are exact zeros) on tile + halo 1: replicate
+  // borders horizontally (image.c:436-464), folded coefficients on the first / last row (image.c:376-399).
+  // Only in-image entries are ever read back.
+  for (int n = tid; n < DS_W * DS_W; n += 256) {
+    const int qy = n / DS_W, qx = n - qy * DS_W;
+    const int y = y0 + qy - 1, x = x0 + qx - 1;
+    float sval = 0.0f;
+    if (y >= 0 && y < h && x >= 0 && x < w) {
+      const int c = (qy + 1) * DU_W + qx + 1;
+      const float uc = uu_t[c];
+      const float ux = D3_C0 * uu_t[c - 1] + D3_C1 * uc + D3_C2 * uu_t[c + 1];
+      float uy;
+      if (y == 0) uy = (D3_C0 + D3_C1) * uc + D3_C2 * uu_t[c + DU_W];
+      else if (y == h - 1) uy = D3_C0 * uu_t[c - DU_W] + (D3_C1 + D3_C2) * uc;
+      else uy = D3_C0 * uu_t[c - DU_W] + D3_C1 * uc + D3_C2 * uu_t[c + DU_W];
+      sval = a.quarter_alpha / sqrtf(ux * ux + uy * uy + EPS_SMOOTH);
+    }
+    s_t[n] = sval;
+  }
+  __syncthreads();
+  // stage 2: per pixel -- compute_data_DE, then sub_laplacian(b1, wx, smooth_horiz, smooth_vert) in its scatter
+  // order: -left, +right, -top, +bottom (opticalflow_aux.c:172-199)
+  float res[DT_PIX][4];
+  const int qx = tid % DT;
+#pragma unroll
+  for (int k = 0; k < DT_PIX; ++k) {
+    const int ry = tid / DT + k * (256 / DT);
+    const int y = y0 + ry, x = x0 + qx;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) res[k][q] = 0.0f;
+    if (y >= h || x >= w) continue;
+    const int i = y * w + x;
+    const int sc_i = (ry + 1) * DS_W + qx + 1;  // in the halo-1 tile
+    const int uc = (ry + 2) * DU_W + qx + 2;    // in the halo-2 tiles
+    const float sc = s_t[sc_i];
+    const float sh_c = (x < w - 1) ? sc + s_t[sc_i + 1] : 0.0f;      // opticalflow_aux.c:150-154
+    const float sv_c = (y < h - 1) ? sc + s_t[sc_i + DS_W] : 0.0f;   // :158-163
+    float a11, b1;
+    const float* dbase = a.derivs + (size_t)frame * 8 * noc * npx + i;
+    auto D = [&](int kk, int c) { return dbase[((size_t)kk * noc + c) * npx]; };
+    data_term_de(D, noc, a.mask[fo + i], du_t[uc], a.half_delta_over3, a.half_gamma_over3, a11, b1);
+    const float wxc = wx_t[uc];
+    if (x > 0) b1 -= (s_t[sc_i - 1] + sc) * (wxc - wx_t[uc - 1]);
+    if (x < w - 1) b1 += sh_c * (wx_t[uc + 1] - wxc);
+    if (y > 0) b1 -= (s_t[sc_i - DS_W] + sc) * (wxc - wx_t[uc - DU_W]);
+    if (y < h - 1) b1 += sv_c * (wx_t[uc + DU_W] - wxc);
+    res[k][0] = a11; res[k][1] = b1; res[k][2] = sh_c; res[k][3] = sv_c;
+  }
+  __syncthreads();  // input tiles dead: reuse the LDS as the output staging area [plane][ry][qx]
+#pragma unroll
+  for (int k = 0; k < DT_PIX; ++k) {
+    const int ry = tid / DT + k * (256 / DT);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lds[(q * DT + ry) * DT + qx] = res[k][q];
+  }
+  __syncthreads();
+  // stage 3: the four planes in diag layout, rotated enumeration (lane -> x-1, y+1)
+  for (int n = tid; n < DT * DT; n += 256) {
+    const int ry = n % DT, r = n / DT;
+    const int rx = (r - ry) & (DT - 1);
+    const int y = y0 + ry, x = x0 + rx;
+    if (y < h && x < w) {
+      float* out = a.sys + (size_t)frame * 4 * npx + diag_index(x, y, w, h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[(size_t)q * npx] = lds[(q * DT + ry) * DT + rx];
+    }
+  }
 }
 
 hipError_t launch_de_system(const DeSystemArgs& a, hipStream_t s) {
-  const long long total = (long long)a.t.w * a.t.h * a.t.nframes;
-  hipLaunchKernelGGL(de_system_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  const int tiles = ((a.t.w + DT - 1) / DT) * ((a.t.h + DT - 1) / DT);
+  hipLaunchKernelGGL(de_system_kernel, dim3(((a.t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
-// One sweep of sor_coupled_slow_but_readable_DE over frames of at most 64 rows: lane = row j, step t handles
-// column t - j; the updated left value is the lane's own previous result, the updated top value the previous
-// lane's previous result, right and bottom come from the not-yet-updated diag row t+1.
-__global__ __launch_bounds__(256) void de_sor_sweep_kernel(const DeSorArgs a, const int R) {
+// sor_coupled_slow_but_readable_DE, all NS sweeps of the call in one pass
+// (the scheme of sor_wave_kernel, ofdis_sor.hip): lane = row j, at step t sweep s is at column t - j - 2s.  The
+// updated left value is the lane's own previous result of the same sweep, the updated top value the previous
+// lane's; own, right and bottom are the previous sweep's results (the stored du for sweep 0: right and bottom
+// come from diag row t+1).  Loads run PD steps ahead through a register ring that also hands each pixel's
+// coefficients from sweep 0 to the trailing sweeps.
+struct DeSlot {
+  float a11, b1, sh, sv;  // loaded (diag row tau)
+  float dur;              // stored du of the right neighbour (diag row tau+1)
+  float hl, vt;           // left / top edge weights, filled in at step tau
+};
+
+// MAXT == 0: frames of at most 64 rows, 64 / R frames per wavefront, four wavefronts per workgroup.
+// MAXT > 0 (the scheme of sor_block_kernel): one workgroup per frame, wavefront k owns rows 64k .. 64k+63, all
+// wavefronts advance in lock step; the values that cross a wavefront boundary travel through a double-buffered LDS
+// mailbox written at the end of a step and read at the start of the next.  Up to 16 wavefronts (h <= 1024).
+template <int NS, int PD, int MAXT>
+__global__ __launch_bounds__(MAXT > 0 ? MAXT : 256) void de_sor_kernel(const DeSorArgs a, const int R) {
+  constexpr bool BLOCK = MAXT > 0;
+  constexpr int LIFE = (2 * (NS - 1) > 1) ? 2 * (NS - 1) : 1;
+  constexpr int RS = PD + LIFE + 1;
+  __shared__ float mail_top[BLOCK ? 2 : 1][BLOCK ? 16 : 1][NS + 1];  // lane 63 of wave k -> lane 0 of wave k+1
+  __shared__ float mail_bot[BLOCK ? 2 : 1][BLOCK ? 16 : 1][NS];      // lane 0 of wave k -> lane 63 of wave k-1
   const int w = a.t.w, h = a.t.h;
   const int npx = w * h;
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int G = 64 / R;
-  if (wid * G >= a.t.nframes) return;
-  int f = wid * G + lane / R;
-  const int jr = lane % R;
-  const bool row_ok = (f < a.t.nframes) && (jr < h);
-  if (f >= a.t.nframes) f = a.t.nframes - 1;
+  const int wave = threadIdx.x >> 6;
+  int f, jr;
+  bool row_ok, first_lane = false, last_lane = false;
+  if constexpr (BLOCK) {
+    f = blockIdx.x;
+    jr = threadIdx.x;
+    row_ok = jr < h;
+    first_lane = lane == 0 && wave > 0;
+    last_lane = lane == 63 && wave + 1 < (int)(blockDim.x >> 6);
+  } else {
+    const int wid = blockIdx.x * 4 + wave;
+    const int G = 64 / R;
+    if (wid * G >= a.t.nframes) return;
+    f = wid * G + lane / R;
+    jr = lane % R;
+    row_ok = (f < a.t.nframes) && (jr < h);
+    if (f >= a.t.nframes) f = a.t.nframes - 1;
+  }
   const int j = jr < h ? jr : h - 1;
   const bool has_top = j > 0, has_bot = j < h - 1;
   const float omega = a.omega;
   const float* __restrict__ sysf = a.sys + (size_t)f * 4 * npx + j;
   float* __restrict__ duf = a.du + (size_t)f * npx + j;
+
+  DeSlot ring[RS];
+#pragma unroll
+  for (int r = 0; r < RS; ++r) ring[r] = DeSlot{0, 0, 0, 0, 0, 0, 0};
+  float ru[NS], ru2[NS];  // result of sweep s one / two steps ago
+#pragma unroll
+  for (int s = 0; s < NS; ++s) ru[s] = ru2[s] = 0.0f;
+  auto load_slot = [&](DeSlot& sl, int drow, int drow1) {
+    const int o = drow * h;
+    sl.a11 = sysf[o];
+    sl.b1 = sysf[(size_t)npx + o];
+    sl.sh = sysf[(size_t)2 * npx + o];
+    sl.sv = sysf[(size_t)3 * npx + o];
+    sl.dur = duf[drow1 * h];
+  };
   auto next_row = [&](int r) { return (r + 1 == w) ? 0 : r + 1; };
-  float own = duf[0];        // du of pixel (j, t - j) before the sweep: "right" of the previous step
-  float res_prev = 0.0f;     // this lane's result of the previous step (its left neighbour, updated)
-  float sh_prev = 0.0f, sv_prev = 0.0f;
-  int row = 0;
-  for (int t = 0; t <= (w - 1) + (h - 1); ++t) {
-    const int i = t - j;
-    const int o = row * h, o1 = next_row(row) * h;
-    const float a11 = sysf[o], b1 = sysf[(size_t)npx + o], sh = sysf[(size_t)2 * npx + o], sv = sysf[(size_t)3 * npx + o];
-    const float right = duf[o1];                  // (j, i+1), old
-    const float bottom = wave_from_next(right);   // lane j+1 at column i-1: its right is (j+1, i), old
-    const float top = wave_from_prev(res_prev);   // (j-1, i), updated one step ago
-    const float vt = wave_from_prev(sv_prev);     // smooth_vert(j-1, i)
-    float sigma = 0.0f, sum = 0.0f;
-    if (has_top) { sigma -= vt * top; sum += vt; }
-    if (i > 0) { sigma -= sh_prev * res_prev; sum += sh_prev; }
-    if (has_bot) { sigma -= sv * bottom; sum += sv; }
-    if (i < w - 1) { sigma -= sh * right; sum += sh; }
-    const float A11 = a11 + sum;
-    const float B1 = b1 - sigma;
-    const float res = (1.0f - omega) * own + omega * (B1 / A11);
-    if (row_ok && i >= 0 && i < w) duf[o] = res;
-    res_prev = res;
-    sh_prev = sh;
-    sv_prev = sv;
-    own = right;
-    row = next_row(row);
+  int lrow = 0;
+#pragma unroll
+  for (int q = 0; q < PD; ++q) {
+    load_slot(ring[q], lrow, next_row(lrow));
+    lrow = next_row(lrow);
+  }
+  ring[RS - 1].dur = duf[0];  // "right" of step -1 = own of step 0
+  int srow = (w - ((2 * (NS - 1)) % w)) % w;  // diag row of the pixel the last sweep finishes at step 0
+  if constexpr (BLOCK) {
+    // mailbox for step 0: nothing has been computed yet, but sweep 0's "bottom" of lane 63 is the next wavefront's
+    // lane-0 right value of step 0, which is loaded
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) mail_bot[1][wave][q] = 0.0f;
+      mail_bot[1][wave][0] = ring[0].dur;
+    }
+    if (lane == 63) {
+#pragma unroll
+      for (int q = 0; q < NS + 1; ++q) mail_top[1][wave][q] = 0.0f;
+    }
+    __syncthreads();
+  }
+  const int tend = (w - 1) + (h - 1) + 2 * (NS - 1);
+  for (int t0 = 0; t0 <= tend; t0 += RS) {
+#pragma unroll
+    for (int u = 0; u < RS; ++u) {
+      const int t = t0 + u;
+      load_slot(ring[(u + PD) % RS], lrow, next_row(lrow));
+      lrow = next_row(lrow);
+      float top_sv = 0.0f, top_u[NS], bot_u[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) top_u[s] = bot_u[s] = 0.0f;
+      if constexpr (BLOCK) {
+        const int rd = (t + 1) & 1;  // written at the end of step t-1
+        if (first_lane) {
+          top_sv = mail_top[rd][wave - 1][NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) top_u[s] = mail_top[rd][wave - 1][s];
+        }
+        if (last_lane) {
+#pragma unroll
+          for (int s = 0; s < NS; ++s) bot_u[s] = mail_bot[rd][wave + 1][s];
+        }
+      }
+      {
+        DeSlot& c = ring[u];
+        const DeSlot& p = ring[(u + RS - 1) % RS];
+        c.hl = p.sh;                   // smooth_horiz(j, i0 - 1): used for i0 > 0 only
+        c.vt = wave_from_prev(p.sv);   // smooth_vert(j - 1, i0): lane j-1 was at column i0 one step ago
+        if (BLOCK && first_lane) c.vt = top_sv;
+      }
+      float nu[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int i = t - j - 2 * s;
+        const DeSlot& c = ring[(u - 2 * s + 2 * RS) % RS];
+        float own, right, bottom;
+        if (s == 0) {
+          const DeSlot& p = ring[(u + RS - 1) % RS];
+          own = p.dur;
+          right = c.dur;
+          bottom = wave_from_next(c.dur);  // lane j+1 is at column i-1: its right is (j+1, i)
+        } else {
+          own = ru2[s - 1];
+          right = ru[s - 1];
+          bottom = wave_from_next(ru[s - 1]);
+        }
+        if (BLOCK && last_lane) bottom = bot_u[s];
+        float top = wave_from_prev(ru[s]);
+        if (BLOCK && first_lane) top = top_u[s];
+        const float left = ru[s];
+        float sigma = 0.0f, sum = 0.0f;                                  // solver.c:436-456
+        if (has_top) { sigma -= c.vt * top; sum += c.vt; }
+        if (i > 0) { sigma -= c.hl * left; sum += c.hl; }
+        if (has_bot) { sigma -= c.sv * bottom; sum += c.sv; }
+        if (i < w - 1) { sigma -= c.sh * right; sum += c.sh; }
+        const float A11 = c.a11 + sum;
+        const float B1 = c.b1 - sigma;
+        nu[s] = (1.0f - omega) * own + omega * (B1 / A11);
+      }
+      {
+        const int i = t - j - 2 * (NS - 1);
+        if (row_ok && i >= 0 && i < w) duf[srow * h] = nu[NS - 1];
+        srow = next_row(srow);
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        ru2[s] = ru[s];
+        ru[s] = nu[s];
+      }
+      if constexpr (BLOCK) {  // publish for step t+1
+        const int wr = t & 1;
+        if (lane == 63) {
+#pragma unroll
+          for (int s = 0; s < NS; ++s) mail_top[wr][wave][s] = ru[s];
+          mail_top[wr][wave][NS] = ring[u].sv;  // slot of step t: the next step's top weight
+        }
+        if (lane == 0) {
+          // bottom of sweep s at step t+1: sweep 0 -> this lane's right value of step t+1; sweep s > 0 -> its
+          // sweep s-1 result of step t
+          mail_bot[wr][wave][0] = ring[(u + 1) % RS].dur;
+#pragma unroll
+          for (int s = 1; s < NS; ++s) mail_bot[wr][wave][s] = ru[s - 1];
+        }
+        // only the LDS mailboxes cross wavefronts: drain the LDS counter, not the loads requested PD steps ahead
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
   }
 }
 
@@ -211,14 +410,33 @@ __global__ void de_sor_serial_kernel(const DeSorArgs a) {
 
 hipError_t launch_de_sor(const DeSorArgs& a, hipStream_t s) {
   const int h = a.t.h;
-  if (h <= 64 && a.t.w >= 2) {
-    const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
-    const int G = 64 / R;
-    const int waves = (a.t.nframes + G - 1) / G;
-    for (int it = 0; it < a.iterations; ++it)
-      hipLaunchKernelGGL(de_sor_sweep_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, a, R);
-  } else {
+  constexpr int PD = 3;
+  if (a.t.w < 2 || h > 1024) {
     hipLaunchKernelGGL(de_sor_serial_kernel, dim3((a.t.nframes + 63) / 64), dim3(64), 0, s, a);
+    return hipGetLastError();
+  }
+  const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
+  const int waves = (a.t.nframes + 64 / R - 1) / (64 / R);
+  const int threads = ((h + 63) / 64) * 64;
+  for (int left = a.iterations; left > 0;) {   // at most four sweeps share a pass (three above 64 rows)
+    const int ns = h <= 64 ? (left < 4 ? left : 4) : (left < 3 ? left : 3);
+    if (h <= 64) {
+      const dim3 g((waves + 3) / 4), b(256);
+      switch (ns) {
+        case 1: hipLaunchKernelGGL((de_sor_kernel<1, PD, 0>), g, b, 0, s, a, R); break;
+        case 2: hipLaunchKernelGGL((de_sor_kernel<2, PD, 0>), g, b, 0, s, a, R); break;
+        case 3: hipLaunchKernelGGL((de_sor_kernel<3, PD, 0>), g, b, 0, s, a, R); break;
+        default: hipLaunchKernelGGL((de_sor_kernel<4, PD, 0>), g, b, 0, s, a, R); break;
+      }
+    } else {
+      const dim3 g(a.t.nframes), b(threads);
+      switch (ns) {
+        case 1: hipLaunchKernelGGL((de_sor_kernel<1, PD, 1024>), g, b, 0, s, a, 64); break;
+        case 2: hipLaunchKernelGGL((de_sor_kernel<2, PD, 1024>), g, b, 0, s, a, 64); break;
+        default: hipLaunchKernelGGL((de_sor_kernel<3, PD, 1024>), g, b, 0, s, a, 64); break;
+      }
+    }
+    left -= ns;
   }
   return hipGetLastError();
 }
@@ -236,7 +454,7 @@ __global__ __launch_bounds__(256) void de_update_kernel(TvGeom t, const float* w
   const int y = i / t.w, x = i - y * t.w;
   const float v = wx[gi] + du[(size_t)frame * npx + diag_index(x, y, t.w, t.h)];
   const float r = camlr == 0 ? (v < 0.0f ? v : 0.0f) : (v > 0.0f ? v : 0.0f);
-  uu[gi] = r;
+  if (uu) uu[gi] = r;
   if (out) out[gi] = r;
 }
 

@@ -399,7 +399,7 @@ __device__ __forceinline__ float gray8_abs_sum(const f2 (&x)[8]) {
   return gray8_combine(cx, cy);
 }
 
-template <int COST>
+template <int COST, bool STEREO>
 __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs a) {
   constexpr int LPP = 4, Q = 16, R = 8;
   const int costfct = COST >= 0 ? COST : a.costfct;
@@ -473,18 +473,24 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
       pyy[r] = Ty[r] * Ty[r];
     }
     float H00 = gray8_sum(pxx);
-    const float H01 = gray8_sum(pxy);
-    float H11 = gray8_sum(pyy);
-    if (H00 * H11 - H01 * H01 == 0.0f) {
-      H00 = (float)((double)H00 + 1e-10);
-      H11 = (float)((double)H11 + 1e-10);
-    }
-    l00 = H00; l10 = H01; l11 = H11;
-    if (!(l00 <= 0.0f)) {
-      l00 = sqrtf(l00);
-      l10 = l10 / l00;
-      const float x = l11 - l10 * l10;
-      if (!(x <= 0.0f)) l11 = sqrtf(x);
+    if constexpr (STEREO) {  // 1x1 Hessian of the horizontal displacement (patch.cpp:83-87)
+      if (H00 == 0.0f) H00 = (float)((double)H00 + 1e-10);
+      l00 = H00; l10 = 0.0f; l11 = 1.0f;
+      if (!(l00 <= 0.0f)) l00 = sqrtf(l00);
+    } else {
+      const float H01 = gray8_sum(pxy);
+      float H11 = gray8_sum(pyy);
+      if (H00 * H11 - H01 * H01 == 0.0f) {
+        H00 = (float)((double)H00 + 1e-10);
+        H11 = (float)((double)H11 + 1e-10);
+      }
+      l00 = H00; l10 = H01; l11 = H11;
+      if (!(l00 <= 0.0f)) {
+        l00 = sqrtf(l00);
+        l10 = l10 / l00;
+        const float x = l11 - l10 * l10;
+        if (!(x <= 0.0f)) l11 = sqrtf(x);
+      }
     }
   }
   // ---- InitializeFromCoarserOF (patchgrid.cpp:195-211)
@@ -492,9 +498,13 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
   if (a.flow_prev) {
     const int x = (int)floorf(rx / 2), y = (int)floorf(ry / 2);
     const int i = y * (g.w / 2) + x;
-    const float* fp = a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2) * 2;
-    pin0 = fp[2 * i] * 2;
-    pin1 = fp[2 * i + 1] * 2;
+    if constexpr (STEREO) {  // one channel
+      pin0 = (a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2))[i] * 2;
+    } else {
+      const float* fp = a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2) * 2;
+      pin0 = fp[2 * i] * 2;
+      pin1 = fp[2 * i + 1] * 2;
+    }
   }
   // ---- OptimizeIter (patch.cpp:159-212)
   // Register budget: the residual vector lives only inside one evaluation.  What the next Gauss-Newton step
@@ -605,12 +615,19 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
     cnt++;
     // delta_p = LLT(H).solve(b) (patch.cpp:184).  div_by(a, b, rcp_refined(b)) == a / b unless 0 < |a| < 2^-102
     // (ofdis_dev.h), which a sum of products of image values cannot be (DESIGN.md "Arithmetic contract")
-    const float y0 = div_by(b0, l00, r00);
-    const float y1 = div_by(b1 - l10 * y0, l11, r11);
-    dp1 = div_by(y1, l11, r11);
-    dp0 = div_by(y0 - l10 * dp1, l00, r00);
-    p0 -= dp0;
-    p1 -= dp1;
+    if constexpr (STEREO) {  // patch.cpp:180-193: 1x1 system, then the disparity sign constraint of the camera side
+      dp0 = (b0 / l00) / l00;
+      dp1 = 0.0f;
+      p0 -= dp0;
+      p0 = a.camlr == 0 ? ((0.0f < p0) ? 0.0f : p0) : ((p0 < 0.0f) ? 0.0f : p0);  // std::min / std::max (p, 0)
+    } else {
+      const float y0 = div_by(b0, l00, r00);
+      const float y1 = div_by(b1 - l10 * y0, l11, r11);
+      dp1 = div_by(y1, l11, r11);
+      dp0 = div_by(y0 - l10 * dp1, l00, r00);
+      p0 -= dp0;
+      p1 -= dp1;
+    }
     ptx = rx + p0;
     pty = ry + p1;
     const float ex = stx - ptx, ey = sty - pty;
@@ -1209,7 +1226,7 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s, const ofdis_tu
   const int M = (a.g.novals + 63) / 64;
   const bool full = a.g.novals == 64 * M;
   const ofdis_tuning tn = tnp ? *tnp : tuning();
-  const bool gray8 = a.g.noc == 1 && a.g.P == 8 && !a.stereo && tn.gray8;
+  const bool gray8 = a.g.noc == 1 && a.g.P == 8 && tn.gray8;
   // RGB 12x12 (operating points 3 and 4, BASELINE configs[3]): 432 entries, 6 full groups of 64 + 48.  ofdis_tuning::rgb12_lpp = 32:
   // two patches per wavefront (the scalar solve, predicates and every reduction instruction shared by two patches:
   // 929 -> 705 instructions per patch and iteration, 82 -> 127 VGPRs).  Measured on configs[3] the same 19.6 +- 0.4 ms per
@@ -1228,10 +1245,12 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s, const ofdis_tu
   const int blocks_per_frame = (wpf + wpb - 1) / wpb;
   const int grid = ((a.nframes + 7) / 8) * 8 * blocks_per_frame;
   const dim3 gd(grid), bd(wpb * 64);
-  if (M <= 1 && gray8 && a.costfct == 0)
-    hipLaunchKernelGGL((patch_optimize_gray8_kernel<0>), gd, bd, 0, s, a);
+  if (M <= 1 && gray8 && a.stereo)
+    hipLaunchKernelGGL((patch_optimize_gray8_kernel<-1, true>), gd, bd, 0, s, a);
+  else if (M <= 1 && gray8 && a.costfct == 0)
+    hipLaunchKernelGGL((patch_optimize_gray8_kernel<0, false>), gd, bd, 0, s, a);
   else if (M <= 1 && gray8)
-    hipLaunchKernelGGL((patch_optimize_gray8_kernel<-1>), gd, bd, 0, s, a);
+    hipLaunchKernelGGL((patch_optimize_gray8_kernel<-1, false>), gd, bd, 0, s, a);
   else if (M <= 1 && full && a.costfct == 0)
     hipLaunchKernelGGL((patch_optimize_kernel<1, 8, 64, 0>), gd, bd, 0, s, a);
   else if (M <= 1 && full)

@@ -175,8 +175,8 @@ struct DeSystemArgs {
   TvGeom t;
   const float* mask;   // row-major [B][h][w]
   const float* wx;     // row-major: the flow before the increment
-  const float* uu;     // row-major: clamped flow + increment of the previous fixed-point iteration
-  const float* du;     // diag
+  const float* du;     // diag: the increment of the previous fixed-point iterations
+  int clamp;           // uu = wx (< 0: before the first solve), min(wx + du, 0) (0: left camera), max(., 0) (1: right)
   const float* derivs; // row-major [B][8*noc][h][w]
   float quarter_alpha, half_delta_over3, half_gamma_over3;
   float* sys;          // [B][4][w*h] diag: a11, b1, smooth_horiz, smooth_vert

@@ -43,9 +43,16 @@ def test_stereo_patchgrid_levels(gpu, noc, opp):
         prev = rflow
 
 
-@pytest.mark.parametrize("noc,size", [(1, (640, 480)), (1, (1024, 436)), (3, (320, 240))])
-def test_stereo_varref_levels(gpu, noc, size):
-    p, pa, pb = _case(size[0], size[1], 91, noc, 2 if noc == 1 else 3, 1)
+@pytest.mark.parametrize("noc,size,opp,solverit", [(1, (640, 480), 2, 0), (1, (1024, 436), 2, 0), (3, (320, 240), 3, 0),
+                                                   (1, (333, 251), 3, 0), (1, (600, 300), 3, 5), (1, (1242, 375), 2, 5),
+                                                   (1, (640, 480), 2, 1), (1, (520, 1100), 3, 2)])
+def test_stereo_varref_levels(gpu, noc, size, opp, solverit):
+    """Levels of at most 64 rows (several frames per wavefront), taller ones (one workgroup per frame, the wavefronts
+    in lock step: operating point 3 ends at half resolution), and solver sweep counts on either side of what one pass
+    pipelines (4, or 3 above 64 rows)."""
+    p, pa, pb = _case(size[0], size[1], 91, noc, opp, 1)
+    if solverit:
+        p = p.copy(tv_solverit=solverit)
     R = _ref(noc)
     rng = np.random.default_rng(4)
     for l in range(p.sc_f, p.sc_l - 1, -1):

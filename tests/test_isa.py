@@ -96,7 +96,7 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     ("tv_fused_kernelILi3ELb1ELi0EE", 192, "tv_fused_kernel<3, true, 0>, throughput mapping: two wavefronts per SIMD"),
     ("tv_fused_kernelILi3ELb1ELi2EE", 168, "tv_fused_kernel<3, true, 2>, split mapping: 12 wavefronts of a workgroup on one CU"),
     ("tv_fused_xcu_kernelILi3ELb1EE", 128, "tv_fused_xcu_kernel<3, true>, cross-CU mapping: one wavefront per SIMD, four workgroups per CU at most"),
-    ("patch_optimize_gray8_kernelILi0EE", 128, "gray 8x8 patch kernel: four wavefronts per SIMD"),
+    ("patch_optimize_gray8_kernelILi0ELb0EE", 128, "gray 8x8 patch kernel: four wavefronts per SIMD"),
     ("patch_optimize_kernelILi7ELi64ELi432ELi1EE", 84, "RGB 12x12 patch kernel, L1 cost: six wavefronts per SIMD"),
     ("patch_optimize_rgb12x_kernelILi1EE", 168, "RGB 12x12 patch kernel of the exact contract (blocks for the taps, chains for the sums): three wavefronts per SIMD"),
     ("patch_optimize_rgb12_kernelILi1EE", 168, "RGB 12x12 patch kernel of the fused contract (3x3 pixel block per lane, Ty in LDS): three wavefronts per SIMD"),

@@ -160,8 +160,8 @@ def summarize(name, body, quiet=False):
 PROFILE_KERNELS = {
     "patch_optimize_rgb12_fused": ("ofdis_dis.fused.o", "ofdis::fused::patch_optimize_rgb12_kernel<1>(", 4),
     "patch_optimize_rgb12_exact": ("ofdis_dis.o", "ofdis::exact::patch_optimize_rgb12x_kernel<1>(", 4),
-    "patch_optimize_gray8_fused": ("ofdis_dis.fused.o", "ofdis::fused::patch_optimize_gray8_kernel<0>(", 16),
-    "patch_optimize_gray8_exact": ("ofdis_dis.o", "ofdis::exact::patch_optimize_gray8_kernel<0>(", 16),
+    "patch_optimize_gray8_fused": ("ofdis_dis.fused.o", "ofdis::fused::patch_optimize_gray8_kernel<0, false>(", 16),
+    "patch_optimize_gray8_exact": ("ofdis_dis.o", "ofdis::exact::patch_optimize_gray8_kernel<0, false>(", 16),
 }
 
 

@@ -20,7 +20,7 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 capi.check(capi.lib().ofdis_set_device(0))
 capi.set_tuning(contract=1 if contract == "fused" else 0)
-p = oppoint(2, W, H, noc=1, usetvref=True, verbosity=0)
+p = oppoint(int(os.environ.get("OPP", "2")), W, H, noc=1, verbosity=0)
 ia, ib = bench.synth_frames_range(0, min(n, 64), W, H, 1234, dev)
 reps = (n + ia.shape[0] - 1) // ia.shape[0]
 ia, ib = ia.repeat(reps, 1, 1)[:n].contiguous(), ib.repeat(reps, 1, 1)[:n].contiguous()
