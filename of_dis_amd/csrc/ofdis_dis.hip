@@ -673,13 +673,16 @@ __device__ __forceinline__ float row16_sum(float x) {  // all-reduce inside a DP
   return x;
 }
 
-template <int COST>
+// NOC = 1: the same mapping for gray 12 x 12 patches (operating points 3 and 4 of run_OF_INT / run_DE_INT): 9 entries per
+// lane, one 16-byte load per window row.  STEREO: the 1-D search of the depth mode (patch.cpp:83-87, 180-193).
+template <int COST, int NOC, bool STEREO>
 __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisArgs a) {
-  constexpr int Q = 4, NE = 27, NV = 432;  // patches per wavefront, entries per lane, entries per patch
+  constexpr int Q = 4, NE = 9 * NOC, NV = 144 * NOC;  // patches per wavefront, entries per lane, entries per patch
+  constexpr int RL = 3 * NOC;                         // floats per row of the lane's 3 x 3 pixel block
   // The template's y gradient lives in LDS, [entry / 4][thread] as 16-byte groups (a lane reads its own seven groups once
   // per evaluation, conflict-free): 27 registers less = 168 without scratch = three wavefronts per SIMD instead of two
   typedef float f4l __attribute__((ext_vector_type(4)));
-  __shared__ f4l tyl[7 * 256];
+  __shared__ f4l tyl[NOC == 3 ? 7 * 256 : 1];  // (gray: 9 registers, kept)
   const LevelGeom& g = a.g;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
     return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)frame * plane), 0, (int)(plane * sizeof(float)), 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t rsB = plane_rsrc(a.im_b);
-  const int row_bytes = tw * 12;
+  const int row_bytes = tw * 4 * NOC;
   auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
   const float rx = (float)(gx * g.steps + g.offw), ry = (float)(gy * g.steps + g.offh);
   const float inv_nv = 1.0f / (float)NV;
@@ -713,20 +716,26 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
   {
     const int px = (int)roundf(rx) + g.pad, py = (int)roundf(ry) + g.pad;
     const __amdgpu_buffer_rsrc_t rsA = plane_rsrc(a.im_a), rsAx = plane_rsrc(a.im_a_dx), rsAy = plane_rsrc(a.im_a_dy);
-    const int vbase = ((py - 6 + 3 * rg) * tw + px - 6 + 3 * cg) * 12;
+    const int vbase = ((py - 6 + 3 * rg) * tw + px - 6 + 3 * cg) * (4 * NOC);
     auto ld9 = [&](const __amdgpu_buffer_rsrc_t& rs, int rr, float* dst) {
-      const auto q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, vbase, rr * row_bytes, 0);
-      const auto q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + 16, rr * row_bytes, 0);
-      const unsigned q2 = __builtin_amdgcn_raw_buffer_load_b32(rs, vbase + 32, rr * row_bytes, 0);
-      const unsigned u0 = q0[0], u1 = q0[1], u2 = q0[2], u3 = q0[3], u4 = q1[0], u5 = q1[1], u6 = q1[2], u7 = q1[3];
-      dst[0] = asf(u0); dst[1] = asf(u1); dst[2] = asf(u2); dst[3] = asf(u3); dst[4] = asf(u4);
-      dst[5] = asf(u5); dst[6] = asf(u6); dst[7] = asf(u7); dst[8] = asf(q2);
+      if constexpr (NOC == 1) {
+        const auto q = __builtin_amdgcn_raw_buffer_load_b96(rs, vbase, rr * row_bytes, 0);
+        const unsigned u0 = q[0], u1 = q[1], u2 = q[2];
+        dst[0] = asf(u0); dst[1] = asf(u1); dst[2] = asf(u2);
+      } else {
+        const auto q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, vbase, rr * row_bytes, 0);
+        const auto q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + 16, rr * row_bytes, 0);
+        const unsigned q2 = __builtin_amdgcn_raw_buffer_load_b32(rs, vbase + 32, rr * row_bytes, 0);
+        const unsigned u0 = q0[0], u1 = q0[1], u2 = q0[2], u3 = q0[3], u4 = q1[0], u5 = q1[1], u6 = q1[2], u7 = q1[3];
+        dst[0] = asf(u0); dst[1] = asf(u1); dst[2] = asf(u2); dst[3] = asf(u3); dst[4] = asf(u4);
+        dst[5] = asf(u5); dst[6] = asf(u6); dst[7] = asf(u7); dst[8] = asf(q2);
+      }
     };
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) {
-      ld9(rsA, rr, T + 9 * rr);
-      ld9(rsAx, rr, Tx + 9 * rr);
-      ld9(rsAy, rr, Ty + 9 * rr);
+      ld9(rsA, rr, T + RL * rr);
+      ld9(rsAx, rr, Tx + RL * rr);
+      ld9(rsAy, rr, Ty + RL * rr);
     }
     if (a.patnorm > 0) {
       float c = T[0];
@@ -750,31 +759,43 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
       hyy += Ty[e] * Ty[e];
     }
     float H00 = row16_sum(hxx);
-    const float H01 = row16_sum(hxy);
-    float H11 = row16_sum(hyy);
-    if (H00 * H11 - H01 * H01 == 0.0f) {
-      H00 = (float)((double)H00 + 1e-10);
-      H11 = (float)((double)H11 + 1e-10);
-    }
-    l00 = H00; l10 = H01; l11 = H11;
-    if (!(l00 <= 0.0f)) {
-      l00 = sqrtf(l00);
-      l10 = l10 / l00;
-      const float x = l11 - l10 * l10;
-      if (!(x <= 0.0f)) l11 = sqrtf(x);
+    if constexpr (STEREO) {  // 1x1 Hessian of the horizontal displacement (patch.cpp:83-87)
+      if (H00 == 0.0f) H00 = (float)((double)H00 + 1e-10);
+      l00 = H00; l10 = 0.0f; l11 = 1.0f;
+      if (!(l00 <= 0.0f)) l00 = sqrtf(l00);
+    } else {
+      const float H01 = row16_sum(hxy);
+      float H11 = row16_sum(hyy);
+      if (H00 * H11 - H01 * H01 == 0.0f) {
+        H00 = (float)((double)H00 + 1e-10);
+        H11 = (float)((double)H11 + 1e-10);
+      }
+      l00 = H00; l10 = H01; l11 = H11;
+      if (!(l00 <= 0.0f)) {
+        l00 = sqrtf(l00);
+        l10 = l10 / l00;
+        const float x = l11 - l10 * l10;
+        if (!(x <= 0.0f)) l11 = sqrtf(x);
+      }
     }
   }
+  if constexpr (NOC == 3) {
 #pragma unroll
-  for (int q = 0; q < 7; ++q)
-    tyl[q * 256 + threadIdx.x] = f4l{Ty[4 * q], Ty[4 * q + 1], Ty[4 * q + 2], q < 6 ? Ty[4 * q + 3] : 0.0f};
+    for (int q = 0; q < 7; ++q)
+      tyl[q * 256 + threadIdx.x] = f4l{Ty[4 * q], Ty[4 * q + 1], Ty[4 * q + 2], q < 6 ? Ty[4 * q + 3] : 0.0f};
+  }
   // ---- InitializeFromCoarserOF (patchgrid.cpp:195-211)
   float pin0 = 0.0f, pin1 = 0.0f;
   if (a.flow_prev) {
     const int x = (int)floorf(rx / 2), y = (int)floorf(ry / 2);
     const int i = y * (g.w / 2) + x;
-    const float* fp = a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2) * 2;
-    pin0 = fp[2 * i] * 2;
-    pin1 = fp[2 * i + 1] * 2;
+    if constexpr (STEREO) {  // one channel
+      pin0 = (a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2))[i] * 2;
+    } else {
+      const float* fp = a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2) * 2;
+      pin0 = fp[2 * i] * 2;
+      pin1 = fp[2 * i + 1] * 2;
+    }
   }
   // ---- OptimizeIter (patch.cpp:159-212); state uniform per patch (16 lanes)
   const float r00 = rcp_refined(l00), r11 = rcp_refined(l11);
@@ -788,33 +809,35 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
   bool converged = false;
   // this lane's 3 rows of 9 weights within the patch's 432 (entry (row, col, c) at (row * 12 + col) * 3 + c)
   // (internal layout, ofdis_dev.h: pweight_row -- patch rows are nopw * 36 floats apart)
-  float* const pwout = a.pweight + (size_t)frame * g.nop * NV + pweight_row(g, gx, gy, 3 * rg) + 9 * cg;
-  const int pwstride = g.nopw * 36;
+  float* const pwout = a.pweight + (size_t)frame * g.nop * NV + pweight_row(g, gx, gy, 3 * rg) + RL * cg;
+  const int pwstride = g.nopw * 12 * NOC;
   // A patch whose weights the densification reads unshifted (ofdis_dev.h: patch_weights_unshifted -- all but the patches on
   // the left / right / top border) stores ONE float per pixel, the denominator max(2,|r_0|) + max(2,|r_1|) + max(2,|r_2|) of
   // the pixel's weight (patchgrid.cpp:256-259, the same three operations in the same order), instead of its 432 |r|: the lane
   // holds the three channels of each of its nine pixels.  108 instead of 324 bytes per lane.
-  const bool compact = a.pixw != nullptr && patch_weights_unshifted(g, gx, gy);
-  float* const pxout = a.pixw ? a.pixw + (size_t)frame * g.nop * 144 + pixw_row(g, gx, gy, 3 * rg) + 3 * cg : nullptr;
+  const bool compact = NOC == 3 && a.pixw != nullptr && patch_weights_unshifted(g, gx, gy);
+  float* const pxout = (NOC == 3 && a.pixw) ? a.pixw + (size_t)frame * g.nop * 144 + pixw_row(g, gx, gy, 3 * rg) + 3 * cg : nullptr;
   const int pxstride = g.nopw * 12;
   auto store_pw = [&](const float (&v)[NE], bool zero) {
-    if (compact) {
+    if constexpr (NOC == 3) {
+      if (compact) {
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr)
+        for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-        for (int xx = 0; xx < 3; ++xx) {
-          const int e = rr * 9 + xx * 3;
-          float sden = fmaxf(2.0f, fabsf(v[e]));
-          sden += fmaxf(2.0f, fabsf(v[e + 1]));
-          sden += fmaxf(2.0f, fabsf(v[e + 2]));
-          pxout[rr * pxstride + xx] = zero ? 6.0f : sden;  // (never evaluated: |r| = 0 three times)
-        }
-      return;
+          for (int xx = 0; xx < 3; ++xx) {
+            const int e = rr * 9 + xx * 3;
+            float sden = fmaxf(2.0f, fabsf(v[e]));
+            sden += fmaxf(2.0f, fabsf(v[e + 1]));
+            sden += fmaxf(2.0f, fabsf(v[e + 2]));
+            pxout[rr * pxstride + xx] = zero ? 6.0f : sden;  // (never evaluated: |r| = 0 three times)
+          }
+        return;
+      }
     }
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-      for (int q = 0; q < 9; ++q) pwout[rr * pwstride + q] = zero ? 0.0f : fabsf(v[rr * 9 + q]);
+      for (int q = 0; q < RL; ++q) pwout[rr * pwstride + q] = zero ? 0.0f : fabsf(v[rr * RL + q]);
   };
 
   auto compute_err = [&](bool stop) {  // patch.cpp:264-284, 335-402, 223-262
@@ -826,12 +849,12 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
     pos1 += g.pad;
     // window: rows pos1 - 7 + 3 rg + j, j = 0..3; pixels pos0 - 7 + 3 cg + i, i = 0..3 (12 floats per row).  Entry (rr, xx, c)
     // takes a = W[rr+1][xx+1], b = W[rr+1][xx], c = W[rr][xx+1], d = W[rr][xx] (patch.cpp:335-402)
-    const int voff = ((pos1 - 7 + 3 * rg) * tw + pos0 - 7 + 3 * cg) * 12;
-    float W[4][12];
+    const int voff = ((pos1 - 7 + 3 * rg) * tw + pos0 - 7 + 3 * cg) * (4 * NOC);
+    float W[4][4 * NOC];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NOC; ++q) {
         const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 16 * q, j * row_bytes, 0);
         const unsigned u0 = t[0], u1 = t[1], u2 = t[2], u3 = t[3];
         W[j][4 * q] = asf(u0); W[j][4 * q + 1] = asf(u1); W[j][4 * q + 2] = asf(u2); W[j][4 * q + 3] = asf(u3);
@@ -842,11 +865,11 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {  // q = xx * 3 + c: the left neighbour pixel is 3 floats back
-        const int e = rr * 9 + q;
-        float v = we0 * W[rr + 1][q + 3] - T[e];
+      for (int q = 0; q < RL; ++q) {  // q = xx * NOC + c: the left neighbour pixel is NOC floats back
+        const int e = rr * RL + q;
+        float v = we0 * W[rr + 1][q + NOC] - T[e];
         v = we1 * W[rr + 1][q] + v;
-        v = we2 * W[rr][q + 3] + v;
+        v = we2 * W[rr][q + NOC] + v;
         v = we3 * W[rr][q] + v;
         d[e] = v;  // interpolated value minus the (mean-normalised) template
         se += v;
@@ -858,21 +881,33 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
     } else {              // T was not normalised: d = v - T already
     }
     float g0 = 0.0f, g1 = 0.0f, sa = 0.0f;
+    if constexpr (NOC == 3) {
 #pragma unroll
-    for (int q = 0; q < 7; ++q) {
-      const f4l ty = tyl[q * 256 + threadIdx.x];
-      const float tyq[4] = {ty.x, ty.y, ty.z, ty.w};
+      for (int q = 0; q < 7; ++q) {
+        const f4l ty = tyl[q * 256 + threadIdx.x];
+        const float tyq[4] = {ty.x, ty.y, ty.z, ty.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int e = 4 * q + i;
-        if (e < NE) {
-          float r = d[e];
-          if (COST == 1) r = copysignf(__builtin_amdgcn_sqrtf(fabsf(r)), r);  // L1 (patch.cpp:238-246)
-          d[e] = r;
-          g0 += Tx[e] * r;
-          g1 += tyq[i] * r;
-          sa += fabsf(r);
+        for (int i = 0; i < 4; ++i) {
+          const int e = 4 * q + i;
+          if (e < NE) {
+            float r = d[e];
+            if (COST == 1) r = copysignf(__builtin_amdgcn_sqrtf(fabsf(r)), r);  // L1 (patch.cpp:238-246)
+            d[e] = r;
+            g0 += Tx[e] * r;
+            g1 += tyq[i] * r;
+            sa += fabsf(r);
+          }
         }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        float r = d[e];
+        if (COST == 1) r = copysignf(__builtin_amdgcn_sqrtf(fabsf(r)), r);
+        d[e] = r;
+        g0 += Tx[e] * r;
+        g1 += Ty[e] * r;
+        sa += fabsf(r);
       }
     }
     b0 = row16_sum(g0);
@@ -900,12 +935,19 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
   }
   while (!converged) {
     cnt++;
-    const float y0 = div_by(b0, l00, r00);
-    const float y1 = div_by(b1 - l10 * y0, l11, r11);
-    dp1 = div_by(y1, l11, r11);
-    dp0 = div_by(y0 - l10 * dp1, l00, r00);
-    p0 -= dp0;
-    p1 -= dp1;
+    if constexpr (STEREO) {  // patch.cpp:180-193: 1x1 system, then the disparity sign constraint of the camera side
+      dp0 = (b0 / l00) / l00;
+      dp1 = 0.0f;
+      p0 -= dp0;
+      p0 = a.camlr == 0 ? ((0.0f < p0) ? 0.0f : p0) : ((p0 < 0.0f) ? 0.0f : p0);  // std::min / std::max (p, 0)
+    } else {
+      const float y0 = div_by(b0, l00, r00);
+      const float y1 = div_by(b1 - l10 * y0, l11, r11);
+      dp1 = div_by(y1, l11, r11);
+      dp0 = div_by(y0 - l10 * dp1, l00, r00);
+      p0 -= dp0;
+      p1 -= dp1;
+    }
     ptx = rx + p0;
     pty = ry + p1;
     const float ex = stx - ptx, ey = sty - pty;
@@ -938,9 +980,14 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
 // The interpolated values go from A to B through LDS once per evaluation (27 four-byte writes and reads per lane, inside
 // the wavefront: LDS operations of a wavefront execute in order, no barrier).  About 150 instead of 515 instructions per
 // patch and iteration.
-template <int COST>
+// NOC = 1: gray 12 x 12 (144 entries: chain 0 has three entries k = pl, pl + 64, pl + 128, chains 1-3 two).  STEREO: the
+// 1-D search of the depth mode.
+template <int COST, int NOC, bool STEREO>
 __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const DisArgs a) {
-  constexpr int Q = 4, NV = 432;
+  constexpr int Q = 4, NV = 144 * NOC;
+  constexpr int RL = 12 * NOC;         // floats per patch row
+  constexpr int MC = (NV + 63) / 64;   // slots per chain (7 / 3); NB = 4 chains
+  constexpr int NB = 4 * MC;
   __shared__ float xl[4 * Q * NV];  // [wavefront][patch][entry]: the A -> B hand-over
   const LevelGeom& g = a.g;
   const int lane = threadIdx.x & 63;
@@ -964,53 +1011,58 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const Dis
     return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)frame * plane), 0, (int)(plane * sizeof(float)), 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t rsB = plane_rsrc(a.im_b);
-  const int row_bytes = tw * 12;
+  const int row_bytes = tw * 4 * NOC;
   auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
   const float rx = (float)(gx * g.steps + g.offw), ry = (float)(gy * g.steps + g.offh);
   const float fnv = (float)NV, rcp_nv = rcp_refined(fnv);
   auto div_nv = [&](float x) { return div_by(x, fnv, rcp_nv); };  // == x / 432, correctly rounded (ofdis_dev.h)
-  // layout B: entry i = c * 7 + m of this lane is k = 16 c + pl + 64 m; chain 3 has six entries (k < 432)
+  // layout B: entry i = c * MC + m of this lane is k = 16 c + pl + 64 m; RGB: chain 3 has six entries (k < 432)
   auto kB = [&](int c, int m) { return 16 * c + pl + 64 * m; };
+  auto vB = [](int c, int m) { return 16 * c + 64 * m + 15 < NV; };  // (NV is a multiple of 16: the same for every lane)
   // sum of one value per entry in the documented order (see above): the four chain sums (accumulated by the caller, m
   // ascending, starting FROM the first entry), each reduced over the patch's 16 lanes, then distance 16 and 32
   auto finish4 = [&](const float (&sc)[4]) {
     const float r0 = row16_sum(sc[0]), r1 = row16_sum(sc[1]), r2 = row16_sum(sc[2]), r3 = row16_sum(sc[3]);
     return (r0 + r1) + (r2 + r3);
   };
-  auto sumB = [&](const float (&x)[28]) {
+  auto sumB = [&](const float (&x)[NB]) {
     float sc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      float t = x[c * 7];
+      float t = x[c * MC];
 #pragma unroll
-      for (int m = 1; m < (c == 3 ? 6 : 7); ++m) t = t + x[c * 7 + m];
+      for (int m = 1; m < MC; ++m)
+        if (vB(c, m)) t = t + x[c * MC + m];
       sc[c] = t;
     }
     return finish4(sc);
   };
 
   // ---- InitializePatch (patch.cpp:287-332) in layout B
-  float T[28], Tx[28], Ty[28];
+  float T[NB], Tx[NB], Ty[NB];
   {
     const int px = (int)roundf(rx) + g.pad, py = (int)roundf(ry) + g.pad;
     const float* __restrict__ imA = a.im_a + (size_t)frame * plane;
     const float* __restrict__ imAx = a.im_a_dx + (size_t)frame * plane;
     const float* __restrict__ imAy = a.im_a_dy + (size_t)frame * plane;
-    const int base = ((py - 6) * tw + px - 6) * 3;
+    const int base = ((py - 6) * tw + px - 6) * NOC;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < 7; ++m) {
-        const int i = c * 7 + m;
-        if (c == 3 && m == 6) { T[i] = Tx[i] = Ty[i] = 0.0f; continue; }
-        const int k = kB(c, m), row = k / 36, col = k - row * 36;
-        const unsigned o = (unsigned)(base + row * tw * 3 + col);
+      for (int m = 0; m < MC; ++m) {
+        const int i = c * MC + m;
+        if (!vB(c, m)) { T[i] = Tx[i] = Ty[i] = 0.0f; continue; }
+        const int k = kB(c, m), row = k / RL, col = k - row * RL;
+        const unsigned o = (unsigned)(base + row * tw * NOC + col);
         T[i] = imA[o]; Tx[i] = imAx[o]; Ty[i] = imAy[o];
       }
     if (a.patnorm > 0) {
       const float mean = div_nv(sumB(T));
 #pragma unroll
-      for (int i = 0; i < 27; ++i) T[i] -= mean;
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < MC; ++m)
+          if (vB(c, m)) T[c * MC + m] -= mean;
     }
   }
   // ---- ComputeHessian + Cholesky factor (patch.cpp:71-88, Eigen LLT as in oracle/eigen_shim)
@@ -1020,26 +1072,33 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const Dis
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < (c == 3 ? 6 : 7); ++m) {
-        const int i = c * 7 + m;
+      for (int m = 0; m < MC; ++m) {
+        if (!vB(c, m)) continue;
+        const int i = c * MC + m;
         const float xx = Tx[i] * Tx[i], xy = Tx[i] * Ty[i], yy = Ty[i] * Ty[i];
         sxx[c] = m ? sxx[c] + xx : xx;
         sxy[c] = m ? sxy[c] + xy : xy;
         syy[c] = m ? syy[c] + yy : yy;
       }
     float H00 = finish4(sxx);
-    const float H01 = finish4(sxy);
-    float H11 = finish4(syy);
-    if (H00 * H11 - H01 * H01 == 0.0f) {
-      H00 = (float)((double)H00 + 1e-10);
-      H11 = (float)((double)H11 + 1e-10);
-    }
-    l00 = H00; l10 = H01; l11 = H11;
-    if (!(l00 <= 0.0f)) {
-      l00 = sqrtf(l00);
-      l10 = l10 / l00;
-      const float x = l11 - l10 * l10;
-      if (!(x <= 0.0f)) l11 = sqrtf(x);
+    if constexpr (STEREO) {  // 1x1 Hessian of the horizontal displacement (patch.cpp:83-87)
+      if (H00 == 0.0f) H00 = (float)((double)H00 + 1e-10);
+      l00 = H00; l10 = 0.0f; l11 = 1.0f;
+      if (!(l00 <= 0.0f)) l00 = sqrtf(l00);
+    } else {
+      const float H01 = finish4(sxy);
+      float H11 = finish4(syy);
+      if (H00 * H11 - H01 * H01 == 0.0f) {
+        H00 = (float)((double)H00 + 1e-10);
+        H11 = (float)((double)H11 + 1e-10);
+      }
+      l00 = H00; l10 = H01; l11 = H11;
+      if (!(l00 <= 0.0f)) {
+        l00 = sqrtf(l00);
+        l10 = l10 / l00;
+        const float x = l11 - l10 * l10;
+        if (!(x <= 0.0f)) l11 = sqrtf(x);
+      }
     }
   }
   // ---- InitializeFromCoarserOF (patchgrid.cpp:195-211)
@@ -1047,9 +1106,13 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const Dis
   if (a.flow_prev) {
     const int x = (int)floorf(rx / 2), y = (int)floorf(ry / 2);
     const int i = y * (g.w / 2) + x;
-    const float* fp = a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2) * 2;
-    pin0 = fp[2 * i] * 2;
-    pin1 = fp[2 * i + 1] * 2;
+    if constexpr (STEREO) {  // one channel
+      pin0 = (a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2))[i] * 2;
+    } else {
+      const float* fp = a.flow_prev + (size_t)frame * (size_t)(g.w / 2) * (g.h / 2) * 2;
+      pin0 = fp[2 * i] * 2;
+      pin1 = fp[2 * i + 1] * 2;
+    }
   }
   // ---- OptimizeIter (patch.cpp:159-212)
   const float r00 = rcp_refined(l00), r11 = rcp_refined(l11);
@@ -1065,36 +1128,40 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const Dis
   // (see patch_optimize_rgb12_kernel: one float per pixel for the patches the densification reads unshifted.  The residual
   // lives in layout B here, a pixel's three channels in three lanes: |r| goes through the hand-over vector once more and is
   // read back by pixel blocks, layout A)
-  const bool compact = a.pixw != nullptr && patch_weights_unshifted(g, gx, gy);
-  float* const pxout = a.pixw ? a.pixw + (size_t)frame * g.nop * 144 + pixw_row(g, gx, gy, 3 * rg) + 3 * cg : nullptr;
+  const bool compact = NOC == 3 && a.pixw != nullptr && patch_weights_unshifted(g, gx, gy);
+  float* const pxout = (NOC == 3 && a.pixw) ? a.pixw + (size_t)frame * g.nop * 144 + pixw_row(g, gx, gy, 3 * rg) + 3 * cg : nullptr;
   const int pxstride = g.nopw * 12;
-  auto store_pw = [&](const float (&v)[28], bool zero) {  // |residual| of this lane's entries (layout B)
-    if (compact) {
-      __builtin_amdgcn_wave_barrier();
+  auto store_pw = [&](const float (&v)[NB], bool zero) {  // |residual| of this lane's entries (layout B)
+    if constexpr (NOC == 3) {
+      if (compact) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int m = 0; m < (c == 3 ? 6 : 7); ++m) xp[kB(c, m)] = zero ? 0.0f : fabsf(v[c * 7 + m]);
-      __builtin_amdgcn_wave_barrier();
+          for (int m = 0; m < MC; ++m)
+            if (vB(c, m)) xp[kB(c, m)] = zero ? 0.0f : fabsf(v[c * MC + m]);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr)
+        for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-        for (int xx = 0; xx < 3; ++xx) {
-          const float* e = xp + (3 * rg + rr) * 36 + 9 * cg + 3 * xx;
-          float sden = fmaxf(2.0f, e[0]);
-          sden += fmaxf(2.0f, e[1]);
-          sden += fmaxf(2.0f, e[2]);
-          pxout[rr * pxstride + xx] = sden;
-        }
-      __builtin_amdgcn_wave_barrier();  // (a later evaluation of the wavefront's other patches does not touch this vector)
-      return;
+          for (int xx = 0; xx < 3; ++xx) {
+            const float* e = xp + (3 * rg + rr) * 36 + 9 * cg + 3 * xx;
+            float sden = fmaxf(2.0f, e[0]);
+            sden += fmaxf(2.0f, e[1]);
+            sden += fmaxf(2.0f, e[2]);
+            pxout[rr * pxstride + xx] = sden;
+          }
+        __builtin_amdgcn_wave_barrier();  // (a later evaluation of the wavefront's other patches does not touch this vector)
+        return;
+      }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < (c == 3 ? 6 : 7); ++m) {
-        const int k = kB(c, m), row = k / 36;  // (36 floats per patch row: a compile-time divisor)
-        pwf[pweight_row(g, gx, gy, row) + (k - row * 36)] = zero ? 0.0f : fabsf(v[c * 7 + m]);
+      for (int m = 0; m < MC; ++m) {
+        if (!vB(c, m)) continue;
+        const int k = kB(c, m), row = k / RL;  // (RL floats per patch row: a compile-time divisor)
+        pwf[pweight_row(g, gx, gy, row) + (k - row * RL)] = zero ? 0.0f : fabsf(v[c * MC + m]);
       }
   };
 
@@ -1106,12 +1173,12 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const Dis
     pos0 += g.pad;
     pos1 += g.pad;
     {  // layout A: the lane's 3x3 pixel block from its 4x4 pixel window, handed over entry by entry
-      const int voff = ((pos1 - 7 + 3 * rg) * tw + pos0 - 7 + 3 * cg) * 12;
-      float W[4][12];
+      const int voff = ((pos1 - 7 + 3 * rg) * tw + pos0 - 7 + 3 * cg) * (4 * NOC);
+      float W[4][4 * NOC];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NOC; ++q) {
           const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 16 * q, j * row_bytes, 0);
           const unsigned u0 = t[0], u1 = t[1], u2 = t[2], u3 = t[3];
           W[j][4 * q] = asf(u0); W[j][4 * q + 1] = asf(u1); W[j][4 * q + 2] = asf(u2); W[j][4 * q + 3] = asf(u3);
@@ -1121,27 +1188,31 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const Dis
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-        for (int q = 0; q < 9; ++q)
-          xp[(3 * rg + rr) * 36 + 9 * cg + q] =
-              we0 * W[rr + 1][q + 3] + we1 * W[rr + 1][q] + we2 * W[rr][q + 3] + we3 * W[rr][q];  // patch.cpp:391
+        for (int q = 0; q < 3 * NOC; ++q)
+          xp[(3 * rg + rr) * RL + 3 * NOC * cg + q] =
+              we0 * W[rr + 1][q + NOC] + we1 * W[rr + 1][q] + we2 * W[rr][q + NOC] + we3 * W[rr][q];  // patch.cpp:391
       __builtin_amdgcn_wave_barrier();
     }
-    float v[28];
+    float v[NB];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < 7; ++m) v[c * 7 + m] = (c == 3 && m == 6) ? 0.0f : xp[kB(c, m)];
+      for (int m = 0; m < MC; ++m) v[c * MC + m] = vB(c, m) ? xp[kB(c, m)] : 0.0f;
     if (a.patnorm > 0) {
       const float mean = div_nv(sumB(v));
 #pragma unroll
-      for (int i = 0; i < 27; ++i) v[i] -= mean;
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < MC; ++m)
+          if (vB(c, m)) v[c * MC + m] -= mean;
     }
     float sgx[4], sgy[4], spw[4];  // chain sums on the fly: Tx . r, Ty . r, |r|
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < (c == 3 ? 6 : 7); ++m) {
-        const int i = c * 7 + m;
+      for (int m = 0; m < MC; ++m) {
+        if (!vB(c, m)) continue;
+        const int i = c * MC + m;
         float d = v[i] - T[i];
         if (COST == 1) d = copysignf(sqrt_rn(fabsf(d)), d);  // L1 (patch.cpp:238-246)
         v[i] = d;
@@ -1175,12 +1246,19 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const Dis
   }
   while (!converged) {
     cnt++;
-    const float y0 = div_by(b0, l00, r00);
-    const float y1 = div_by(b1 - l10 * y0, l11, r11);
-    dp1 = div_by(y1, l11, r11);
-    dp0 = div_by(y0 - l10 * dp1, l00, r00);
-    p0 -= dp0;
-    p1 -= dp1;
+    if constexpr (STEREO) {  // patch.cpp:180-193: 1x1 system, then the disparity sign constraint of the camera side
+      dp0 = (b0 / l00) / l00;
+      dp1 = 0.0f;
+      p0 -= dp0;
+      p0 = a.camlr == 0 ? ((0.0f < p0) ? 0.0f : p0) : ((p0 < 0.0f) ? 0.0f : p0);  // std::min / std::max (p, 0)
+    } else {
+      const float y0 = div_by(b0, l00, r00);
+      const float y1 = div_by(b1 - l10 * y0, l11, r11);
+      dp1 = div_by(y1, l11, r11);
+      dp0 = div_by(y0 - l10 * dp1, l00, r00);
+      p0 -= dp0;
+      p1 -= dp1;
+    }
     ptx = rx + p0;
     pty = ry + p1;
     const float ex = stx - ptx, ey = sty - pty;
@@ -1204,13 +1282,24 @@ hipError_t launch_patch_optimize_rgb12(const DisArgs& a, hipStream_t s) {
   const int wpf = (a.g.nop + 3) / 4;  // four patches per wavefront
   const int blocks_per_frame = (wpf + 3) / 4;
   const dim3 gd(((a.nframes + 7) / 8) * 8 * blocks_per_frame), bd(256);
-  if constexpr (FUSED) {
-    if (a.costfct == 0) hipLaunchKernelGGL((patch_optimize_rgb12_kernel<0>), gd, bd, 0, s, a);
-    else hipLaunchKernelGGL((patch_optimize_rgb12_kernel<1>), gd, bd, 0, s, a);
-  } else {
-    if (a.costfct == 0) hipLaunchKernelGGL((patch_optimize_rgb12x_kernel<0>), gd, bd, 0, s, a);
-    else hipLaunchKernelGGL((patch_optimize_rgb12x_kernel<1>), gd, bd, 0, s, a);
-  }
+  const bool gray = a.g.noc == 1, l1 = a.costfct != 0;
+#define OFDIS_P12(KERNEL)                                                                                    \
+  do {                                                                                                       \
+    if (a.stereo) {                                                                                          \
+      if (gray) { if (l1) hipLaunchKernelGGL((KERNEL<1, 1, true>), gd, bd, 0, s, a);                         \
+                  else hipLaunchKernelGGL((KERNEL<0, 1, true>), gd, bd, 0, s, a); }                          \
+      else      { if (l1) hipLaunchKernelGGL((KERNEL<1, 3, true>), gd, bd, 0, s, a);                         \
+                  else hipLaunchKernelGGL((KERNEL<0, 3, true>), gd, bd, 0, s, a); }                          \
+    } else {                                                                                                 \
+      if (gray) { if (l1) hipLaunchKernelGGL((KERNEL<1, 1, false>), gd, bd, 0, s, a);                        \
+                  else hipLaunchKernelGGL((KERNEL<0, 1, false>), gd, bd, 0, s, a); }                         \
+      else      { if (l1) hipLaunchKernelGGL((KERNEL<1, 3, false>), gd, bd, 0, s, a);                        \
+                  else hipLaunchKernelGGL((KERNEL<0, 3, false>), gd, bd, 0, s, a); }                         \
+    }                                                                                                        \
+  } while (0)
+  if constexpr (FUSED) OFDIS_P12(patch_optimize_rgb12_kernel);
+  else OFDIS_P12(patch_optimize_rgb12x_kernel);
+#undef OFDIS_P12
   return hipGetLastError();
 }
 
@@ -1234,8 +1323,10 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s, const ofdis_tu
   // (PMC: 18 % fewer VALU instructions, same time) -- so one patch per wavefront stays the default.
   const int rgb12_lpp = tn.rgb12_lpp == 0 ? 16 : tn.rgb12_lpp;
   const bool rgb12 = a.g.novals == 432 && !a.stereo && (a.costfct == 0 || a.costfct == 1) && tn.rgb12;
-  // RGB 12x12 has its own mapping (16 lanes per patch, four patches per wavefront: ofdis_tuning::rgb12_lpp = 16, the default)
-  if (rgb12 && rgb12_lpp == 16) return launch_patch_optimize_rgb12<kFusedContract>(a, s);
+  // 12x12 patches, RGB or gray, flow or stereo, have their own mapping (16 lanes per patch, four patches per wavefront:
+  // ofdis_tuning::rgb12 with rgb12_lpp = 16, the default)
+  const bool p12 = a.g.P == 12 && (a.g.noc == 1 || a.g.noc == 3) && (a.costfct == 0 || a.costfct == 1) && tn.rgb12;
+  if (p12 && rgb12_lpp == 16) return launch_patch_optimize_rgb12<kFusedContract>(a, s);
   if (a.pixw) return hipErrorInvalidValue;  // (only the kernels above write the compact weights)
   const int lpp = (M <= 1) ? (gray8 ? 4 : 8) : ((rgb12 && rgb12_lpp == 32) ? 32 : 64);  // lanes per patch
   const int ppw = 64 / lpp;                           // patches per wavefront

@@ -222,6 +222,17 @@ def test_fused_contract_rgb(gpu, orc, lpp, cost):
     _check(orc, p, 320, 240, ref, ex, fu, f"rgb op3 cost {cost}, {lpp} lanes per patch")
 
 
+@pytest.mark.parametrize("size,opp,cost,seed", [((320, 240), 3, 0, 81), ((333, 251), 3, 1, 82), ((160, 120), 4, 0, 83)])
+def test_fused_contract_gray_12x12(gpu, orc, size, opp, cost, seed):
+    """run_OF_INT at operating points 3 / 4 (gray 12x12 patches) against the plain reference build: the fused contract's
+    16-lanes-per-patch kernel (a 3x3 pixel block per lane, in-lane sums + four DPP steps) within the bar."""
+    p, pa, pb, _, _ = synth_case(size[0], size[1], seed, 1, opp, 1)
+    p = p.copy(costfct=cost)
+    ref = _plain_ref("int").flow(p, pa[0], pa[1], pa[2], pb[0])
+    ex, fu = _both_contracts(gpu, lambda: gpu.flow(p, pa[0], pa[1], pa[2], pb[0]))
+    _check(orc, p, size[0], size[1], ref, ex, fu, f"gray op{opp} cost {cost}")
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("seed", [4242, 4243, 4244])
 def test_fused_contract_config4_tail(gpu, orc, seed):

@@ -289,6 +289,27 @@ def test_rgb_flow_bit_exact(gpu, orc, lpp, cost):
         assert mean < 1e-4 and mx < 1e-3, (mean, mx, frac)
 
 
+@pytest.mark.parametrize("rgb12", [1, 0])
+@pytest.mark.parametrize("size,opp,cost", [((320, 240), 3, 0), ((203, 131), 3, 1), ((160, 120), 4, 0), ((333, 251), 3, 0)])
+def test_gray_12x12_flow_bit_exact(gpu, orc, size, opp, cost, rgb12):
+    """run_OF_INT at operating points 3 and 4: gray 12x12 patches (144 values).  The 16-lanes-per-patch kernel (taps by 3x3
+    pixel blocks; sums by the entry chains of the one-patch-per-wavefront mapping: chain 0 three entries, chains 1-3 two)
+    and the generic kernel (ofdis_tuning.rgb12 = 0) give the reference's bits."""
+    p, pa, pb, _, _ = synth_case(size[0], size[1], 79, 1, opp, 1)
+    p = p.copy(costfct=cost)
+    assert p.p_samp_s == 12
+    ref = orc.flow(p, pa[0], pa[1], pa[2], pb[0])
+    old = gpu.set_tuning(rgb12=rgb12)
+    try:
+        got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
+    finally:
+        gpu.restore_tuning(old)
+    assert_bits_equal(got, ref, "gray 12x12 flow")
+    R = oracle.need_ref("int", True)
+    if R is not None:
+        assert_bits_equal(got, R.flow(p, pa[0], pa[1], pa[2], pb[0]), "gray 12x12 flow vs reference sources")
+
+
 @pytest.mark.parametrize("size,cost", [((320, 240), 1), ((320, 240), 0), ((203, 131), 1)])
 def test_rgb_two_patches_per_wavefront(gpu, orc, size, cost):
     """ofdis_tuning.rgb12_lpp = 32: the RGB 12x12 patch kernel with two patches per wavefront (32 lanes each, two
