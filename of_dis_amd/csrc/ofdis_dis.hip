@@ -665,6 +665,30 @@ __global__ __launch_bounds__(256) void patch_optimize_gray8_kernel(const DisArgs
 //     tests are paid once per four patches.
 // About 105 instead of 353 instructions per patch and iteration.  Same algorithm, same taps, same control flow: results
 // within the fused contract's tolerance of the exact kernel (tests/test_gpu_contract.py).
+// N contiguous floats at byte offset voff (per lane) + soff (scalar): 16-byte buffer loads, then the widest load for the rest
+template <int N>
+__device__ __forceinline__ void buffer_load_floats(const __amdgpu_buffer_rsrc_t& rs, int voff, int soff, float* dst) {
+  auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };  // (vector elements go through scalars, see compute_err)
+#pragma unroll
+  for (int q = 0; q + 4 <= N; q += 4) {
+    const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 4 * q, soff, 0);
+    const unsigned u0 = t[0], u1 = t[1], u2 = t[2], u3 = t[3];
+    dst[q] = asf(u0); dst[q + 1] = asf(u1); dst[q + 2] = asf(u2); dst[q + 3] = asf(u3);
+  }
+  constexpr int F = N / 4 * 4;
+  if constexpr (N % 4 == 3) {
+    const auto t = __builtin_amdgcn_raw_buffer_load_b96(rs, voff + 4 * F, soff, 0);
+    const unsigned u0 = t[0], u1 = t[1], u2 = t[2];
+    dst[F] = asf(u0); dst[F + 1] = asf(u1); dst[F + 2] = asf(u2);
+  } else if constexpr (N % 4 == 2) {
+    const auto t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 4 * F, soff, 0);
+    const unsigned u0 = t[0], u1 = t[1];
+    dst[F] = asf(u0); dst[F + 1] = asf(u1);
+  } else if constexpr (N % 4 == 1) {
+    dst[F] = asf(__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4 * F, soff, 0));
+  }
+}
+
 __device__ __forceinline__ float row16_sum(float x) {  // all-reduce inside a DPP row of 16 lanes
   x = x + dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
   x = x + dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
@@ -674,15 +698,20 @@ __device__ __forceinline__ float row16_sum(float x) {  // all-reduce inside a DP
 }
 
 // NOC = 1: the same mapping for gray 12 x 12 patches (operating points 3 and 4 of run_OF_INT / run_DE_INT): 9 entries per
-// lane, one 16-byte load per window row.  STEREO: the 1-D search of the depth mode (patch.cpp:83-87, 180-193).
-template <int COST, int NOC, bool STEREO>
+// lane, one 16-byte load per window row.  BS = 2: RGB 8 x 8 patches (operating points 1 and 2 of run_OF_RGB / run_DE_RGB):
+// a 2 x 2 pixel block per lane, 12 entries, a 3 x 3 pixel window.  STEREO: the 1-D search of the depth mode
+// (patch.cpp:83-87, 180-193).
+template <int COST, int NOC, bool STEREO, int BS>
 __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisArgs a) {
-  constexpr int Q = 4, NE = 9 * NOC, NV = 144 * NOC;  // patches per wavefront, entries per lane, entries per patch
-  constexpr int RL = 3 * NOC;                         // floats per row of the lane's 3 x 3 pixel block
+  constexpr int Q = 4, NE = BS * BS * NOC, NV = 16 * NE;  // patches per wavefront, entries per lane, entries per patch
+  constexpr int RL = BS * NOC;                            // floats per row of the lane's BS x BS pixel block
+  constexpr int P = 4 * BS, HP = P / 2;                   // patch size
+  constexpr bool TYL = NOC == 3 && BS == 3;               // the template's y gradient lives in LDS
+  constexpr bool PIXW = NOC == 3 && BS == 3;              // compact per-pixel weights (ofdis_dev.h: pixw_row)
   // The template's y gradient lives in LDS, [entry / 4][thread] as 16-byte groups (a lane reads its own seven groups once
   // per evaluation, conflict-free): 27 registers less = 168 without scratch = three wavefronts per SIMD instead of two
   typedef float f4l __attribute__((ext_vector_type(4)));
-  __shared__ f4l tyl[NOC == 3 ? 7 * 256 : 1];  // (gray: 9 registers, kept)
+  __shared__ f4l tyl[TYL ? 7 * 256 : 1];  // (9 or 12 entries per lane: registers)
   const LevelGeom& g = a.g;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -705,7 +734,6 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
   };
   const __amdgpu_buffer_rsrc_t rsB = plane_rsrc(a.im_b);
   const int row_bytes = tw * 4 * NOC;
-  auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
   const float rx = (float)(gx * g.steps + g.offw), ry = (float)(gy * g.steps + g.offh);
   const float inv_nv = 1.0f / (float)NV;
 
@@ -716,26 +744,12 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
   {
     const int px = (int)roundf(rx) + g.pad, py = (int)roundf(ry) + g.pad;
     const __amdgpu_buffer_rsrc_t rsA = plane_rsrc(a.im_a), rsAx = plane_rsrc(a.im_a_dx), rsAy = plane_rsrc(a.im_a_dy);
-    const int vbase = ((py - 6 + 3 * rg) * tw + px - 6 + 3 * cg) * (4 * NOC);
-    auto ld9 = [&](const __amdgpu_buffer_rsrc_t& rs, int rr, float* dst) {
-      if constexpr (NOC == 1) {
-        const auto q = __builtin_amdgcn_raw_buffer_load_b96(rs, vbase, rr * row_bytes, 0);
-        const unsigned u0 = q[0], u1 = q[1], u2 = q[2];
-        dst[0] = asf(u0); dst[1] = asf(u1); dst[2] = asf(u2);
-      } else {
-        const auto q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, vbase, rr * row_bytes, 0);
-        const auto q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + 16, rr * row_bytes, 0);
-        const unsigned q2 = __builtin_amdgcn_raw_buffer_load_b32(rs, vbase + 32, rr * row_bytes, 0);
-        const unsigned u0 = q0[0], u1 = q0[1], u2 = q0[2], u3 = q0[3], u4 = q1[0], u5 = q1[1], u6 = q1[2], u7 = q1[3];
-        dst[0] = asf(u0); dst[1] = asf(u1); dst[2] = asf(u2); dst[3] = asf(u3); dst[4] = asf(u4);
-        dst[5] = asf(u5); dst[6] = asf(u6); dst[7] = asf(u7); dst[8] = asf(q2);
-      }
-    };
+    const int vbase = ((py - HP + BS * rg) * tw + px - HP + BS * cg) * (4 * NOC);
 #pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {
-      ld9(rsA, rr, T + RL * rr);
-      ld9(rsAx, rr, Tx + RL * rr);
-      ld9(rsAy, rr, Ty + RL * rr);
+    for (int rr = 0; rr < BS; ++rr) {
+      buffer_load_floats<RL>(rsA, vbase, rr * row_bytes, T + RL * rr);
+      buffer_load_floats<RL>(rsAx, vbase, rr * row_bytes, Tx + RL * rr);
+      buffer_load_floats<RL>(rsAy, vbase, rr * row_bytes, Ty + RL * rr);
     }
     if (a.patnorm > 0) {
       float c = T[0];
@@ -779,7 +793,7 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
       }
     }
   }
-  if constexpr (NOC == 3) {
+  if constexpr (TYL) {
 #pragma unroll
     for (int q = 0; q < 7; ++q)
       tyl[q * 256 + threadIdx.x] = f4l{Ty[4 * q], Ty[4 * q + 1], Ty[4 * q + 2], q < 6 ? Ty[4 * q + 3] : 0.0f};
@@ -809,17 +823,17 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
   bool converged = false;
   // this lane's 3 rows of 9 weights within the patch's 432 (entry (row, col, c) at (row * 12 + col) * 3 + c)
   // (internal layout, ofdis_dev.h: pweight_row -- patch rows are nopw * 36 floats apart)
-  float* const pwout = a.pweight + (size_t)frame * g.nop * NV + pweight_row(g, gx, gy, 3 * rg) + RL * cg;
-  const int pwstride = g.nopw * 12 * NOC;
+  float* const pwout = a.pweight + (size_t)frame * g.nop * NV + pweight_row(g, gx, gy, BS * rg) + RL * cg;
+  const int pwstride = g.nopw * P * NOC;
   // A patch whose weights the densification reads unshifted (ofdis_dev.h: patch_weights_unshifted -- all but the patches on
   // the left / right / top border) stores ONE float per pixel, the denominator max(2,|r_0|) + max(2,|r_1|) + max(2,|r_2|) of
   // the pixel's weight (patchgrid.cpp:256-259, the same three operations in the same order), instead of its 432 |r|: the lane
   // holds the three channels of each of its nine pixels.  108 instead of 324 bytes per lane.
-  const bool compact = NOC == 3 && a.pixw != nullptr && patch_weights_unshifted(g, gx, gy);
-  float* const pxout = (NOC == 3 && a.pixw) ? a.pixw + (size_t)frame * g.nop * 144 + pixw_row(g, gx, gy, 3 * rg) + 3 * cg : nullptr;
+  const bool compact = PIXW && a.pixw != nullptr && patch_weights_unshifted(g, gx, gy);
+  float* const pxout = (PIXW && a.pixw) ? a.pixw + (size_t)frame * g.nop * 144 + pixw_row(g, gx, gy, 3 * rg) + 3 * cg : nullptr;
   const int pxstride = g.nopw * 12;
   auto store_pw = [&](const float (&v)[NE], bool zero) {
-    if constexpr (NOC == 3) {
+    if constexpr (PIXW) {
       if (compact) {
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr)
@@ -835,7 +849,7 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
       }
     }
 #pragma unroll
-    for (int rr = 0; rr < 3; ++rr)
+    for (int rr = 0; rr < BS; ++rr)
 #pragma unroll
       for (int q = 0; q < RL; ++q) pwout[rr * pwstride + q] = zero ? 0.0f : fabsf(v[rr * RL + q]);
   };
@@ -849,21 +863,14 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
     pos1 += g.pad;
     // window: rows pos1 - 7 + 3 rg + j, j = 0..3; pixels pos0 - 7 + 3 cg + i, i = 0..3 (12 floats per row).  Entry (rr, xx, c)
     // takes a = W[rr+1][xx+1], b = W[rr+1][xx], c = W[rr][xx+1], d = W[rr][xx] (patch.cpp:335-402)
-    const int voff = ((pos1 - 7 + 3 * rg) * tw + pos0 - 7 + 3 * cg) * (4 * NOC);
-    float W[4][4 * NOC];
+    const int voff = ((pos1 - (HP + 1) + BS * rg) * tw + pos0 - (HP + 1) + BS * cg) * (4 * NOC);
+    float W[BS + 1][(BS + 1) * NOC];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int q = 0; q < NOC; ++q) {
-        const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 16 * q, j * row_bytes, 0);
-        const unsigned u0 = t[0], u1 = t[1], u2 = t[2], u3 = t[3];
-        W[j][4 * q] = asf(u0); W[j][4 * q + 1] = asf(u1); W[j][4 * q + 2] = asf(u2); W[j][4 * q + 3] = asf(u3);
-      }
-    }
+    for (int j = 0; j <= BS; ++j) buffer_load_floats<(BS + 1) * NOC>(rsB, voff, j * row_bytes, W[j]);
     float d[NE];
     float se = 0.0f;
 #pragma unroll
-    for (int rr = 0; rr < 3; ++rr)
+    for (int rr = 0; rr < BS; ++rr)
 #pragma unroll
       for (int q = 0; q < RL; ++q) {  // q = xx * NOC + c: the left neighbour pixel is NOC floats back
         const int e = rr * RL + q;
@@ -881,7 +888,7 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
     } else {              // T was not normalised: d = v - T already
     }
     float g0 = 0.0f, g1 = 0.0f, sa = 0.0f;
-    if constexpr (NOC == 3) {
+    if constexpr (TYL) {
 #pragma unroll
       for (int q = 0; q < 7; ++q) {
         const f4l ty = tyl[q * 256 + threadIdx.x];
@@ -982,10 +989,13 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12_kernel(const DisA
 // patch and iteration.
 // NOC = 1: gray 12 x 12 (144 entries: chain 0 has three entries k = pl, pl + 64, pl + 128, chains 1-3 two).  STEREO: the
 // 1-D search of the depth mode.
-template <int COST, int NOC, bool STEREO>
+// BS = 2: RGB 8 x 8 (192 entries: three per chain).
+template <int COST, int NOC, bool STEREO, int BS>
 __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const DisArgs a) {
-  constexpr int Q = 4, NV = 144 * NOC;
-  constexpr int RL = 12 * NOC;         // floats per patch row
+  constexpr int Q = 4, NV = 16 * BS * BS * NOC;
+  constexpr int P = 4 * BS, HP = P / 2;
+  constexpr bool PIXW = NOC == 3 && BS == 3;
+  constexpr int RL = P * NOC;          // floats per patch row
   constexpr int MC = (NV + 63) / 64;   // slots per chain (7 / 3); NB = 4 chains
   constexpr int NB = 4 * MC;
   __shared__ float xl[4 * Q * NV];  // [wavefront][patch][entry]: the A -> B hand-over
@@ -1012,7 +1022,6 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const Dis
   };
   const __amdgpu_buffer_rsrc_t rsB = plane_rsrc(a.im_b);
   const int row_bytes = tw * 4 * NOC;
-  auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
   const float rx = (float)(gx * g.steps + g.offw), ry = (float)(gy * g.steps + g.offh);
   const float fnv = (float)NV, rcp_nv = rcp_refined(fnv);
   auto div_nv = [&](float x) { return div_by(x, fnv, rcp_nv); };  // == x / 432, correctly rounded (ofdis_dev.h)
@@ -1045,7 +1054,7 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const Dis
     const float* __restrict__ imA = a.im_a + (size_t)frame * plane;
     const float* __restrict__ imAx = a.im_a_dx + (size_t)frame * plane;
     const float* __restrict__ imAy = a.im_a_dy + (size_t)frame * plane;
-    const int base = ((py - 6) * tw + px - 6) * NOC;
+    const int base = ((py - HP) * tw + px - HP) * NOC;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -1128,11 +1137,11 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const Dis
   // (see patch_optimize_rgb12_kernel: one float per pixel for the patches the densification reads unshifted.  The residual
   // lives in layout B here, a pixel's three channels in three lanes: |r| goes through the hand-over vector once more and is
   // read back by pixel blocks, layout A)
-  const bool compact = NOC == 3 && a.pixw != nullptr && patch_weights_unshifted(g, gx, gy);
-  float* const pxout = (NOC == 3 && a.pixw) ? a.pixw + (size_t)frame * g.nop * 144 + pixw_row(g, gx, gy, 3 * rg) + 3 * cg : nullptr;
+  const bool compact = PIXW && a.pixw != nullptr && patch_weights_unshifted(g, gx, gy);
+  float* const pxout = (PIXW && a.pixw) ? a.pixw + (size_t)frame * g.nop * 144 + pixw_row(g, gx, gy, 3 * rg) + 3 * cg : nullptr;
   const int pxstride = g.nopw * 12;
   auto store_pw = [&](const float (&v)[NB], bool zero) {  // |residual| of this lane's entries (layout B)
-    if constexpr (NOC == 3) {
+    if constexpr (PIXW) {
       if (compact) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1173,23 +1182,16 @@ __global__ __launch_bounds__(256, 3) void patch_optimize_rgb12x_kernel(const Dis
     pos0 += g.pad;
     pos1 += g.pad;
     {  // layout A: the lane's 3x3 pixel block from its 4x4 pixel window, handed over entry by entry
-      const int voff = ((pos1 - 7 + 3 * rg) * tw + pos0 - 7 + 3 * cg) * (4 * NOC);
-      float W[4][4 * NOC];
+      const int voff = ((pos1 - (HP + 1) + BS * rg) * tw + pos0 - (HP + 1) + BS * cg) * (4 * NOC);
+      float W[BS + 1][(BS + 1) * NOC];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int q = 0; q < NOC; ++q) {
-          const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff + 16 * q, j * row_bytes, 0);
-          const unsigned u0 = t[0], u1 = t[1], u2 = t[2], u3 = t[3];
-          W[j][4 * q] = asf(u0); W[j][4 * q + 1] = asf(u1); W[j][4 * q + 2] = asf(u2); W[j][4 * q + 3] = asf(u3);
-        }
-      }
+      for (int j = 0; j <= BS; ++j) buffer_load_floats<(BS + 1) * NOC>(rsB, voff, j * row_bytes, W[j]);
       __builtin_amdgcn_wave_barrier();  // (the previous evaluation's reads of the hand-over vector come first)
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr)
+      for (int rr = 0; rr < BS; ++rr)
 #pragma unroll
-        for (int q = 0; q < 3 * NOC; ++q)
-          xp[(3 * rg + rr) * RL + 3 * NOC * cg + q] =
+        for (int q = 0; q < BS * NOC; ++q)
+          xp[(BS * rg + rr) * RL + BS * NOC * cg + q] =
               we0 * W[rr + 1][q + NOC] + we1 * W[rr + 1][q] + we2 * W[rr][q + NOC] + we3 * W[rr][q];  // patch.cpp:391
       __builtin_amdgcn_wave_barrier();
     }
@@ -1282,24 +1284,27 @@ hipError_t launch_patch_optimize_rgb12(const DisArgs& a, hipStream_t s) {
   const int wpf = (a.g.nop + 3) / 4;  // four patches per wavefront
   const int blocks_per_frame = (wpf + 3) / 4;
   const dim3 gd(((a.nframes + 7) / 8) * 8 * blocks_per_frame), bd(256);
-  const bool gray = a.g.noc == 1, l1 = a.costfct != 0;
-#define OFDIS_P12(KERNEL)                                                                                    \
+  const bool l1 = a.costfct != 0;
+#define OFDIS_P16L(KERNEL, NOC, BS)                                                                          \
   do {                                                                                                       \
     if (a.stereo) {                                                                                          \
-      if (gray) { if (l1) hipLaunchKernelGGL((KERNEL<1, 1, true>), gd, bd, 0, s, a);                         \
-                  else hipLaunchKernelGGL((KERNEL<0, 1, true>), gd, bd, 0, s, a); }                          \
-      else      { if (l1) hipLaunchKernelGGL((KERNEL<1, 3, true>), gd, bd, 0, s, a);                         \
-                  else hipLaunchKernelGGL((KERNEL<0, 3, true>), gd, bd, 0, s, a); }                          \
+      if (l1) hipLaunchKernelGGL((KERNEL<1, NOC, true, BS>), gd, bd, 0, s, a);                               \
+      else hipLaunchKernelGGL((KERNEL<0, NOC, true, BS>), gd, bd, 0, s, a);                                  \
     } else {                                                                                                 \
-      if (gray) { if (l1) hipLaunchKernelGGL((KERNEL<1, 1, false>), gd, bd, 0, s, a);                        \
-                  else hipLaunchKernelGGL((KERNEL<0, 1, false>), gd, bd, 0, s, a); }                         \
-      else      { if (l1) hipLaunchKernelGGL((KERNEL<1, 3, false>), gd, bd, 0, s, a);                        \
-                  else hipLaunchKernelGGL((KERNEL<0, 3, false>), gd, bd, 0, s, a); }                         \
+      if (l1) hipLaunchKernelGGL((KERNEL<1, NOC, false, BS>), gd, bd, 0, s, a);                              \
+      else hipLaunchKernelGGL((KERNEL<0, NOC, false, BS>), gd, bd, 0, s, a);                                 \
     }                                                                                                        \
   } while (0)
-  if constexpr (FUSED) OFDIS_P12(patch_optimize_rgb12_kernel);
-  else OFDIS_P12(patch_optimize_rgb12x_kernel);
-#undef OFDIS_P12
+#define OFDIS_P16L_GEOM(KERNEL)                                                                              \
+  do {                                                                                                       \
+    if (a.g.P == 8) OFDIS_P16L(KERNEL, 3, 2);                                                                \
+    else if (a.g.noc == 1) OFDIS_P16L(KERNEL, 1, 3);                                                         \
+    else OFDIS_P16L(KERNEL, 3, 3);                                                                           \
+  } while (0)
+  if constexpr (FUSED) OFDIS_P16L_GEOM(patch_optimize_rgb12_kernel);
+  else OFDIS_P16L_GEOM(patch_optimize_rgb12x_kernel);
+#undef OFDIS_P16L_GEOM
+#undef OFDIS_P16L
   return hipGetLastError();
 }
 
@@ -1323,9 +1328,10 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s, const ofdis_tu
   // (PMC: 18 % fewer VALU instructions, same time) -- so one patch per wavefront stays the default.
   const int rgb12_lpp = tn.rgb12_lpp == 0 ? 16 : tn.rgb12_lpp;
   const bool rgb12 = a.g.novals == 432 && !a.stereo && (a.costfct == 0 || a.costfct == 1) && tn.rgb12;
-  // 12x12 patches, RGB or gray, flow or stereo, have their own mapping (16 lanes per patch, four patches per wavefront:
-  // ofdis_tuning::rgb12 with rgb12_lpp = 16, the default)
-  const bool p12 = a.g.P == 12 && (a.g.noc == 1 || a.g.noc == 3) && (a.costfct == 0 || a.costfct == 1) && tn.rgb12;
+  // 12x12 patches, RGB or gray, and RGB 8x8 patches, flow or stereo, have their own mapping (16 lanes per patch, four
+  // patches per wavefront: ofdis_tuning::rgb12 with rgb12_lpp = 16, the default)
+  const bool p12 = ((a.g.P == 12 && (a.g.noc == 1 || a.g.noc == 3)) || (a.g.P == 8 && a.g.noc == 3)) &&
+                   (a.costfct == 0 || a.costfct == 1) && tn.rgb12;
   if (p12 && rgb12_lpp == 16) return launch_patch_optimize_rgb12<kFusedContract>(a, s);
   if (a.pixw) return hipErrorInvalidValue;  // (only the kernels above write the compact weights)
   const int lpp = (M <= 1) ? (gray8 ? 4 : 8) : ((rgb12 && rgb12_lpp == 32) ? 32 : 64);  // lanes per patch

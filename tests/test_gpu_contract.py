@@ -233,6 +233,17 @@ def test_fused_contract_gray_12x12(gpu, orc, size, opp, cost, seed):
     _check(orc, p, size[0], size[1], ref, ex, fu, f"gray op{opp} cost {cost}")
 
 
+@pytest.mark.parametrize("size,opp,cost,seed", [((320, 240), 2, 0, 84), ((333, 251), 1, 1, 85), ((1024, 436), 2, 0, 86)])
+def test_fused_contract_rgb_8x8(gpu, orc, size, opp, cost, seed):
+    """run_OF_RGB at its default operating point (and op 1): RGB 8x8 patches under the fused contract's 16-lanes-per-patch
+    kernel (a 2x2 pixel block per lane) against the plain RGB reference build."""
+    p, pa, pb, _, _ = synth_case(size[0], size[1], seed, 3, opp, 1 if opp == 2 else 0)
+    p = p.copy(costfct=cost)
+    ref = _plain_ref("rgb").flow(p, pa[0], pa[1], pa[2], pb[0])
+    ex, fu = _both_contracts(gpu, lambda: gpu.flow(p, pa[0], pa[1], pa[2], pb[0]))
+    _check(orc, p, size[0], size[1], ref, ex, fu, f"rgb op{opp} cost {cost}")
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("seed", [4242, 4243, 4244])
 def test_fused_contract_config4_tail(gpu, orc, seed):

@@ -310,6 +310,27 @@ def test_gray_12x12_flow_bit_exact(gpu, orc, size, opp, cost, rgb12):
         assert_bits_equal(got, R.flow(p, pa[0], pa[1], pa[2], pb[0]), "gray 12x12 flow vs reference sources")
 
 
+@pytest.mark.parametrize("rgb12", [1, 0])
+@pytest.mark.parametrize("size,opp,cost", [((320, 240), 2, 0), ((203, 131), 2, 1), ((333, 251), 1, 0), ((1024, 436), 2, 0)])
+def test_rgb_8x8_flow_bit_exact(gpu, orc, size, opp, cost, rgb12):
+    """run_OF_RGB at operating points 1 and 2 (its default): RGB 8x8 patches (192 values).  The 16-lanes-per-patch kernel
+    (a 2x2 pixel block per lane for the taps, three entries per chain for the sums) and the generic one-patch-per-wavefront
+    kernel (ofdis_tuning.rgb12 = 0) give the reference's bits."""
+    p, pa, pb, _, _ = synth_case(size[0], size[1], 80, 3, opp, 1 if opp == 2 else 0)
+    p = p.copy(costfct=cost)
+    assert p.p_samp_s == 8
+    ref = orc.flow(p, pa[0], pa[1], pa[2], pb[0])
+    old = gpu.set_tuning(rgb12=rgb12)
+    try:
+        got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
+    finally:
+        gpu.restore_tuning(old)
+    assert_bits_equal(got, ref, "rgb 8x8 flow")
+    R = oracle.need_ref("rgb", True)
+    if R is not None:
+        assert_bits_equal(got, R.flow(p, pa[0], pa[1], pa[2], pb[0]), "rgb 8x8 flow vs reference sources")
+
+
 @pytest.mark.parametrize("size,cost", [((320, 240), 1), ((320, 240), 0), ((203, 131), 1)])
 def test_rgb_two_patches_per_wavefront(gpu, orc, size, cost):
     """ofdis_tuning.rgb12_lpp = 32: the RGB 12x12 patch kernel with two patches per wavefront (32 lanes each, two

@@ -27,7 +27,7 @@ def _ref(noc):
     return R
 
 
-@pytest.mark.parametrize("noc,opp", [(1, 2), (3, 3), (1, 3)])
+@pytest.mark.parametrize("noc,opp", [(1, 2), (3, 3), (1, 3), (3, 2)])
 def test_stereo_patchgrid_levels(gpu, noc, opp):
     p, pa, pb = _case(640, 480, 90, noc, opp, 0)
     R = _ref(noc)
@@ -65,7 +65,7 @@ def test_stereo_varref_levels(gpu, noc, size, opp, solverit):
 
 
 @pytest.mark.parametrize("size,noc,opp,tv", [((1024, 436), 1, 2, 1), ((640, 480), 1, 2, 0), ((333, 251), 1, 1, 1),
-                                             ((320, 240), 3, 3, 1), ((333, 251), 1, 3, 1), ((200, 160), 1, 4, 0)])
+                                             ((320, 240), 3, 3, 1), ((333, 251), 1, 3, 1), ((200, 160), 1, 4, 0), ((320, 240), 3, 2, 1)])
 def test_stereo_flow_bit_exact(gpu, size, noc, opp, tv):
     p, pa, pb = _case(size[0], size[1], 92, noc, opp, tv)
     R = _ref(noc)

@@ -98,8 +98,8 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     ("tv_fused_xcu_kernelILi3ELb1EE", 128, "tv_fused_xcu_kernel<3, true>, cross-CU mapping: one wavefront per SIMD, four workgroups per CU at most"),
     ("patch_optimize_gray8_kernelILi0ELb0EE", 128, "gray 8x8 patch kernel: four wavefronts per SIMD"),
     ("patch_optimize_kernelILi7ELi64ELi432ELi1EE", 84, "RGB 12x12 patch kernel, L1 cost: six wavefronts per SIMD"),
-    ("patch_optimize_rgb12x_kernelILi1ELi3ELb0EE", 168, "RGB 12x12 patch kernel of the exact contract (blocks for the taps, chains for the sums): three wavefronts per SIMD"),
-    ("patch_optimize_rgb12_kernelILi1ELi3ELb0EE", 168, "RGB 12x12 patch kernel of the fused contract (3x3 pixel block per lane, Ty in LDS): three wavefronts per SIMD"),
+    ("patch_optimize_rgb12x_kernelILi1ELi3ELb0ELi3EE", 168, "RGB 12x12 patch kernel of the exact contract (blocks for the taps, chains for the sums): three wavefronts per SIMD"),
+    ("patch_optimize_rgb12_kernelILi1ELi3ELb0ELi3EE", 168, "RGB 12x12 patch kernel of the fused contract (3x3 pixel block per lane, Ty in LDS): three wavefronts per SIMD"),
     ("tv_fused_kernelILi3ELb1ELi1EE", 168, "tv_fused_kernel<3, true, 1>, iteration-pipelined mapping: three wavefronts per SIMD (three workgroups of four iterations per CU)"),
     ("tv_fused_tall_kernelILi3ELb1ELb", 216, "tv_fused_tall_kernel<3, true> (two to four wavefronts per strip, 65-256 rows): two wavefronts per SIMD"),
     ("densify_kernelILb1EE", 64, "densify_kernel<true>: eight wavefronts per SIMD"),
@@ -132,7 +132,7 @@ def test_rgb12_fused_kernel_spills_only_outside_its_iteration_loop():
                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
     text = subprocess.run([llvm + "/llvm-objdump", "-d", "--demangle", co], capture_output=True, text=True, check=True).stdout
     checked = 0
-    for m in re.finditer(r"^[0-9a-f]+ <(void ofdis::fused::patch_optimize_rgb12_kernel<\d, 3, \w+>\(ofdis::DisArgs\))>:\n(.*?)(?=^[0-9a-f]+ <|\Z)",
+    for m in re.finditer(r"^[0-9a-f]+ <(void ofdis::fused::patch_optimize_rgb12_kernel<\d, 3, \w+, 3>\(ofdis::DisArgs\))>:\n(.*?)(?=^[0-9a-f]+ <|\Z)",
                          text, flags=re.S | re.M):
         lines = [l for l in m.group(2).splitlines() if re.search(r"//\s*[0-9A-Fa-f]+:", l)]
         addr = [int(re.search(r"//\s*([0-9A-Fa-f]+):", l).group(1), 16) for l in lines]
@@ -153,8 +153,8 @@ def test_rgb12_fused_kernel_spills_only_outside_its_iteration_loop():
 
 @pytest.mark.parametrize("pattern,blocks_per_cu,what", [
     ("tv_fused_kernelILi3ELb1ELi1EE", 3, "iteration-pipelined fused TV: three workgroups of four wavefronts per compute unit"),
-    ("patch_optimize_rgb12_kernelILi1ELi3ELb0EE", 3, "fused contract's RGB 12x12 patch kernel: three blocks of four wavefronts per compute unit"),
-    ("patch_optimize_rgb12x_kernelILi1ELi3ELb0EE", 3, "exact contract's RGB 12x12 patch kernel: three blocks of four wavefronts per compute unit"),
+    ("patch_optimize_rgb12_kernelILi1ELi3ELb0ELi3EE", 3, "fused contract's RGB 12x12 patch kernel: three blocks of four wavefronts per compute unit"),
+    ("patch_optimize_rgb12x_kernelILi1ELi3ELb0ELi3EE", 3, "exact contract's RGB 12x12 patch kernel: three blocks of four wavefronts per compute unit"),
 ])
 def test_lds_budgets(kernels, pattern, blocks_per_cu, what):
     """The occupancy these kernels were brought to by moving registers into LDS must not be taken away by the LDS itself

@@ -158,8 +158,8 @@ def summarize(name, body, quiet=False):
 # the kernels whose iteration loops bench.py prices against the VALU issue peak (static counts of the SHIPPED objects):
 # key -> (object file, kernel name as disassembled, patches per wavefront)
 PROFILE_KERNELS = {
-    "patch_optimize_rgb12_fused": ("ofdis_dis.fused.o", "ofdis::fused::patch_optimize_rgb12_kernel<1, 3, false>(", 4),
-    "patch_optimize_rgb12_exact": ("ofdis_dis.o", "ofdis::exact::patch_optimize_rgb12x_kernel<1, 3, false>(", 4),
+    "patch_optimize_rgb12_fused": ("ofdis_dis.fused.o", "ofdis::fused::patch_optimize_rgb12_kernel<1, 3, false, 3>(", 4),
+    "patch_optimize_rgb12_exact": ("ofdis_dis.o", "ofdis::exact::patch_optimize_rgb12x_kernel<1, 3, false, 3>(", 4),
     "patch_optimize_gray8_fused": ("ofdis_dis.fused.o", "ofdis::fused::patch_optimize_gray8_kernel<0, false>(", 16),
     "patch_optimize_gray8_exact": ("ofdis_dis.o", "ofdis::exact::patch_optimize_gray8_kernel<0, false>(", 16),
 }

@@ -1,5 +1,5 @@
-"""Developer probe: the batched path at another frame size (gray, operating point 2), with the per-kernel table per level.
-    python tools/size_probe.py W H [pairs=1024] [contract=fused]"""
+"""Developer probe: the batched path at another frame size / operating point / channel count / mode, with the per-stage table.
+    [OPP=2] [NOC=1|3] [MODE=1|2 (2 = stereo depth)] python tools/size_probe.py W H [pairs=1024] [contract=fused]"""
 import json
 import os
 import sys
@@ -20,10 +20,11 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 capi.check(capi.lib().ofdis_set_device(0))
 capi.set_tuning(contract=1 if contract == "fused" else 0)
-p = oppoint(int(os.environ.get("OPP", "2")), W, H, noc=1, verbosity=0)
-ia, ib = bench.synth_frames_range(0, min(n, 64), W, H, 1234, dev)
-reps = (n + ia.shape[0] - 1) // ia.shape[0]
-ia, ib = ia.repeat(reps, 1, 1)[:n].contiguous(), ib.repeat(reps, 1, 1)[:n].contiguous()
+noc = int(os.environ.get("NOC", "1"))
+p = oppoint(int(os.environ.get("OPP", "2")), W, H, noc=noc, verbosity=0).copy(selectmode=int(os.environ.get("MODE", "1")))
+ia, ib = bench.synth_frames_range(0, min(n, 64), W, H, 1234, dev, channels=noc)
+reps = [(n + ia.shape[0] - 1) // ia.shape[0]] + [1] * (ia.dim() - 1)
+ia, ib = ia.repeat(*reps)[:n].contiguous(), ib.repeat(*reps)[:n].contiguous()
 s = torch.cuda.Stream(device=dev)
 b = capi.Batch(p, n)
 b.set_pipeline(2 if n >= 1024 else 1)
@@ -39,5 +40,5 @@ for k, name in enumerate(capi.K_NAMES):
     if cnt:
         rows[name] = {"ms": round(ms, 3), "launches": cnt}
 print(json.dumps({"size": [W, H], "padded": [p.width, p.height], "levels": {l: p.level_size(l) for l in range(p.sc_l, p.sc_f + 1)},
-                  "pairs": n, "contract": contract, "ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(n / dt, 1),
+                  "pairs": n, "contract": contract, "channels": noc, "opp": int(os.environ.get("OPP", "2")), "selectmode": p.selectmode, "ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(n / dt, 1),
                   "kernels": rows}))
