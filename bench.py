@@ -28,6 +28,7 @@ The JSON carries, besides the contract fields:
   batch512          BASELINE configs[4]: 512 pairs in total, sharded over the ranks of this run
   small_batch       64 pairs per step on one GPU (the per-GPU share of configs[4] at 8 GPUs), one pass at a time and with
                     D passes in flight (`depth`)
+  other_modes       run_OF_RGB at its default operating point, run_OF_INT at operating point 3, run_DE_INT (stereo) at a KITTI-sized pair
   frame_sizes       the same path at 1242x375 (KITTI), 1280x720 and 1920x1080 (secondary: their finest levels are wider / taller
                     than the metric's)
   dropin_latency    ofdis_flow(): one pair per call, host pyramids in, host flow out
@@ -745,7 +746,37 @@ def block_frame_sizes(capi, torch, p, batch, ia, ib, stream, dev, args):
                         f"{args.contract_used} contract (secondary; the metric's size is 1024x436)", **out}
 
 
-BLOCKS = [("small_batch", block_small_batch), ("frame_sizes", block_frame_sizes), ("dropin_latency", block_dropin_latency),
+def block_other_modes(capi, torch, p, batch, ia, ib, stream, dev, args):
+    """The reference's other binaries / operating points on the same path (secondary): run_OF_RGB at its default
+    operating point (RGB 8x8 patches), run_OF_INT at operating point 3 (gray 12x12 patches, finest level at half resolution)
+    and run_DE_INT (stereo depth, one displacement channel) at a KITTI-sized pair.  Round 6 moved all three off the
+    one-patch-per-wavefront patch kernel, and the stereo mode off its per-pixel system kernel and one-launch-per-sweep solver."""
+    from of_dis_amd.params import oppoint
+    out = {}
+    for name, (w, h), opp, noc, mode, n in (("run_OF_RGB_op2_1024x436", (WIDTH, HEIGHT), 2, 3, 1, 1024),
+                                            ("run_OF_INT_op3_1024x436", (WIDTH, HEIGHT), 3, 1, 1, 256),
+                                            ("run_DE_INT_op2_1242x375", (1242, 375), 2, 1, 2, 1024)):
+        pq = oppoint(opp, w, h, noc=noc, verbosity=0).copy(selectmode=mode)
+        xa, xb = synth_frames_range(0, 64, w, h, 778, dev, channels=noc)
+        reps = [n // 64] + [1] * (xa.dim() - 1)
+        xa, xb = xa.repeat(*reps).contiguous(), xb.repeat(*reps).contiguous()
+        bq = capi.Batch(pq, n)
+        torch.cuda.synchronize()
+        bq.build_pyramids_u8(xa.data_ptr(), xb.data_ptr(), w, h, stream)
+        dt = timed_steps(torch, lambda: bq.run(stream), 10, 3)
+        bq.timing(True)
+        bq.run(stream)
+        torch.cuda.synchronize()
+        rows = {kn: round(bq.kernel_time(k)[0], 3) for k, kn in enumerate(capi.K_NAMES) if bq.kernel_time(k)[1]}
+        bq.close()
+        del xa, xb
+        out[name] = {"channels": noc, "operating_point": opp, "selectmode": mode, "pairs_per_step": n,
+                     "levels": [list(pq.level_size(l)) for l in range(pq.sc_l, pq.sc_f + 1)],
+                     "ms_per_step": round(dt * 1e3, 3), "value": round(n / dt, 1), "unit": "frames/s", "stage_ms": rows}
+    return {"workload": f"the reference's other binaries / operating points, {args.contract_used} contract (secondary)", **out}
+
+
+BLOCKS = [("small_batch", block_small_batch), ("frame_sizes", block_frame_sizes), ("other_modes", block_other_modes), ("dropin_latency", block_dropin_latency),
           ("warp_standalone", block_warp_standalone), ("e2e", block_e2e), ("host_e2e", block_host_e2e),
           ("config4", block_config4)]
 
