@@ -250,7 +250,8 @@ __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(con
     }
   };
   // tau = unwrapped step number of the row (MW only): the LDS ring slot
-  // (MODE 0) zero_uv: this lane's pixel of the row still belongs to the FIRST fixed-point iteration, where du = dv = 0
+  // (MODE 0) zero_uv: this lane's pixel of the row still belongs to the FIRST fixed-point iteration, where du = dv = 0 (or lies
+  // past the last iteration's columns, where the value only ever meets a zero edge weight but must be finite)
   // (image_erase, refine_variational.cpp:186-187): the load gets an offset beyond the resource, for which the hardware
   // returns +0 without a memory access -- the caller never has to clear the array and iteration 1 reads 8 bytes less per pixel
   auto load_w = [&](FRow& r, int drow, int tau, bool zero_uv) {
@@ -436,7 +437,11 @@ __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(con
           nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
         }
         {
-          if (!MW) first_w = ig + (PDW + 1 + 2 * (NS - 1)) < rw;  // for the next step's row
+          if (!MW) {  // for the next step's row: its column is in the first iteration, or PAST the last one -- nothing the
+            // launch reads there may come from memory (one iteration never writes the array: whatever the allocation held)
+            const int cw = ig + (PDW + 1 + 2 * (NS - 1));
+            first_w = (cw < rw) | (cw >= wtot);
+          }
           if (MW && it < n_iters - 1) {  // hand the row to the next iteration (lanes outside their columns publish finite
             // values nobody reads as a pixel: the reader's lane is outside its columns at the same step number)
             xring[(it * MW_RING + (taus & (MW_RING - 1))) * 64 + lane] = make_float2(nu[NS - 1], nv[NS - 1]);

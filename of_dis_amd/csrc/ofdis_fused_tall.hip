@@ -332,7 +332,10 @@ __global__ __launch_bounds__(GROUPED ? 512 : 256) void tv_fused_tall_kernel(cons
         nv[s] = ov + omega * (c.a12 * B1 + c.a22 * B2 - ov);
       }
       {
-        first_w = ig + (PDW + 1 + 2 * (NS - 1)) < rw;  // for the next step's row
+        {  // for the next step's row: first iteration, or past the last one (see tv_fused_kernel)
+          const int cw = ig + (PDW + 1 + 2 * (NS - 1));
+          first_w = (cw < rw) | (cw >= wtot);
+        }
         const u32x2 v = {__builtin_bit_cast(unsigned, nu[NS - 1]), __builtin_bit_cast(unsigned, nv[NS - 1])};
         const int lastc = ig - (wtot - rw);  // >= 0: this column belongs to the last fixed-point iteration
         const bool on = row_ok & (ig >= 0) & (aos_out ? lastc < 0 : ig < wtot);

@@ -322,6 +322,36 @@ def test_random_varref_levels(gpu, orc, seed, tv_variant):
     assert_bits_equal(got[0], ref, f"seed {seed}: {w}x{h} noc={noc} innerit={p.tv_innerit} solverit={p.tv_solverit}")
 
 
+@pytest.mark.parametrize("w,h,solverit", [(59, 59, 3), (102, 57, 2), (121, 76, 2), (62, 58, 2), (200, 130, 1), (16, 4, 3)])
+def test_one_fixed_point_iteration_reads_no_scratch(gpu, orc, monkeypatch, w, h, solverit):
+    """A level with ONE fixed-point iteration (tv_innerit = 1 at level 0) on the fused path never writes the du / dv array,
+    and its sweep requests rows past its last column: those requests must not reach memory (round 6: they did, and a NaN
+    pattern left there by an earlier allocation turned the last column into NaN -- found by a seed campaign, flaky by
+    nature).  Contexts start from zeroed scratch; with OFDIS_POISON_SCRATCH=1 they start from NaN patterns instead, which
+    is how this test (and, as a campaign, the whole GPU suite) shows that no result depends on either."""
+    import gen_synth
+    from of_dis_amd.params import oppoint
+    rng = np.random.default_rng(31000 + w * h)
+    ia, ib, _ = gen_synth.make_pair(w, h, 31100 + w, 1)
+    p = oppoint(2, w, h, noc=1).copy(sc_f=0, sc_l=0, p_samp_s=4, imgpadding=4, tv_innerit=1, tv_solverit=solverit)
+    p.width, p.height = w, h
+    pa, pb = orc.build_pyramid(p, ia), orc.build_pyramid(p, ib)
+    flow = rand_planes(rng, h, w, 2, scale=1.5)
+    ref = orc.varref_level(p, 0, pa[0][0], pb[0][0], flow)
+    monkeypatch.setenv("OFDIS_POISON_SCRATCH", "1")
+    b = gpu.Batch(p, 2)
+    assert np.isnan(b.download_all()).all(), "the poison hook is not live"
+    b.close()
+    for _ in range(2):
+        got = gpu.varref_level(p, 0, pa[0][0][None], pb[0][0][None], flow[None])
+        assert_bits_equal(got[0], ref, f"{w}x{h}, one fixed-point iteration, poisoned scratch")
+    monkeypatch.delenv("OFDIS_POISON_SCRATCH")
+    b = gpu.Batch(p, 2)
+    assert not b.download_all().any(), "a context's scratch starts zeroed"
+    b.close()
+    assert_bits_equal(gpu.varref_level(p, 0, pa[0][0][None], pb[0][0][None], flow[None])[0], ref, "zeroed scratch")
+
+
 @pytest.mark.parametrize("seed", range(32))
 def test_random_patchgrid_levels(gpu, orc, seed):
     """Random patch size / overlap / iteration limits / cost function at one level with a random coarse flow that
