@@ -157,11 +157,12 @@ def build(force=False, verbose=False):
     if force or _newer(so, objs + [vs]):
         _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={vs}", "-o", so] + objs, verbose)
     # host executables: the reference's CLI contract (run_OF_INT / run_OF_RGB and the stereo-depth run_DE_INT / run_DE_RGB,
-    # one pair per process: host/run_dense_main.cpp) and the sequence driver (run_OF_INT_seq / run_OF_RGB_seq: many pairs,
+    # one pair per process: host/run_dense_main.cpp) and the sequence drivers (run_OF_*_seq / run_DE_*_seq: many pairs,
     # one host thread per GPU: host/run_seq_main.cpp); every other .cpp under host/ is shared by both mains
     host_dir = os.path.join(CSRC, "host")
     mains = {"run_dense_main.cpp": (("run_OF_INT", 1, 1), ("run_OF_RGB", 3, 1), ("run_DE_INT", 1, 2), ("run_DE_RGB", 3, 2)),
-             "run_seq_main.cpp": (("run_OF_INT_seq", 1, 1), ("run_OF_RGB_seq", 3, 1))}
+             "run_seq_main.cpp": (("run_OF_INT_seq", 1, 1), ("run_OF_RGB_seq", 3, 1), ("run_DE_INT_seq", 1, 2),
+                                  ("run_DE_RGB_seq", 3, 2))}
     if os.path.isdir(host_dir):
         common = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".cpp") and f not in mains]
         host_hdrs = [os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".h")]

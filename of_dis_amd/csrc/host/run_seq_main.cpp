@@ -1,5 +1,7 @@
 // run_OF_INT_seq / run_OF_RGB_seq -- the reference's run_OF_* main (run_dense.cpp:185-431) over MANY frame pairs and
 // several GPUs of one node, in the host language of the reference, on top of the C ABI (include/ofdis.h).
+// With -DOFDIS_MODE=2: run_DE_INT_seq / run_DE_RGB_seq, the stereo-depth binaries' counterpart (one displacement channel,
+// "img1 img2 out.pfm" per line).
 //
 //   run_OF_INT_seq pairs.txt [--gpus N | --devices d0,d1,..] [--chunk C] [--depth D] [--dry-run 1] [oppoint 1-4 | p1 .. p20]
 //
@@ -49,6 +51,10 @@
 #ifndef OFDIS_NOC
 #define OFDIS_NOC 1
 #endif
+#ifndef OFDIS_MODE  // the reference's SELECTMODE: 1 optical flow (run_OF_*_seq, .flo), 2 stereo depth (run_DE_*_seq, .pfm)
+#define OFDIS_MODE 1
+#endif
+#define OFDIS_NCH (OFDIS_MODE == 2 ? 1 : 2)
 
 namespace {
 
@@ -169,7 +175,7 @@ void run_share(const std::vector<Pair>& pairs, const ofdis_params& p0, int width
   sh->chunk_pairs = C;
   const int D = std::max(1, std::min(depth, device_bench > 0 ? device_bench : (n_share + C - 1) / C));  // slots in flight on the device
   const size_t img_bytes = (size_t)width_org * height_org * OFDIS_NOC;
-  const size_t flo_floats = (size_t)2 * width_org * height_org;
+  const size_t flo_floats = (size_t)OFDIS_NCH * width_org * height_org;
   std::vector<Slot> slots(D);
   // chunk buffers: one being decoded, D on the device, one being written
   std::vector<Chunk> bufs(D + 2);
@@ -265,7 +271,11 @@ void run_share(const std::vector<Pair>& pairs, const ofdis_params& p0, int width
         parallel_for(discard ? 0 : c->m, io_threads, [&](int k) {
           if (!c->ok[k]) return;
           std::string err;
+#if OFDIS_MODE == 2
+          if (!ofdis_host::write_pfm(pairs[c->c0 + k].out, c->full + k * flo_floats, width_org, height_org, &err))
+#else
           if (!ofdis_host::write_flo(pairs[c->c0 + k].out, c->full + k * flo_floats, width_org, height_org, &err))
+#endif
             fprintf(stderr, "%s\n", err.c_str());
           else
             ++written;
@@ -517,7 +527,7 @@ int main(int argc, char** argv) {
     }
   }
   ofdis_params p;
-  if (int st = ofdis_host::parse_params(argc, argv, k, width_org, OFDIS_NOC, 1, &p)) return st;
+  if (int st = ofdis_host::parse_params(argc, argv, k, width_org, OFDIS_NOC, OFDIS_MODE, &p)) return st;
   ofdis_host::pad_size(&p, width_org, height_org);
   const int verbosity = p.verbosity;
 

@@ -291,6 +291,30 @@ def test_sequence_driver_matches_the_single_pair_binary(gpu, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("channels,opp", [(1, "2"), (3, "3")])
+def test_stereo_sequence_driver_matches_the_single_pair_binary(gpu, tmp_path, channels, opp):
+    """run_DE_INT_seq / run_DE_RGB_seq (the sequence driver compiled for the reference's SELECTMODE=2): every .pfm is, byte for
+    byte, the file the single-pair run_DE_* writes for that pair -- over two shares and a chunk size that does not divide them."""
+    w, h, n = 320, 192, 11
+    pairs = [(fb, fa) for fa, fb in _write_pairs(tmp_path, n, w, h, channels=channels, seed0=900)]  # negative horizontal motion
+    kind = "INT" if channels == 1 else "RGB"
+    single = []
+    for k, (fa, fb) in enumerate(pairs):
+        fo = str(tmp_path / f"single{k:03d}.pfm")
+        r = subprocess.run([os.path.join(LIB, f"run_DE_{kind}"), fa, fb, fo, opp], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        single.append(open(fo, "rb").read())
+    assert len(set(single)) > 1
+    lst = tmp_path / "de.txt"
+    lst.write_text("".join(f"{fa} {fb} {tmp_path}/seq{k:03d}.pfm\n" for k, (fa, fb) in enumerate(pairs)))
+    r = subprocess.run([os.path.join(LIB, f"run_DE_{kind}_seq"), str(lst), "--devices", "0,0", "--chunk", "4", opp],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    for k in range(n):
+        assert open(tmp_path / f"seq{k:03d}.pfm", "rb").read() == single[k], f"pair {k} differs from run_DE_{kind}'s .pfm"
+
+
+@pytest.mark.gpu
 def test_sequence_driver_rgb_and_unreadable_pairs(gpu, tmp_path):
     """run_OF_RGB_seq (operating point by number); a pair whose image is missing or has another size is reported, the others
     are still written, and the exit status says that not everything went through."""
