@@ -87,41 +87,46 @@ __device__ __forceinline__ void data_term_de(DF D, int noc, float m, float u, fl
 // Inputs row-major: mask, wx [B][h][w], derivs [B][8*noc][h][w]; du in diag layout.  The flow the smoothness weights
 // are taken of, uu = min|max(wx + du, 0) by camera side (refine_variational.cpp:299-316; plain wx before the first
 // solve, :283), is formed here from wx and du instead of being written by one kernel and read back by the next.
-// One workgroup per 32 x 32 tile: wx and du (halo 2) are staged once, the smoothness weight of every pixel of the
+// One workgroup per 32 x 16 tile (16 rows: 0.71 against 0.78 ms per 1024 KITTI-sized pairs with 32 -- levels of 48 / 24 / 12
+// rows fill 16-row tiles; 8 rows: 0.78): wx and du (halo 2) are staged once, the smoothness weight of every pixel of the
 // tile + halo 1 is computed once (the per-pixel version evaluated five of them per pixel), du comes in and the four
 // planes go out through LDS with the rotated enumeration of tv_system_kernel, so that both sides of the diag layout
 // move as contiguous runs instead of one cache line per lane.
-constexpr int DT = 32;                          // output tile edge
-constexpr int DU_W = DT + 4, DS_W = DT + 2;     // uu tile (halo 2), smoothness / wx tiles (halo 1)
-constexpr int DT_PIX = DT * DT / 256;           // pixels per thread
+#ifndef OFDIS_DE_TILE_H
+#define OFDIS_DE_TILE_H 16
+#endif
+constexpr int DT = 32, DTH = OFDIS_DE_TILE_H;   // output tile: DT columns x DTH rows (DTH <= DT)
+constexpr int DU_W = DT + 4, DU_H = DTH + 4;    // uu / wx / du tiles (halo 2)
+constexpr int DS_W = DT + 2, DS_H = DTH + 2;    // smoothness tile (halo 1)
+constexpr int DT_PIX = DT * DTH / 256;          // pixels per thread
 
 __global__ __launch_bounds__(256) void de_system_kernel(const DeSystemArgs a) {
-  constexpr int IN_FLOATS = 3 * DU_W * DU_W + DS_W * DS_W;
-  constexpr int OUT_FLOATS = 4 * DT * DT;
+  constexpr int IN_FLOATS = 3 * DU_W * DU_H + DS_W * DS_H;
+  constexpr int OUT_FLOATS = 4 * DT * DTH;
   __shared__ float lds[IN_FLOATS > OUT_FLOATS ? IN_FLOATS : OUT_FLOATS];
   float* uu_t = lds;                    // halo 2
-  float* wx_t = uu_t + DU_W * DU_W;     // halo 2
-  float* du_t = wx_t + DU_W * DU_W;     // halo 2
-  float* s_t = du_t + DU_W * DU_W;      // halo 1
+  float* wx_t = uu_t + DU_W * DU_H;     // halo 2
+  float* du_t = wx_t + DU_W * DU_H;     // halo 2
+  float* s_t = du_t + DU_W * DU_H;      // halo 1
   const int w = a.t.w, h = a.t.h, noc = a.t.noc;
   const int npx = w * h;
   const int tiles_x = (w + DT - 1) / DT;
   int frame, tile;
-  xcd_frame_map(blockIdx.x, tiles_x * ((h + DT - 1) / DT), a.t.nframes, frame, tile);
+  xcd_frame_map(blockIdx.x, tiles_x * ((h + DTH - 1) / DTH), a.t.nframes, frame, tile);
   if (frame >= a.t.nframes) return;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
-  const int x0 = tx * DT, y0 = ty * DT;
+  const int x0 = tx * DT, y0 = ty * DTH;
   const int tid = threadIdx.x;
   const size_t fo = (size_t)frame * npx;
 
   // stage 0: wx (row-major) and du (diag layout, rotated enumeration) on tile + halo 2 at border-clamped coordinates
-  for (int n = tid; n < DU_W * DU_W; n += 256) {
+  for (int n = tid; n < DU_W * DU_H; n += 256) {
     const int qy = n / DU_W, qx = n - qy * DU_W;
     const int y = clampi(y0 + qy - 2, 0, h - 1), x = clampi(x0 + qx - 2, 0, w - 1);
     wx_t[n] = a.wx[fo + y * w + x];
   }
-  for (int n = tid; n < DU_W * DU_W; n += 256) {
-    const int qy = n % DU_W, r = n / DU_W;
+  for (int n = tid; n < DU_W * DU_H; n += 256) {
+    const int qy = n % DU_H, r = n / DU_H;
     int qx = r - qy;
     if (qx < 0) qx += DU_W;
     const int y = clampi(y0 + qy - 2, 0, h - 1), x = clampi(x0 + qx - 2, 0, w - 1);
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void de_system_kernel(const DeSystemArgs a) {
   }
   __syncthreads();
   // uu: SSE minps / maxps of refine_variational.cpp:303-315 (the second operand, zero, is returned for a NaN)
-  for (int n = tid; n < DU_W * DU_W; n += 256) {
+  for (int n = tid; n < DU_W * DU_H; n += 256) {
     const float v = wx_t[n] + du_t[n];
     uu_t[n] = a.clamp < 0 ? wx_t[n] : (a.clamp == 0 ? (v < 0.0f ? v : 0.0f) : (v > 0.0f ? v : 0.0f));
   }
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256) void de_system_kernel(const DeSystemArgs a) {
   // stage 1: compute_smoothness with vv == 0 (its derivative terms are exact zeros) on tile + halo 1: replicate
   // borders horizontally (image.c:436-464), folded coefficients on the first / last row (image.c:376-399).
   // Only in-image entries are ever read back.
-  for (int n = tid; n < DS_W * DS_W; n += 256) {
+  for (int n = tid; n < DS_W * DS_H; n += 256) {
     const int qy = n / DS_W, qx = n - qy * DS_W;
     const int y = y0 + qy - 1, x = x0 + qx - 1;
     float sval = 0.0f;
@@ -187,24 +192,24 @@ __global__ __launch_bounds__(256) void de_system_kernel(const DeSystemArgs a) {
   for (int k = 0; k < DT_PIX; ++k) {
     const int ry = tid / DT + k * (256 / DT);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) lds[(q * DT + ry) * DT + qx] = res[k][q];
+    for (int q = 0; q < 4; ++q) lds[(q * DTH + ry) * DT + qx] = res[k][q];
   }
   __syncthreads();
   // stage 3: the four planes in diag layout, rotated enumeration (lane -> x-1, y+1)
-  for (int n = tid; n < DT * DT; n += 256) {
-    const int ry = n % DT, r = n / DT;
+  for (int n = tid; n < DT * DTH; n += 256) {
+    const int ry = n % DTH, r = n / DTH;
     const int rx = (r - ry) & (DT - 1);
     const int y = y0 + ry, x = x0 + rx;
     if (y < h && x < w) {
       float* out = a.sys + (size_t)frame * 4 * npx + diag_index(x, y, w, h);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) out[(size_t)q * npx] = lds[(q * DT + ry) * DT + rx];
+      for (int q = 0; q < 4; ++q) out[(size_t)q * npx] = lds[(q * DTH + ry) * DT + rx];
     }
   }
 }
 
 hipError_t launch_de_system(const DeSystemArgs& a, hipStream_t s) {
-  const int tiles = ((a.t.w + DT - 1) / DT) * ((a.t.h + DT - 1) / DT);
+  const int tiles = ((a.t.w + DT - 1) / DT) * ((a.t.h + DTH - 1) / DTH);
   hipLaunchKernelGGL(de_system_kernel, dim3(((a.t.nframes + 7) / 8) * 8 * tiles), dim3(256), 0, s, a);
   return hipGetLastError();
 }
