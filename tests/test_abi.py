@@ -92,6 +92,9 @@ def test_tuning_environment_variables_match_header():
             if name == "ofdis_capi.hip":
                 text = text.replace(init, "")
             code = re.sub(r"//[^\n]*", "", text)  # (comments may mention it)
+            # the one exception: the scratch-poisoning TEST HOOK, read where a context allocates its memory (never on a launch
+            # path; the tests switch it on and off while the library is loaded)
+            code = code.replace('getenv("OFDIS_POISON_SCRATCH")', "")
             assert "getenv(" not in code, f"{name} reads the environment outside the tuning initialisation"
 
 
