@@ -221,7 +221,8 @@ int ofdis_batch_kernel_times(ofdis_batch* b, int kernel_class, double* ms_out, i
  * ------------------------------------------------------------------------------------------- */
 typedef struct ofdis_tuning {
   int gray8;          /* 1: gray 8x8 patches use the 4-lanes-per-patch kernel; 0: generic kernel     OFDIS_NO_GRAY8 -> 0 */
-  int rgb12;          /* 1: RGB 12x12 patches use the compile-time instantiations                  OFDIS_NO_RGB12 -> 0 */
+  int rgb12;          /* 1: RGB 12x12, gray 12x12 and RGB 8x8 patches (flow or stereo, cost function 0 / 1) use the
+                       * 16-lanes-per-patch kernels / the compile-time instantiations; 0: generic kernel   OFDIS_NO_RGB12 -> 0 */
   int rgb12_lpp;      /* lanes per RGB 12x12 patch: 0 = the library's choice (16), 64 = one patch per wavefront, 32 = two,
                        * 16 = four (a 3x3 pixel block per lane for the taps; the exact contract moves the interpolated
                        * values through LDS into the entry order its documented summation needs, the fused contract sums

@@ -10,11 +10,17 @@
 // (patch.cpp:306-324).  A patch is owned by LPP lanes of a wavefront:
 //   * gray P = 8 (operating points 1, 2; patch_optimize_gray8_kernel): 4 lanes per patch, 16 patches per wavefront,
 //     a lane holds two adjacent patch columns (16 entries) -- see the comment at that kernel;
+//   * RGB P = 12 (BASELINE configs[3]), gray P = 12 (operating points 3, 4) and RGB P = 8 (run_OF_RGB's default):
+//     16 lanes per patch, four patches per wavefront, a lane holds a 3x3 / 2x2 pixel block
+//     (patch_optimize_rgb12_kernel under the fused contract, patch_optimize_rgb12x_kernel under the exact one);
 //   * other patches of at most 64 entries: 8 lanes per patch (generic kernel, M = 1);
-//   * larger patches (P = 12, RGB): one patch per wavefront, lane l owns entries l, l+64, ... (M per lane).
-// The template T, its gradients Tx, Ty, the residual and the weights never leave VGPRs; the reductions of an
+//   * everything else (other patch sizes, cost function 2, ofdis_tuning::rgb12 = 0): one patch per wavefront, lane l
+//     owns entries l, l+64, ... (generic kernel, M per lane) -- the mapping whose summation order the exact contract documents.
+// The stereo-depth mode's 1-D search is a template parameter of the first two.
+// The template T, its gradients Tx, Ty, the residual and the weights never leave VGPRs (the exact contract's 16-lane
+// kernel hands the interpolated values from the block layout to the entry-chain layout through LDS); the reductions of an
 // iteration (mean, Tx.r, Ty.r, |r|) are in-lane sums plus DPP / permlane steps in the documented order
-// (ofdis_dev.h, DESIGN.md "Reduction order"); no LDS is used.  The bilinear taps are loads from the padded level
+// (ofdis_dev.h, DESIGN.md "Reduction order").  The bilinear taps are loads from the padded level
 // image, which is 41 KB at op-point 2 and therefore L1/L2 resident; blocks are mapped so that all patches of a
 // frame run on one XCD (its L2 then holds that frame's four planes once).
 #include <math.h>
@@ -1325,7 +1331,8 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s, const ofdis_tu
   // two patches per wavefront (the scalar solve, predicates and every reduction instruction shared by two patches:
   // 929 -> 705 instructions per patch and iteration, 82 -> 127 VGPRs).  Measured on configs[3] the same 19.6 +- 0.4 ms per
   // 16-pair level-1 launch either way -- patches that reset early leave their wavefront's other half running alone
-  // (PMC: 18 % fewer VALU instructions, same time) -- so one patch per wavefront stays the default.
+  // (PMC: 18 % fewer VALU instructions, same time) -- so one patch per wavefront stayed the default until the
+  // 16-lanes-per-patch kernels (round 4) took it over.
   const int rgb12_lpp = tn.rgb12_lpp == 0 ? 16 : tn.rgb12_lpp;
   const bool rgb12 = a.g.novals == 432 && !a.stereo && (a.costfct == 0 || a.costfct == 1) && tn.rgb12;
   // 12x12 patches, RGB or gray, and RGB 8x8 patches, flow or stereo, have their own mapping (16 lanes per patch, four
