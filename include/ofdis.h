@@ -39,7 +39,7 @@ extern "C" {
  * without a bump), ofdis_batch_status and ofdis_batch_upsample_frames were added.  3 (round 6): streams, pinned host memory
  * asynchronous copies and events (ofdis_stream_create, ofdis_host_alloc, ofdis_memcpy_h2d_async / _d2h_async,
  * ofdis_event_*), ofdis_build_id; ofdis_tuning grew to
- * 19 ints (fused_xcu_drop, prep_densify, fused_tall_group) and fused_xcu_spin became a time in microseconds.  A caller checks ofdis_version() ==
+ * 20 ints (fused_xcu_drop, prep_densify, fused_tall_group, fused_rgb_min) and fused_xcu_spin became a time in microseconds.  A caller checks ofdis_version() ==
  * OFDIS_VERSION before passing structs (of_dis_amd/capi.py does at load). */
 #define OFDIS_VERSION 3
 
@@ -228,7 +228,8 @@ typedef struct ofdis_tuning {
                        * values through LDS into the entry order its documented summation needs, the fused contract sums
                        * block-wise)                                                                  OFDIS_RGB12_LPP */
   int fused_tv;       /* 1: gray levels of <= 256 rows and <= 256 columns take the fused TV path (warp + derivatives kernel,
-                       * fused system + SOR kernel)                                                   OFDIS_NO_FUSED -> 0 */
+                       * fused system + SOR kernel), RGB levels of <= 64 rows the fused system + SOR kernel (fused_rgb_min)
+                       *                                                                              OFDIS_NO_FUSED -> 0 */
   int fused_mw_max;   /* frame groups up to which the multi-wave fused TV kernels are launched       OFDIS_FUSED_MW_MAX
                        * (default 512 and at most 1024 frames per batch; 0 = never; >= 2^30 = always) */
   int fused_split;    /* 1: multi-wave kernel with producer + solver wavefronts per iteration  OFDIS_FUSED_NO_SPLIT -> 0 */
@@ -264,6 +265,10 @@ typedef struct ofdis_tuning {
   int fused_tall_group; /* levels of 65 ... 96 rows (the finest level of a 1080p / 4K gray pair is 120 x 68): 1 = the fused TV
                        * kernel takes up to three strips per workgroup, their rows beyond the 64th sharing ONE wavefront
                        * (2 .. 7: at most that many); 0 = two wavefronts per strip   OFDIS_TALL_GROUP, OFDIS_NO_TALL_GROUP -> 0 */
+  int fused_rgb_min;  /* RGB levels of <= 64 rows take the fused system + SOR kernel (three derivative record arrays; with
+                       * fused_tv and finish_fusion) in contexts of at least this many frames: 0 = the library's choice (16:
+                       * below it the one-launch-per-stage kernels are as fast), 1 = always, 2^30 = never
+                       *                                                                            OFDIS_FUSED_RGB_MIN */
 } ofdis_tuning;
 int ofdis_get_tuning(ofdis_tuning* out);
 int ofdis_set_tuning(const ofdis_tuning* in);

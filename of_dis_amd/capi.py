@@ -44,7 +44,7 @@ class OfdisTuning(C.Structure):
     (0 = exact arithmetic, 1 = the FMA / fast-reciprocal tolerance contract)."""
     _fields_ = [(n, C.c_int) for n in ("gray8", "rgb12", "rgb12_lpp", "fused_tv", "fused_mw_max", "fused_split",
                                        "finish_fusion", "fused_strip", "prep_band_rows", "graph", "flow_dma", "flow_whole",
-                                       "fused_xcu_max", "fused_tp_pipe", "fused_xcu_spin", "contract", "fused_xcu_drop", "prep_densify", "fused_tall_group")]
+                                       "fused_xcu_max", "fused_tp_pipe", "fused_xcu_spin", "contract", "fused_xcu_drop", "prep_densify", "fused_tall_group", "fused_rgb_min")]
 
 
 class OfdisError(RuntimeError):

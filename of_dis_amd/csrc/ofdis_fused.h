@@ -74,6 +74,54 @@ __device__ __forceinline__ void data_term_gray(const FDer& D, float u, float v, 
   a11 *= 3; a12 *= 3; a22 *= 3; b1 *= 3; b2 *= 3;
 }
 
+// Data term of one RGB pixel (opticalflow_aux.c:383-427 = ofdis_tvmath.h data_term(), noc == 3, mask 1), the same operations
+// in the same order with the quotients written out as above; a masked pixel is an all-zero record in every channel (the
+// argument of data_term_gray holds channel by channel).
+template <bool BRIGHT>
+__device__ __forceinline__ void data_term_rgb(const FDer (&D)[3], float u, float v, float hd3, float hg3, float& a11,
+                                              float& a12, float& a22, float& b1, float& b2) {
+  a11 = 0.0f; a12 = 0.0f; a22 = 0.0f; b1 = 0.0f; b2 = 0.0f;
+  if (BRIGHT) {
+    float t[3];
+    FDen dn[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      t[c] = D[c].iz + D[c].ix * u + D[c].iy * v;
+      dn[c] = fden(D[c].ix * D[c].ix + D[c].iy * D[c].iy + DATANORM);
+    }
+    const float tmp = fdiv_by_sqrt(hd3, fdiv_by(t[0] * t[0], dn[0]) + fdiv_by(t[1] * t[1], dn[1]) + fdiv_by(t[2] * t[2], dn[2]) + EPS_COLOR);
+    const float tt[3] = {fdiv_by(tmp, dn[0]), fdiv_by(tmp, dn[1]), fdiv_by(tmp, dn[2])};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      a11 += tt[c] * D[c].ix * D[c].ix;
+      a12 += tt[c] * D[c].ix * D[c].iy;
+      a22 += tt[c] * D[c].iy * D[c].iy;
+      b1 -= tt[c] * D[c].iz * D[c].ix;
+      b2 -= tt[c] * D[c].iz * D[c].iy;
+    }
+  }
+  FDen d1[3], d2[3];
+  float t1[3], t2[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    d1[c] = fden(D[c].ixx * D[c].ixx + D[c].ixy * D[c].ixy + DATANORM);
+    d2[c] = fden(D[c].iyy * D[c].iyy + D[c].ixy * D[c].ixy + DATANORM);
+    t1[c] = D[c].ixz + D[c].ixx * u + D[c].ixy * v;
+    t2[c] = D[c].iyz + D[c].ixy * u + D[c].iyy * v;
+  }
+  const float tmp = fdiv_by_sqrt(hg3, fdiv_by(t1[0] * t1[0], d1[0]) + fdiv_by(t2[0] * t2[0], d2[0]) + fdiv_by(t1[1] * t1[1], d1[1]) +
+                                          fdiv_by(t2[1] * t2[1], d2[1]) + fdiv_by(t1[2] * t1[2], d1[2]) + fdiv_by(t2[2] * t2[2], d2[2]) + EPS_GRAD);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float w1 = fdiv_by(tmp, d1[c]), w2 = fdiv_by(tmp, d2[c]);
+    a11 += w1 * D[c].ixx * D[c].ixx + w2 * D[c].ixy * D[c].ixy;
+    a12 += w1 * D[c].ixx * D[c].ixy + w2 * D[c].ixy * D[c].iyy;
+    a22 += w2 * D[c].iyy * D[c].iyy + w1 * D[c].ixy * D[c].ixy;
+    b1 -= w1 * D[c].ixx * D[c].ixz + w2 * D[c].ixy * D[c].iyz;
+    b2 -= w2 * D[c].iyy * D[c].iyz + w1 * D[c].ixy * D[c].ixz;
+  }
+}
+
 // Workgroup barrier of the multi-wave variant's step loop.  Only LDS traffic crosses wavefronts there (the du/dv ring), so
 // only the LDS counter is drained: __syncthreads() also waits for vmcnt(0), i.e. for the global row loads that are
 // deliberately kept 3-5 steps in flight, and would expose one memory latency per step.

@@ -84,14 +84,16 @@ constexpr int SP_MAX_ITERS = 6;  // MODE 2: 2 wavefronts per iteration, 12 per w
 //         the slot of row t+1 and consuming the slot of row t -- and the solver hands the finished du/dv row to the next
 //         iteration's producer through the same LDS ring MODE 1 uses.  A lone wavefront issues one instruction per ~6
 //         clocks (dependent-issue latency), so halving the instructions per wavefront and step nearly halves the step.
-template <int NS, bool BRIGHT, int MODE>
+// NOC = 3 (round 6, MODE 0 only): RGB levels of at most 64 rows -- three derivative record arrays [c][records][8] (written by
+// derivatives_kernel in its record form, ofdis_tv.hip), the data term of opticalflow_aux.c:383-427; everything else is shared.
+template <int NS, bool BRIGHT, int MODE, int NOC = 1>
 // MODE 1 is held to 168 registers = three wavefronts per SIMD (amdgpu_waves_per_eu): three workgroups of four iterations per
 // compute unit instead of two.  That only pays without scratch: with the (wx, wy) ring and the run buffer of the wavefront that
 // writes the flow in registers (24 that one of a workgroup's wavefronts uses) the allocator spilled 7 and level 3 of the
 // headline took 5.84 instead of 4.41 ms; with both in LDS (wdring, obring: two ds_write and two ds_read per step of that one
 // wavefront) nothing spills: 4.30-4.34 -> 4.13-4.15 ms on the same box (fused contract; exact: 167 registers, unchanged time).
 __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * MW_MAX_ITERS : 256))
-__attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(const FusedArgs a, const int R) {
+__attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : (NOC == 3 ? 2 : 1)))) void tv_fused_kernel(const FusedArgs a, const int R) {
   constexpr int U = 6;
   constexpr bool MW = MODE != 0;
   constexpr int MAXIT = MODE == 2 ? SP_MAX_ITERS : MW_MAX_ITERS;
@@ -112,7 +114,9 @@ __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(con
   // (MODE 1 with the step loop compiled once per role -- the last iteration's wavefront writes the flow, the others hand their
   // rows on: 223 instead of 292 instructions per step for the others, 278 for the last -- measured 4.48 against 4.29 ms on the
   // same box, 4.46 with the roles rotated between the workgroups that share a compute unit: not kept)
-  constexpr int PDW = 5, PDD = 3;
+  // (RGB: the derivative rows two steps ahead -- a step is twice as long, and 24 registers less keep the kernel at two
+  // wavefronts per SIMD)
+  constexpr int PDW = 5, PDD = NOC == 3 ? 2 : 3;
   constexpr int PDU = MODE == 2 ? 4 : (MODE == 1 ? 3 : PDW);  // read-ahead of du/dv (MODE 1 / 2: from LDS, in / one step before the step of their first use)
   constexpr int LAG = MODE == 2 ? SP_LAG : MW_LAG;
   static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
@@ -153,7 +157,11 @@ __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(con
     return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)s0 * strip_recs * rec_floats), 0,
                                              (int)(nst * strip_recs * rec_floats * 4), 0x00020000);
   };
-  const __amdgpu_buffer_rsrc_t rsD = rsrc(a.d8, 8), rsW = rsrc(a.wrec, 2), rsU = rsrc(a.uv, 2);
+  const __amdgpu_buffer_rsrc_t rsW = rsrc(a.wrec, 2), rsU = rsrc(a.uv, 2);
+  // (RGB: channel c's records follow channel c-1's for all frames of this launch)
+  const __amdgpu_buffer_rsrc_t rsD = rsrc(a.d8, 8);
+  const __amdgpu_buffer_rsrc_t rsD1 = rsrc(a.d8 + (NOC == 3 ? (size_t)a.t.nframes * w * h * 8 : 0), 8);
+  const __amdgpu_buffer_rsrc_t rsD2 = rsrc(a.d8 + (NOC == 3 ? (size_t)a.t.nframes * w * h * 16 : 0), 8);
   const int vrec = fl * (int)strip_recs + j;  // this lane's record within a diag row 0 of its strip
   const int vo8 = vrec * 32, vo2 = vrec * 8;
   auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
@@ -168,7 +176,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(con
   const bool aos_out = MODE != 2 && a.flow_out != nullptr;
 
   FRow W[6];
-  FDer D[3];
+  FDer D[PDD][NOC];
   float uu[3], vv[3], sm[3];
   FSlot slot[6];
 #pragma unroll
@@ -180,8 +188,11 @@ __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(con
   for (int r = 0; r < 3; ++r) {
     uu[r] = vv[r] = 0.0f;
     sm[r] = 1.0f;
-    D[r] = FDer{0, 0, 0, 0, 0, 0, 0, 0};
   }
+#pragma unroll
+  for (int r = 0; r < PDD; ++r)
+#pragma unroll
+    for (int c = 0; c < NOC; ++c) D[r][c] = FDer{0, 0, 0, 0, 0, 0, 0, 0};
   float ru[NS], rv[NS], ru2[NS], rv2[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) { ru[s] = rv[s] = ru2[s] = rv2[s] = 0.0f; }
@@ -266,13 +277,20 @@ __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(con
       r.du = asf(q0); r.dv = asf(q1);
     }  // MODE 1 / 2: du/dv follow from the LDS ring, PDW - PDU steps later
   };
-  auto load_d = [&](FDer& r, int drow) {
-    const int o = drow * h * 32;
-    const auto lo = __builtin_amdgcn_raw_buffer_load_b128(rsD, vo8, o, 0);
-    const auto hi = __builtin_amdgcn_raw_buffer_load_b128(rsD, vo8 + 16, o, 0);
+  auto load_d1 = [&](FDer& r, const __amdgpu_buffer_rsrc_t& rs, int o) {
+    const auto lo = __builtin_amdgcn_raw_buffer_load_b128(rs, vo8, o, 0);
+    const auto hi = __builtin_amdgcn_raw_buffer_load_b128(rs, vo8 + 16, o, 0);
     const unsigned l0 = lo[0], l1 = lo[1], l2 = lo[2], l3 = lo[3], h0 = hi[0], h1 = hi[1], h2 = hi[2], h3 = hi[3];
     r.ix = asf(l0); r.iz = asf(l1); r.ixx = asf(l2); r.ixz = asf(l3);
     r.iy = asf(h0); r.ixy = asf(h1); r.iyz = asf(h2); r.iyy = asf(h3);
+  };
+  auto load_d = [&](FDer (&r)[NOC], int drow) {
+    const int o = drow * h * 32;
+    load_d1(r[0], rsD, o);
+    if constexpr (NOC == 3) {
+      load_d1(r[1], rsD1, o);
+      load_d1(r[2], rsD2, o);
+    }
   };
 
   // ring index of diag row rho is (rho + 3) mod ring size; the loop variable is k = t + 3, u = k % 6,
@@ -318,7 +336,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(con
         if constexpr (MW) ring_uv(W[(u + PDU) % 6], tauW - (PDW - PDU));
         rowW = next_row(rowW);
         ++tauW;
-        load_d(D[(u + PDD) % 3], rowD);
+        load_d(D[(u + PDD) % PDD], rowD);
         rowD = next_row(rowD);
         // ---- (2) uu, vv of row t+3 (refine_variational.cpp:210-216: uu = wx + du of before this call)
         {
@@ -359,7 +377,8 @@ __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(con
           const FRow& rm = W[u % 6];        // row tau-1
           const FRow& rp = W[(u + 2) % 6];  // row tau+1
           float a11, a12, a22, b1, b2;
-          data_term_gray<BRIGHT>(D[(u + 1) % 3], rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
+          if constexpr (NOC == 1) data_term_gray<BRIGHT>(D[(u + 1) % PDD][0], rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
+          else data_term_rgb<BRIGHT>(D[(u + 1) % PDD], rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
           const float wx_u = from_prev(rm.wx), wy_u = from_prev(rm.wy);
           const float wx_d = from_next(rp.wx), wy_d = from_next(rp.wy);
           const float sh_l = slot[u % 6].sh;         // (s_l + sc), 0 on column 0
@@ -485,7 +504,8 @@ __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : 1))) void tv_fused_kernel(con
 
 bool tv_fused_supported(const TvGeom& t, int iterations) {
   // (65 ... 256 rows: the two- to four-wavefront form of the throughput mapping, ofdis_fused_tall.hip)
-  return (t.noc == 1 && t.h >= 2 && t.h <= 64 && t.w >= 16 && iterations >= 1 && iterations <= 3) || tv_fused_tall_supported(t, iterations);
+  return ((t.noc == 1 || t.noc == 3) && t.h >= 2 && t.h <= 64 && t.w >= 16 && iterations >= 1 && iterations <= 3) ||
+         tv_fused_tall_supported(t, iterations);
 }
 
 bool tv_fused_params_ok(float qa, float hd3, float hg3) {
@@ -506,6 +526,7 @@ constexpr int MW_MAX_BATCH_FRAMES = 1024;
 int tv_fused_mode(const FusedArgs& a, const FusedXcu* x) {
   const int h = a.t.h;
   if (h > 64) return 0;  // two to four wavefronts per strip (ofdis_fused_tall.hip): the throughput mapping only, whatever the batch
+  if (a.t.noc == 3) return 0;  // RGB: the throughput mapping, one frame per strip
   const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
   const int groups = (a.t.nframes + 64 / R - 1) / (64 / R);
   const int total = a.total_frames > 0 ? a.total_frames : a.t.nframes;
@@ -537,6 +558,19 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow, 
   const int mode = tv_fused_mode(a, x);
   if (wrote_flow) *wrote_flow = a.flow_out != nullptr;  // every mapping writes the refined AoS flow itself
   if (mode == 3) return launch_tv_fused_xcu(a, *x, waves, R, s);
+  if (a.t.noc == 3) {
+    if (a.S != 1) return hipErrorInvalidValue;
+#define OFDIS_FUSED_RGB(NS)                                                                                            \
+  if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 0, 3>), dim3(blocks), dim3(256), 0, s, a, R);              \
+  else hipLaunchKernelGGL((tv_fused_kernel<NS, false, 0, 3>), dim3(blocks), dim3(256), 0, s, a, R)
+    switch (a.iterations) {
+      case 1: OFDIS_FUSED_RGB(1); break;
+      case 2: OFDIS_FUSED_RGB(2); break;
+      default: OFDIS_FUSED_RGB(3); break;
+    }
+#undef OFDIS_FUSED_RGB
+    return hipGetLastError();
+  }
 #define OFDIS_FUSED_LAUNCH(NS)                                                                                         \
   if (mode == 2) {                                                                                                     \
     if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 2>), dim3(waves), dim3(128 * a.n_inner), 0, s, a, R);    \

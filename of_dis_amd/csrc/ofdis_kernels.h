@@ -70,6 +70,13 @@ struct DerivArgs {
   int im1_padded, pad, tmp_w, tmp_h;
   const float* im2w;
   float* out;  // [B][8][noc][h][w] row-major
+  // record form (the RGB fused TV path; ofdis_tv.hip): with rec_d8 the planes are not written; [noc][B][w*h][8] derivative
+  // records and [B][w*h][2] (wx, wy) records in the diag layout instead, zeroed by the warp's mask
+  float* rec_d8 = nullptr;
+  float* rec_w = nullptr;
+  const float* mask = nullptr;  // row-major [B][h][w]
+  const float* wx = nullptr;    // row-major
+  const float* wy = nullptr;
 };
 
 // image_warp + get_derivatives of the fused TV path in one row-marching kernel (ofdis_prep.hip): densified AoS flow and the

@@ -195,9 +195,16 @@ __device__ __forceinline__ float v5(const float* t, int pitch, int qy, int qx, i
 
 // (The fused TV path has its own warp + derivatives kernel, ofdis_prep.hip; this tiled one serves RGB / tall levels and
 // the per-function entry point.)
-template <bool PADDED>
+// RECORDS (round 6, the RGB fused TV path): instead of the 8 * noc row-major planes the kernel writes what tv_fused_kernel
+// walks -- per channel an array of 8-float records {Ix, Iz, Ixx, Ixz, Iy, Ixy, Iyz, Iyy} in the diag layout (ofdis_dev.h:
+// diag_index; all zero where the warp's mask is zero, see ofdis_fused.h), channel c's array after channel c-1's for all frames
+// of the launch, and the (wx, wy) records of the same layout -- staged per tile in LDS and written with the rotated
+// enumeration of tv_system_kernel: a wavefront's lanes walk anti-diagonals of the tile, i.e. runs of consecutive records.
+template <bool PADDED, bool RECORDS>
 __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
-  __shared__ float lds[2 * DA_H * DA_W + 2 * DX_H * DX_W];
+  __shared__ __attribute__((aligned(16))) float lds[2 * DA_H * DA_W + 2 * DX_H * DX_W + (RECORDS ? DT_H * DT_W * 10 : 0)];
+  float* rec_t = lds + 2 * DA_H * DA_W + 2 * DX_H * DX_W;  // [pixel of the tile][8]
+  float* wrec_t = rec_t + DT_H * DT_W * 8;                 // [pixel of the tile][2]
   float* avg_t = lds;
   float* iz_t = avg_t + DA_H * DA_W;
   float* ix_t = iz_t + DA_H * DA_W;
@@ -256,7 +263,19 @@ __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
       res[6] = h5(iz_t, DA_W, ay, ax);
       res[7] = v5(iz_t, DA_W, ay, ax, yc, h);
       const int y = y0 + ry, x = x0 + qx;
-      if (y < h && x < w) {
+      if constexpr (RECORDS) {
+        const bool in = y < h && x < w;
+        const float m = in ? a.mask[(size_t)frame * npx + y * w + x] : 0.0f;
+        f4* st = reinterpret_cast<f4*>(rec_t + (ry * DT_W + qx) * 8);
+        const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        st[0] = m != 0.0f ? (f4){res[0], res[2], res[3], res[6]} : zero;  // Ix, Iz, Ixx, Ixz
+        st[1] = m != 0.0f ? (f4){res[1], res[4], res[7], res[5]} : zero;  // Iy, Ixy, Iyz, Iyy
+        if (c == 0) {
+          const size_t o = (size_t)frame * npx + (in ? y * w + x : 0);
+          wrec_t[(ry * DT_W + qx) * 2] = a.wx[o];
+          wrec_t[(ry * DT_W + qx) * 2 + 1] = a.wy[o];
+        }
+      } else if (y < h && x < w) {
         float* out = a.out + ((size_t)frame * 8 * noc + c) * npx + y * w + x;
         const size_t ks = (size_t)noc * npx;
 #pragma unroll
@@ -264,6 +283,27 @@ __global__ __launch_bounds__(256) void derivatives_kernel(const DerivArgs a) {
       }
     }
     __syncthreads();
+    if constexpr (RECORDS) {
+      float* recs = a.rec_d8 + ((size_t)c * a.t.nframes + frame) * npx * 8;
+      for (int n = tid; n < DT_H * DT_W; n += 256) {
+        const int ry = n % DT_H, r = n / DT_H;
+        const int rx = (r - ry) & (DT_W - 1);
+        const int y = y0 + ry, x = x0 + rx;
+        if (y < h && x < w) {
+          const size_t idx = diag_index(x, y, w, h);
+          const f4* st = reinterpret_cast<const f4*>(rec_t + (ry * DT_W + rx) * 8);
+          f4* out = reinterpret_cast<f4*>(recs + idx * 8);
+          out[0] = st[0];
+          out[1] = st[1];
+          if (c == 0) {
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<f2v*>(a.rec_w + ((size_t)frame * npx + idx) * 2) =
+                *reinterpret_cast<const f2v*>(wrec_t + (ry * DT_W + rx) * 2);
+          }
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -271,8 +311,12 @@ hipError_t launch_derivatives(const DerivArgs& a, hipStream_t s) {
   if (a.t.h < 4) return hipErrorInvalidValue;  // the reference's vertical filter reads rows 0..3
   const int tiles = ((a.t.w + DT_W - 1) / DT_W) * ((a.t.h + DT_H - 1) / DT_H);
   const dim3 g(((a.t.nframes + 7) / 8) * 8 * tiles), b(256);
-  if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true>), g, b, 0, s, a);
-  else hipLaunchKernelGGL((derivatives_kernel<false>), g, b, 0, s, a);
+  if (a.rec_d8) {
+    if (!a.rec_w || !a.mask || !a.wx || !a.wy) return hipErrorInvalidValue;
+    if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((derivatives_kernel<false, true>), g, b, 0, s, a);
+  } else if (a.im1_padded) hipLaunchKernelGGL((derivatives_kernel<true, false>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((derivatives_kernel<false, false>), g, b, 0, s, a);
   return hipGetLastError();
 }
 

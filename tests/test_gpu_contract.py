@@ -244,6 +244,20 @@ def test_fused_contract_rgb_8x8(gpu, orc, size, opp, cost, seed):
     _check(orc, p, size[0], size[1], ref, ex, fu, f"rgb op{opp} cost {cost}")
 
 
+@pytest.mark.parametrize("size,seed", [((1024, 436), 87), ((320, 240), 88)])
+def test_fused_contract_rgb_on_the_fused_tv_kernel(gpu, orc, size, seed):
+    """run_OF_RGB at its default operating point with the RGB levels on the fused system + SOR kernel (forced), fused
+    arithmetic contract, against the plain RGB reference build."""
+    p, pa, pb, _, _ = synth_case(size[0], size[1], seed, 3, 2, 1)
+    ref = _plain_ref("rgb").flow(p, pa[0], pa[1], pa[2], pb[0])
+    old = gpu.set_tuning(fused_rgb_min=1)
+    try:
+        ex, fu = _both_contracts(gpu, lambda: gpu.flow(p, pa[0], pa[1], pa[2], pb[0]))
+    finally:
+        gpu.restore_tuning(old)
+    _check(orc, p, size[0], size[1], ref, ex, fu, f"rgb op2 {size}, fused TV kernel")
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("seed", [4242, 4243, 4244])
 def test_fused_contract_config4_tail(gpu, orc, seed):

@@ -331,6 +331,40 @@ def test_rgb_8x8_flow_bit_exact(gpu, orc, size, opp, cost, rgb12):
         assert_bits_equal(got, R.flow(p, pa[0], pa[1], pa[2], pb[0]), "rgb 8x8 flow vs reference sources")
 
 
+@pytest.mark.parametrize("pipe", [0, 2])
+@pytest.mark.parametrize("size,opp,nfr", [((1024, 436), 2, 5), ((320, 240), 2, 9), ((333, 251), 3, 3), ((500, 100), 2, 4)])
+def test_rgb_batches_on_the_fused_tv_kernel(gpu, orc, size, opp, nfr, pipe):
+    """run_OF_RGB batches with their levels of at most 64 rows on the fused system + SOR kernel (forced for these small
+    contexts; operating point 3: only the coarse levels qualify, the finer ones keep the per-stage kernels in the same pass),
+    also cut into pipelined sub-batches (frame views of the record arrays): every frame's flow is the oracle's, bit for bit,
+    and the same as with the kernel switched off."""
+    cases = [synth_case(size[0], size[1], 5200 + k, 3, opp, 1) for k in range(min(nfr, 3))]
+    p = cases[0][0]
+    refs = [orc.flow(c[0], c[1][0], c[1][1], c[1][2], c[2][0]) for c in cases]
+    outs = {}
+    for force in (1, 1 << 30):
+        old = gpu.set_tuning(fused_rgb_min=force)
+        try:
+            b = gpu.Batch(p, nfr)
+            if pipe:
+                b.set_pipeline(pipe)
+            for slot in range(nfr):
+                c = cases[slot % len(cases)]
+                b.upload(slot, c[1][0], c[1][1], c[1][2], c[2][0])
+            b.timing(True) if not pipe else None
+            b.run()
+            outs[force] = b.download_all()
+            if not pipe:
+                names = [n for k, n in enumerate(gpu.K_NAMES) if b.kernel_time(k)[1]]
+                assert ("tv_fused" in names) == (force == 1), names
+            b.close()
+        finally:
+            gpu.restore_tuning(old)
+    for slot in range(nfr):
+        assert_bits_equal(outs[1][slot], refs[slot % len(cases)], f"slot {slot}, fused RGB levels")
+        assert_bits_equal(outs[1 << 30][slot], refs[slot % len(cases)], f"slot {slot}, per-stage kernels")
+
+
 @pytest.mark.parametrize("size,cost", [((320, 240), 1), ((320, 240), 0), ((203, 131), 1)])
 def test_rgb_two_patches_per_wavefront(gpu, orc, size, cost):
     """ofdis_tuning.rgb12_lpp = 32: the RGB 12x12 patch kernel with two patches per wavefront (32 lanes each, two

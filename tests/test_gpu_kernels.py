@@ -322,6 +322,43 @@ def test_random_varref_levels(gpu, orc, seed, tv_variant):
     assert_bits_equal(got[0], ref, f"seed {seed}: {w}x{h} noc={noc} innerit={p.tv_innerit} solverit={p.tv_solverit}")
 
 
+@pytest.mark.parametrize("seed", range(36))
+def test_rgb_levels_on_the_fused_system_and_solver(gpu, orc, seed):
+    """RGB levels of at most 64 rows on the fused system + SOR kernel (ofdis_tuning.fused_rgb_min = 1 forces it for these
+    one- to five-frame contexts; by default contexts of 16 frames and more take it): the warp kernel, the derivatives kernel
+    in its record form (three arrays of 8-float records in the diag layout, zeroed by the mask) and tv_fused_kernel with the
+    RGB data term give the bits of n_inner x (tv_system + SOR) -- random geometry (16 <= w < 140, 4 <= h <= 64), TV
+    parameters with and without the brightness term, 1-3 sweeps, a flow with out-of-image displacements."""
+    import gen_synth
+    from of_dis_amd.params import oppoint
+    rng = np.random.default_rng(33000 + seed + _SEED_OFFSET)
+    w = int(rng.integers(16, 140))
+    h = int(rng.integers(4, 65)) if seed % 6 else 64
+    nfr = int(rng.integers(1, 6))
+    p = oppoint(2, w, h, noc=3).copy(sc_f=0, sc_l=0, p_samp_s=4, imgpadding=4,
+                                     tv_innerit=int(rng.integers(1, 4)), tv_solverit=int(rng.integers(1, 4)),
+                                     tv_sor=float(rng.choice([1.0, 1.6, 1.95])), tv_alpha=float(rng.choice([1.0, 10.0, 40.0])),
+                                     tv_gamma=float(rng.choice([0.0, 10.0, 20.0])), tv_delta=float(rng.choice([0.0, 5.0, 15.0])))
+    p.width, p.height = w, h
+    ims_a, ims_b, flows, refs = [], [], [], []
+    for k in range(nfr):
+        ia, ib, _ = gen_synth.make_pair(w, h, 33100 + 7 * seed + k, 3)
+        pa, pb = orc.build_pyramid(p, ia), orc.build_pyramid(p, ib)
+        flow = rand_planes(rng, h, w, 2, scale=float(rng.choice([0.2, 1.5, 6.0])))
+        flow[rng.integers(0, h), rng.integers(0, w)] = (3.0 * w, -3.0 * h)
+        ims_a.append(pa[0][0]); ims_b.append(pb[0][0]); flows.append(flow)
+        refs.append(orc.varref_level(p, 0, pa[0][0], pb[0][0], flow))
+    old = gpu.set_tuning(fused_rgb_min=1)
+    try:
+        got = gpu.varref_level(p, 0, np.stack(ims_a), np.stack(ims_b), np.stack(flows))
+    finally:
+        gpu.restore_tuning(old)
+    plain = gpu.varref_level(p, 0, np.stack(ims_a), np.stack(ims_b), np.stack(flows))   # (one frame: the per-stage kernels)
+    for k in range(nfr):
+        assert_bits_equal(got[k], refs[k], f"seed {seed}: {w}x{h} rgb frame {k} innerit={p.tv_innerit} solverit={p.tv_solverit} delta={p.tv_delta}")
+        assert_bits_equal(plain[k], refs[k], f"seed {seed}: per-stage kernels, frame {k}")
+
+
 @pytest.mark.parametrize("w,h,solverit", [(59, 59, 3), (102, 57, 2), (121, 76, 2), (62, 58, 2), (200, 130, 1), (16, 4, 3)])
 def test_one_fixed_point_iteration_reads_no_scratch(gpu, orc, monkeypatch, w, h, solverit):
     """A level with ONE fixed-point iteration (tv_innerit = 1 at level 0) on the fused path never writes the du / dv array,

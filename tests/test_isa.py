@@ -93,14 +93,15 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
 @pytest.mark.parametrize("pattern,max_vgprs,what", [
     # (three wavefronts per SIMD -- 168 registers, forced with a launch bound -- measured 5 % slower than the 181 the compiler
     # takes by itself: profiles/README.md round 3)
-    ("tv_fused_kernelILi3ELb1ELi0EE", 192, "tv_fused_kernel<3, true, 0>, throughput mapping: two wavefronts per SIMD"),
-    ("tv_fused_kernelILi3ELb1ELi2EE", 168, "tv_fused_kernel<3, true, 2>, split mapping: 12 wavefronts of a workgroup on one CU"),
+    ("tv_fused_kernelILi3ELb1ELi0ELi1EE", 192, "tv_fused_kernel<3, true, 0>, throughput mapping: two wavefronts per SIMD"),
+    ("tv_fused_kernelILi3ELb1ELi0ELi3EE", 256, "tv_fused_kernel<3, true, 0, 3>, RGB levels on the throughput mapping (derivative ring of two rows): two wavefronts per SIMD"),
+    ("tv_fused_kernelILi3ELb1ELi2ELi1EE", 168, "tv_fused_kernel<3, true, 2>, split mapping: 12 wavefronts of a workgroup on one CU"),
     ("tv_fused_xcu_kernelILi3ELb1EE", 128, "tv_fused_xcu_kernel<3, true>, cross-CU mapping: one wavefront per SIMD, four workgroups per CU at most"),
     ("patch_optimize_gray8_kernelILi0ELb0EE", 128, "gray 8x8 patch kernel: four wavefronts per SIMD"),
     ("patch_optimize_kernelILi7ELi64ELi432ELi1EE", 84, "RGB 12x12 patch kernel, L1 cost: six wavefronts per SIMD"),
     ("patch_optimize_rgb12x_kernelILi1ELi3ELb0ELi3EE", 168, "RGB 12x12 patch kernel of the exact contract (blocks for the taps, chains for the sums): three wavefronts per SIMD"),
     ("patch_optimize_rgb12_kernelILi1ELi3ELb0ELi3EE", 168, "RGB 12x12 patch kernel of the fused contract (3x3 pixel block per lane, Ty in LDS): three wavefronts per SIMD"),
-    ("tv_fused_kernelILi3ELb1ELi1EE", 168, "tv_fused_kernel<3, true, 1>, iteration-pipelined mapping: three wavefronts per SIMD (three workgroups of four iterations per CU)"),
+    ("tv_fused_kernelILi3ELb1ELi1ELi1EE", 168, "tv_fused_kernel<3, true, 1>, iteration-pipelined mapping: three wavefronts per SIMD (three workgroups of four iterations per CU)"),
     ("tv_fused_tall_kernelILi3ELb1ELb", 216, "tv_fused_tall_kernel<3, true> (two to four wavefronts per strip, 65-256 rows): two wavefronts per SIMD"),
     ("densify_kernelILb1EE", 64, "densify_kernel<true>: eight wavefronts per SIMD"),
     ("densify_quad_kernel", 64, "densify_quad_kernel: eight wavefronts per SIMD"),
@@ -152,7 +153,7 @@ def test_rgb12_fused_kernel_spills_only_outside_its_iteration_loop():
 
 
 @pytest.mark.parametrize("pattern,blocks_per_cu,what", [
-    ("tv_fused_kernelILi3ELb1ELi1EE", 3, "iteration-pipelined fused TV: three workgroups of four wavefronts per compute unit"),
+    ("tv_fused_kernelILi3ELb1ELi1ELi1EE", 3, "iteration-pipelined fused TV: three workgroups of four wavefronts per compute unit"),
     ("patch_optimize_rgb12_kernelILi1ELi3ELb0ELi3EE", 3, "fused contract's RGB 12x12 patch kernel: three blocks of four wavefronts per compute unit"),
     ("patch_optimize_rgb12x_kernelILi1ELi3ELb0ELi3EE", 3, "exact contract's RGB 12x12 patch kernel: three blocks of four wavefronts per compute unit"),
 ])
