@@ -469,6 +469,13 @@ def test_random_configurations(gpu, orc, seed):
     ref = orc.flow(p, pa[0], pa[1], pa[2], pb[0])
     got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
     assert_bits_equal(got, ref, f"seed {seed}: {w}x{h} noc={noc} {over}")
+    if noc == 3 and p.usetvref:  # ... and with the RGB levels of <= 64 rows forced onto the fused system + SOR kernel
+        old = gpu.set_tuning(fused_rgb_min=1)
+        try:
+            got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
+        finally:
+            gpu.restore_tuning(old)
+        assert_bits_equal(got, ref, f"seed {seed}: {w}x{h} rgb, fused TV kernel forced, {over}")
 
 
 @pytest.mark.parametrize("seed", range(16))
