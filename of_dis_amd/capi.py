@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "ofdis_build_id", "ofdis_stream_create", "ofdis_stream_destroy", "ofdis_host_alloc", "ofdis_host_free", "ofdis_memcpy_h2d_async", "ofdis_memcpy_d2h_async",
     "ofdis_event_create", "ofdis_event_destroy", "ofdis_event_record", "ofdis_stream_wait_event", "ofdis_event_sync",
 ]
-OFDIS_VERSION = 3  # include/ofdis.h: the struct layouts below (OfdisTuning: 19 ints) belong to this ABI version
+OFDIS_VERSION = 3  # include/ofdis.h: the struct layouts below (OfdisTuning: 20 ints) belong to this ABI version
 
 
 class OfdisTuning(C.Structure):
