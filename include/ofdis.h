@@ -265,9 +265,10 @@ typedef struct ofdis_tuning {
   int fused_tall_group; /* levels of 65 ... 96 rows (the finest level of a 1080p / 4K gray pair is 120 x 68): 1 = the fused TV
                        * kernel takes up to three strips per workgroup, their rows beyond the 64th sharing ONE wavefront
                        * (2 .. 7: at most that many); 0 = two wavefronts per strip   OFDIS_TALL_GROUP, OFDIS_NO_TALL_GROUP -> 0 */
-  int fused_rgb_min;  /* RGB levels of <= 64 rows take the fused system + SOR kernel (three derivative record arrays; with
-                       * fused_tv and finish_fusion) in contexts of at least this many frames: 0 = the library's choice (16:
-                       * below it the one-launch-per-stage kernels are as fast), 1 = always, 2^30 = never
+  int fused_rgb_min;  /* RGB levels of <= 64 rows (three derivative record arrays) and gray levels of > 256 columns and <= 256
+                       * rows take the fused system + SOR kernels behind the TILED warp and derivatives kernels (the latter
+                       * writing records; with fused_tv and finish_fusion) in contexts of at least this many frames: 0 = the
+                       * library's choice (16: below it the one-launch-per-stage kernels are as fast), 1 = always, 2^30 = never
                        *                                                                            OFDIS_FUSED_RGB_MIN */
 } ofdis_tuning;
 int ofdis_get_tuning(ofdis_tuning* out);

@@ -322,6 +322,35 @@ def test_random_varref_levels(gpu, orc, seed, tv_variant):
     assert_bits_equal(got[0], ref, f"seed {seed}: {w}x{h} noc={noc} innerit={p.tv_innerit} solverit={p.tv_solverit}")
 
 
+@pytest.mark.parametrize("w,h,nfr", [(300, 40, 2), (512, 224, 1), (600, 100, 3), (260, 64, 4), (257, 65, 2), (700, 17, 2), (1000, 256, 1)])
+def test_wide_gray_levels_on_the_fused_kernels_by_records(gpu, orc, w, h, nfr):
+    """Gray levels of more than 256 columns (the finest level of operating points 3 / 4): too wide for the row-marching warp +
+    derivatives kernel, so -- in contexts of 16 frames and more, forced here -- the tiled warp kernel and the derivatives
+    kernel in its record form feed the fused system + SOR kernels (one wavefront per frame up to 64 rows, two to four up to
+    256): the bits of the per-stage kernels."""
+    import gen_synth
+    from of_dis_amd.params import oppoint
+    rng = np.random.default_rng(34000 + w + h)
+    p = oppoint(2, w, h, noc=1).copy(sc_f=0, sc_l=0, p_samp_s=4, imgpadding=4, tv_innerit=int(rng.integers(1, 4)),
+                                     tv_solverit=int(rng.integers(1, 4)), tv_delta=float(rng.choice([0.0, 5.0])))
+    p.width, p.height = w, h
+    ims_a, ims_b, flows, refs = [], [], [], []
+    for k in range(nfr):
+        ia, ib, _ = gen_synth.make_pair(w, h, 34100 + k + w, 1)
+        pa, pb = orc.build_pyramid(p, ia), orc.build_pyramid(p, ib)
+        flow = rand_planes(rng, h, w, 2, scale=1.5)
+        ims_a.append(pa[0][0]); ims_b.append(pb[0][0]); flows.append(flow)
+        refs.append(orc.varref_level(p, 0, pa[0][0], pb[0][0], flow))
+    for knobs in ({"fused_rgb_min": 1}, {"fused_rgb_min": 1, "fused_tall_group": 0}, {}):
+        old = gpu.set_tuning(**knobs)
+        try:
+            got = gpu.varref_level(p, 0, np.stack(ims_a), np.stack(ims_b), np.stack(flows))
+        finally:
+            gpu.restore_tuning(old)
+        for k in range(nfr):
+            assert_bits_equal(got[k], refs[k], f"{w}x{h} gray frame {k} {knobs} innerit={p.tv_innerit} solverit={p.tv_solverit}")
+
+
 @pytest.mark.parametrize("seed", range(36))
 def test_rgb_levels_on_the_fused_system_and_solver(gpu, orc, seed):
     """RGB levels of at most 64 rows on the fused system + SOR kernel (ofdis_tuning.fused_rgb_min = 1 forces it for these
