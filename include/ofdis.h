@@ -228,7 +228,7 @@ typedef struct ofdis_tuning {
                        * values through LDS into the entry order its documented summation needs, the fused contract sums
                        * block-wise)                                                                  OFDIS_RGB12_LPP */
   int fused_tv;       /* 1: gray levels of <= 256 rows and <= 256 columns take the fused TV path (warp + derivatives kernel,
-                       * fused system + SOR kernel), RGB levels of <= 64 rows the fused system + SOR kernel (fused_rgb_min)
+                       * fused system + SOR kernel), RGB levels of <= 256 rows the fused system + SOR kernels (fused_rgb_min)
                        *                                                                              OFDIS_NO_FUSED -> 0 */
   int fused_mw_max;   /* frame groups up to which the multi-wave fused TV kernels are launched       OFDIS_FUSED_MW_MAX
                        * (default 512 and at most 1024 frames per batch; 0 = never; >= 2^30 = always) */
@@ -265,7 +265,7 @@ typedef struct ofdis_tuning {
   int fused_tall_group; /* levels of 65 ... 96 rows (the finest level of a 1080p / 4K gray pair is 120 x 68): 1 = the fused TV
                        * kernel takes up to three strips per workgroup, their rows beyond the 64th sharing ONE wavefront
                        * (2 .. 7: at most that many); 0 = two wavefronts per strip   OFDIS_TALL_GROUP, OFDIS_NO_TALL_GROUP -> 0 */
-  int fused_rgb_min;  /* RGB levels of <= 64 rows (three derivative record arrays) and gray levels of > 256 columns and <= 256
+  int fused_rgb_min;  /* RGB levels of <= 256 rows (three derivative record arrays) and gray levels of > 256 columns and <= 256
                        * rows take the fused system + SOR kernels behind the TILED warp and derivatives kernels (the latter
                        * writing records; with fused_tv and finish_fusion) in contexts of at least this many frames: 0 = the
                        * library's choice (16: below it the one-launch-per-stage kernels are as fast), 1 = always, 2^30 = never

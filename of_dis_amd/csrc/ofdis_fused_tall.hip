@@ -36,10 +36,11 @@ namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled fo
 // now head i's lane 63 <-> lane RT i of the tail, mailbox i; inside the tail wavefront a DPP shift never crosses into another
 // group's pixels: the first lane of a group takes its upper neighbour from the mailbox, the last row of a strip has no lower
 // neighbour (has_bot = false selects every such value away).  Everything else is the step of the kernel above, unchanged.
-template <int NS, bool BRIGHT, bool GROUPED>
+// NOC = 3: RGB levels (three derivative record arrays, the RGB data term, a derivative ring of two rows: see tv_fused_kernel).
+template <int NS, bool BRIGHT, bool GROUPED, int NOC = 1>
 __global__ __launch_bounds__(GROUPED ? 512 : 256) void tv_fused_tall_kernel(const FusedArgs a, const int RT) {
   constexpr int U = 6;
-  constexpr int PDW = 5, PDD = 3;
+  constexpr int PDW = 5, PDD = NOC == 3 ? 2 : 3;
   constexpr int NDOWN = 5 + 2 * NS, NUP = 6 + 2 * (NS - 1), NMB = 12;  // mailbox words per direction (padded to 16-byte reads)
   static_assert(NDOWN <= NMB && NUP <= NMB, "mailbox too small");
   static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
@@ -87,6 +88,8 @@ __global__ __launch_bounds__(GROUPED ? 512 : 256) void tv_fused_tall_kernel(cons
                                              (int)(nvalid * strip_recs * rec_floats * 4), 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t rsD = rsrc(a.d8, 8), rsW = rsrc(a.wrec, 2), rsU = rsrc(a.uv, 2);
+  const __amdgpu_buffer_rsrc_t rsD1 = rsrc(a.d8 + (NOC == 3 ? (size_t)a.t.nframes * w * h * 8 : 0), 8);
+  const __amdgpu_buffer_rsrc_t rsD2 = rsrc(a.d8 + (NOC == 3 ? (size_t)a.t.nframes * w * h * 16 : 0), 8);
   const int vrec = fl * (int)strip_recs + j;  // this lane's record within diag row 0 of its strip
   const int vo8 = vrec * 32, vo2 = vrec * 8;
   auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(GROUPED ? 512 : 256) void tv_fused_tall_kernel(cons
   const bool aos_out = a.flow_out != nullptr;
 
   FRow W[6];
-  FDer D[3];
+  FDer D[PDD][NOC];
   float uu[3], vv[3], sm[3];
   FSlot slot[6];
 #pragma unroll
@@ -106,8 +109,11 @@ __global__ __launch_bounds__(GROUPED ? 512 : 256) void tv_fused_tall_kernel(cons
   for (int r = 0; r < 3; ++r) {
     uu[r] = vv[r] = 0.0f;
     sm[r] = 1.0f;
-    D[r] = FDer{0, 0, 0, 0, 0, 0, 0, 0};
   }
+#pragma unroll
+  for (int r = 0; r < PDD; ++r)
+#pragma unroll
+    for (int c = 0; c < NOC; ++c) D[r][c] = FDer{0, 0, 0, 0, 0, 0, 0, 0};
   float ru[NS], rv[NS], ru2[NS], rv2[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) { ru[s] = rv[s] = ru2[s] = rv2[s] = 0.0f; }
@@ -160,13 +166,20 @@ __global__ __launch_bounds__(GROUPED ? 512 : 256) void tv_fused_tall_kernel(cons
     const unsigned q0 = qv[0], q1 = qv[1];
     r.du = asf(q0); r.dv = asf(q1);
   };
-  auto load_d = [&](FDer& r, int drow) {
-    const int o = drow * h * 32;
-    const auto lo = __builtin_amdgcn_raw_buffer_load_b128(rsD, vo8, o, 0);
-    const auto hi = __builtin_amdgcn_raw_buffer_load_b128(rsD, vo8 + 16, o, 0);
+  auto load_d1 = [&](FDer& r, const __amdgpu_buffer_rsrc_t& rs, int o) {
+    const auto lo = __builtin_amdgcn_raw_buffer_load_b128(rs, vo8, o, 0);
+    const auto hi = __builtin_amdgcn_raw_buffer_load_b128(rs, vo8 + 16, o, 0);
     const unsigned l0 = lo[0], l1 = lo[1], l2 = lo[2], l3 = lo[3], h0 = hi[0], h1 = hi[1], h2 = hi[2], h3 = hi[3];
     r.ix = asf(l0); r.iz = asf(l1); r.ixx = asf(l2); r.ixz = asf(l3);
     r.iy = asf(h0); r.ixy = asf(h1); r.iyz = asf(h2); r.iyy = asf(h3);
+  };
+  auto load_d = [&](FDer (&r)[NOC], int drow) {
+    const int o = drow * h * 32;
+    load_d1(r[0], rsD, o);
+    if constexpr (NOC == 3) {
+      load_d1(r[1], rsD1, o);
+      load_d1(r[2], rsD2, o);
+    }
   };
 
   // prologue: W rows -1, 0, 1 (indices 2, 3, 4)
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(GROUPED ? 512 : 256) void tv_fused_tall_kernel(cons
       // ---- (1) loads: W row t+5, D row t+3
       load_w(W[(u + PDW) % 6], rowW, first_w);
       rowW = next_row(rowW);
-      load_d(D[(u + PDD) % 3], rowD);
+      load_d(D[(u + PDD) % PDD], rowD);
       rowD = next_row(rowD);
       // ---- (2) uu, vv of row t+3
       {
@@ -272,7 +285,8 @@ __global__ __launch_bounds__(GROUPED ? 512 : 256) void tv_fused_tall_kernel(cons
         const FRow& rm = W[u % 6];
         const FRow& rp = W[(u + 2) % 6];
         float a11, a12, a22, b1, b2;
-        data_term_gray<BRIGHT>(D[(u + 1) % 3], rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
+        if constexpr (NOC == 1) data_term_gray<BRIGHT>(D[(u + 1) % PDD][0], rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
+        else data_term_rgb<BRIGHT>(D[(u + 1) % PDD], rc.du, rc.dv, hd3, hg3, a11, a12, a22, b1, b2);
         const float wx_u = from_prev(rm.wx, 2), wy_u = from_prev(rm.wy, 3);
         const float wx_d = from_next(rp.wx, 2), wy_d = from_next(rp.wy, 3);
         const float sh_l = slot[u % 6].sh;
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(GROUPED ? 512 : 256) void tv_fused_tall_kernel(cons
 }
 
 bool tv_fused_tall_supported(const TvGeom& t, int iterations) {
-  return t.noc == 1 && t.h > 64 && t.h <= 256 && t.w >= 16 && iterations >= 1 && iterations <= 3;
+  return (t.noc == 1 || t.noc == 3) && t.h > 64 && t.h <= 256 && t.w >= 16 && iterations >= 1 && iterations <= 3;
 }
 
 // group: the heads + shared tail form (ofdis_tuning::fused_tall_group): 0 = never, 1 = the default, up to THREE strips per
@@ -377,7 +391,10 @@ hipError_t launch_tv_fused_tall(const FusedArgs& a, hipStream_t s, int group) {
   if (nh >= 2) {
     const dim3 bd(64 * (nh + 1)), gd((nstrips + nh - 1) / nh);
 #define OFDIS_TALL_LAUNCH_G(NS)                                                                           \
-  if (bright) hipLaunchKernelGGL((tv_fused_tall_kernel<NS, true, true>), gd, bd, 0, s, a, RT);             \
+  if (a.t.noc == 3) {                                                                                      \
+    if (bright) hipLaunchKernelGGL((tv_fused_tall_kernel<NS, true, true, 3>), gd, bd, 0, s, a, RT);        \
+    else hipLaunchKernelGGL((tv_fused_tall_kernel<NS, false, true, 3>), gd, bd, 0, s, a, RT);              \
+  } else if (bright) hipLaunchKernelGGL((tv_fused_tall_kernel<NS, true, true>), gd, bd, 0, s, a, RT);      \
   else hipLaunchKernelGGL((tv_fused_tall_kernel<NS, false, true>), gd, bd, 0, s, a, RT)
     switch (a.iterations) {
       case 1: OFDIS_TALL_LAUNCH_G(1); break;
@@ -389,7 +406,10 @@ hipError_t launch_tv_fused_tall(const FusedArgs& a, hipStream_t s, int group) {
   }
   const dim3 bd(64 * ((h + 63) / 64));  // two to four wavefronts per strip
 #define OFDIS_TALL_LAUNCH(NS)                                                                             \
-  if (bright) hipLaunchKernelGGL((tv_fused_tall_kernel<NS, true, false>), dim3(nstrips), bd, 0, s, a, 64); \
+  if (a.t.noc == 3) {                                                                                      \
+    if (bright) hipLaunchKernelGGL((tv_fused_tall_kernel<NS, true, false, 3>), dim3(nstrips), bd, 0, s, a, 64); \
+    else hipLaunchKernelGGL((tv_fused_tall_kernel<NS, false, false, 3>), dim3(nstrips), bd, 0, s, a, 64);  \
+  } else if (bright) hipLaunchKernelGGL((tv_fused_tall_kernel<NS, true, false>), dim3(nstrips), bd, 0, s, a, 64); \
   else hipLaunchKernelGGL((tv_fused_tall_kernel<NS, false, false>), dim3(nstrips), bd, 0, s, a, 64)
   switch (a.iterations) {
     case 1: OFDIS_TALL_LAUNCH(1); break;

@@ -332,7 +332,8 @@ def test_rgb_8x8_flow_bit_exact(gpu, orc, size, opp, cost, rgb12):
 
 
 @pytest.mark.parametrize("pipe", [0, 2])
-@pytest.mark.parametrize("size,opp,nfr", [((1024, 436), 2, 5), ((320, 240), 2, 9), ((333, 251), 3, 3), ((500, 100), 2, 4)])
+@pytest.mark.parametrize("size,opp,nfr", [((1024, 436), 2, 5), ((320, 240), 2, 9), ((333, 251), 3, 3), ((500, 100), 2, 4),
+                                          ((1920, 1080), 2, 4), ((1000, 1700), 2, 2)])
 def test_rgb_batches_on_the_fused_tv_kernel(gpu, orc, size, opp, nfr, pipe):
     """run_OF_RGB batches with their levels of at most 64 rows on the fused system + SOR kernel (forced for these small
     contexts; operating point 3: only the coarse levels qualify, the finer ones keep the per-stage kernels in the same pass),

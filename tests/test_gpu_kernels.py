@@ -351,6 +351,38 @@ def test_wide_gray_levels_on_the_fused_kernels_by_records(gpu, orc, w, h, nfr):
             assert_bits_equal(got[k], refs[k], f"{w}x{h} gray frame {k} {knobs} innerit={p.tv_innerit} solverit={p.tv_solverit}")
 
 
+@pytest.mark.parametrize("knobs", [{}, {"fused_tall_group": 0}, {"fused_tall_group": 7}])
+@pytest.mark.parametrize("w,h,nfr", [(120, 68, 3), (100, 127, 2), (64, 96, 4), (240, 136, 1), (60, 200, 2), (16, 65, 5), (130, 256, 1),
+                                     (33, 80, 7)])
+def test_tall_rgb_levels_on_the_fused_kernel(gpu, orc, w, h, nfr, knobs):
+    """RGB levels of 65 ... 256 rows (the finest level of a 1920x1080 colour pair at operating point 2 is 120 x 68):
+    tv_fused_tall_kernel with three derivative record arrays -- two to four wavefronts per strip, or heads + one shared tail
+    wavefront -- gives the bits of n_inner x (tv_system + block SOR)."""
+    import gen_synth
+    from of_dis_amd.params import oppoint
+    rng = np.random.default_rng(35000 + 3 * w + h)
+    p = oppoint(2, w, h, noc=3).copy(sc_f=0, sc_l=0, p_samp_s=4, imgpadding=4, tv_innerit=int(rng.integers(1, 4)),
+                                     tv_solverit=int(rng.integers(1, 4)), tv_delta=float(rng.choice([0.0, 5.0])))
+    p.width, p.height = w, h
+    ims_a, ims_b, flows, refs = [], [], [], []
+    for k in range(min(nfr, 3)):
+        ia, ib, _ = gen_synth.make_pair(w, h, 35100 + k + w, 3)
+        pa, pb = orc.build_pyramid(p, ia), orc.build_pyramid(p, ib)
+        flow = rand_planes(rng, h, w, 2, scale=1.5)
+        flow[rng.integers(0, h), rng.integers(0, w)] = (3.0 * w, -3.0 * h)
+        ims_a.append(pa[0][0]); ims_b.append(pb[0][0]); flows.append(flow)
+        refs.append(orc.varref_level(p, 0, pa[0][0], pb[0][0], flow))
+    pick = [k % len(refs) for k in range(nfr)]
+    old = gpu.set_tuning(fused_rgb_min=1, **knobs)
+    try:
+        got = gpu.varref_level(p, 0, np.stack([ims_a[k] for k in pick]), np.stack([ims_b[k] for k in pick]),
+                               np.stack([flows[k] for k in pick]))
+    finally:
+        gpu.restore_tuning(old)
+    for slot, k in enumerate(pick):
+        assert_bits_equal(got[slot], refs[k], f"{w}x{h} rgb slot {slot} {knobs} innerit={p.tv_innerit} solverit={p.tv_solverit}")
+
+
 @pytest.mark.parametrize("seed", range(36))
 def test_rgb_levels_on_the_fused_system_and_solver(gpu, orc, seed):
     """RGB levels of at most 64 rows on the fused system + SOR kernel (ofdis_tuning.fused_rgb_min = 1 forces it for these

@@ -102,7 +102,10 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     ("patch_optimize_rgb12x_kernelILi1ELi3ELb0ELi3EE", 168, "RGB 12x12 patch kernel of the exact contract (blocks for the taps, chains for the sums): three wavefronts per SIMD"),
     ("patch_optimize_rgb12_kernelILi1ELi3ELb0ELi3EE", 168, "RGB 12x12 patch kernel of the fused contract (3x3 pixel block per lane, Ty in LDS): three wavefronts per SIMD"),
     ("tv_fused_kernelILi3ELb1ELi1ELi1EE", 168, "tv_fused_kernel<3, true, 1>, iteration-pipelined mapping: three wavefronts per SIMD (three workgroups of four iterations per CU)"),
-    ("tv_fused_tall_kernelILi3ELb1ELb", 216, "tv_fused_tall_kernel<3, true> (two to four wavefronts per strip, 65-256 rows): two wavefronts per SIMD"),
+    ("tv_fused_tall_kernelILi3ELb1ELb0ELi1EE", 216, "tv_fused_tall_kernel<3, true, false> (two to four wavefronts per strip, 65-256 rows): two wavefronts per SIMD"),
+    ("tv_fused_tall_kernelILi3ELb1ELb1ELi1EE", 216, "tv_fused_tall_kernel<3, true, true> (heads + shared tail): two wavefronts per SIMD"),
+    ("tv_fused_tall_kernelILi3ELb1ELb0ELi3EE", 256, "tv_fused_tall_kernel<3, true, false, 3>, RGB: two wavefronts per SIMD"),
+    ("tv_fused_tall_kernelILi3ELb1ELb1ELi3EE", 256, "tv_fused_tall_kernel<3, true, true, 3>, RGB, heads + shared tail (eight wavefronts per workgroup: 256 registers at most)"),
     ("densify_kernelILb1EE", 64, "densify_kernel<true>: eight wavefronts per SIMD"),
     ("densify_quad_kernel", 64, "densify_quad_kernel: eight wavefronts per SIMD"),
     ("tv_prep_kernelILi2ELb0EE", 84, "tv_prep_kernel<2, false> (two wavefronts per 128-column row): six wavefronts per SIMD by registers"),
