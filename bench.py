@@ -748,12 +748,15 @@ def block_frame_sizes(capi, torch, p, batch, ia, ib, stream, dev, args):
 
 def block_other_modes(capi, torch, p, batch, ia, ib, stream, dev, args):
     """The reference's other binaries / operating points on the same path (secondary): run_OF_RGB at its default
-    operating point (RGB 8x8 patches), run_OF_INT at operating point 3 (gray 12x12 patches, finest level at half resolution)
-    and run_DE_INT (stereo depth, one displacement channel) at a KITTI-sized pair.  Round 6 moved all three off the
-    one-patch-per-wavefront patch kernel, and the stereo mode off its per-pixel system kernel and one-launch-per-sweep solver."""
+    operating point (RGB 8x8 patches; also at 1920x1080: finest level 120 x 68), run_OF_INT at operating point 3 (gray 12x12
+    patches, finest level at half resolution) and run_DE_INT (stereo depth, one displacement channel) at a KITTI-sized pair.
+    Round 6 moved all of them off the one-patch-per-wavefront patch kernel, the RGB levels of up to 256 rows (and gray levels
+    wider than 256 columns) onto the fused system + SOR kernels, and the stereo mode off its per-pixel system kernel and
+    one-launch-per-sweep solver."""
     from of_dis_amd.params import oppoint
     out = {}
     for name, (w, h), opp, noc, mode, n in (("run_OF_RGB_op2_1024x436", (WIDTH, HEIGHT), 2, 3, 1, 1024),
+                                            ("run_OF_RGB_op2_1920x1080", (1920, 1080), 2, 3, 1, 512),
                                             ("run_OF_INT_op3_1024x436", (WIDTH, HEIGHT), 3, 1, 1, 256),
                                             ("run_DE_INT_op2_1242x375", (1242, 375), 2, 1, 2, 1024)):
         pq = oppoint(opp, w, h, noc=noc, verbosity=0).copy(selectmode=mode)
