@@ -243,8 +243,9 @@ typedef struct ofdis_tuning {
                        * own workgroup on its own CU (contexts of <= 768 frames; 0 = never)        OFDIS_FUSED_XCU_MAX */
   int fused_tp_pipe;  /* large batches: the fused TV kernel with one wavefront per fixed-point iteration and strip (the
                        * iterations of a strip on one compute unit share the derivative records through the L2) instead of
-                       * one wavefront per strip walking all iterations.  0 = never, 1 = where it is faster (levels of
-                       * more than 32 rows under the fused contract), 2 = always                    OFDIS_FUSED_TP_PIPE */
+                       * one wavefront per strip walking all iterations.  0 = never, 1 = where it is faster (gray levels of
+                       * more than 32 rows under the fused contract; RGB levels of <= 64 rows under the fused contract in
+                       * batches of up to 2048 frames), 2 = always                                  OFDIS_FUSED_TP_PIPE */
   int fused_xcu_spin; /* microseconds a workgroup of that variant waits for a hand-over row (device wall clock) before it
                        * reports the pass as failed and carries on without waiting; 0 = the default, 50 000 (50 ms: a
                        * thousand times the longest healthy wait, and the most a drop-in call can lose before its pass is

@@ -93,7 +93,7 @@ template <int NS, bool BRIGHT, int MODE, int NOC = 1>
 // headline took 5.84 instead of 4.41 ms; with both in LDS (wdring, obring: two ds_write and two ds_read per step of that one
 // wavefront) nothing spills: 4.30-4.34 -> 4.13-4.15 ms on the same box (fused contract; exact: 167 registers, unchanged time).
 __global__ __launch_bounds__(MODE == 2 ? 128 * SP_MAX_ITERS : (MODE == 1 ? 64 * MW_MAX_ITERS : 256))
-__attribute__((amdgpu_waves_per_eu(MODE == 1 ? 3 : (NOC == 3 ? 2 : 1)))) void tv_fused_kernel(const FusedArgs a, const int R) {
+__attribute__((amdgpu_waves_per_eu(NOC == 3 ? 2 : (MODE == 1 ? 3 : 1)))) void tv_fused_kernel(const FusedArgs a, const int R) {
   constexpr int U = 6;
   constexpr bool MW = MODE != 0;
   constexpr int MAXIT = MODE == 2 ? SP_MAX_ITERS : MW_MAX_ITERS;
@@ -526,7 +526,8 @@ constexpr int MW_MAX_BATCH_FRAMES = 1024;
 int tv_fused_mode(const FusedArgs& a, const FusedXcu* x) {
   const int h = a.t.h;
   if (h > 64) return 0;  // two to four wavefronts per strip (ofdis_fused_tall.hip): the throughput mapping only, whatever the batch
-  if (a.t.noc == 3) return 0;  // RGB: the throughput mapping, one frame per strip
+  if (a.t.noc == 3)  // RGB: one frame per strip, one wavefront per frame or -- tp_pipe -- per fixed-point iteration
+    return (a.tp_pipe && a.S == 1 && a.n_inner >= 2 && a.n_inner <= MW_MAX_ITERS) ? 1 : 0;
   const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
   const int groups = (a.t.nframes + 64 / R - 1) / (64 / R);
   const int total = a.total_frames > 0 ? a.total_frames : a.t.nframes;
@@ -561,7 +562,10 @@ hipError_t launch_tv_fused(const FusedArgs& a, hipStream_t s, bool* wrote_flow, 
   if (a.t.noc == 3) {
     if (a.S != 1) return hipErrorInvalidValue;
 #define OFDIS_FUSED_RGB(NS)                                                                                            \
-  if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 0, 3>), dim3(blocks), dim3(256), 0, s, a, R);              \
+  if (mode == 1) {                                                                                                     \
+    if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 1, 3>), dim3(waves), dim3(64 * a.n_inner), 0, s, a, R);  \
+    else hipLaunchKernelGGL((tv_fused_kernel<NS, false, 1, 3>), dim3(waves), dim3(64 * a.n_inner), 0, s, a, R);        \
+  } else if (bright) hipLaunchKernelGGL((tv_fused_kernel<NS, true, 0, 3>), dim3(blocks), dim3(256), 0, s, a, R);       \
   else hipLaunchKernelGGL((tv_fused_kernel<NS, false, 0, 3>), dim3(blocks), dim3(256), 0, s, a, R)
     switch (a.iterations) {
       case 1: OFDIS_FUSED_RGB(1); break;

@@ -409,14 +409,16 @@ def test_rgb_levels_on_the_fused_system_and_solver(gpu, orc, seed):
         flow[rng.integers(0, h), rng.integers(0, w)] = (3.0 * w, -3.0 * h)
         ims_a.append(pa[0][0]); ims_b.append(pb[0][0]); flows.append(flow)
         refs.append(orc.varref_level(p, 0, pa[0][0], pb[0][0], flow))
-    old = gpu.set_tuning(fused_rgb_min=1)
-    try:
-        got = gpu.varref_level(p, 0, np.stack(ims_a), np.stack(ims_b), np.stack(flows))
-    finally:
-        gpu.restore_tuning(old)
+    for knobs in ({"fused_tp_pipe": 0}, {"fused_tp_pipe": 2}):   # a wavefront per frame / per fixed-point iteration
+        old = gpu.set_tuning(fused_rgb_min=1, **knobs)
+        try:
+            got = gpu.varref_level(p, 0, np.stack(ims_a), np.stack(ims_b), np.stack(flows))
+        finally:
+            gpu.restore_tuning(old)
+        for k in range(nfr):
+            assert_bits_equal(got[k], refs[k], f"seed {seed}: {w}x{h} rgb frame {k} {knobs} innerit={p.tv_innerit} solverit={p.tv_solverit} delta={p.tv_delta}")
     plain = gpu.varref_level(p, 0, np.stack(ims_a), np.stack(ims_b), np.stack(flows))   # (one frame: the per-stage kernels)
     for k in range(nfr):
-        assert_bits_equal(got[k], refs[k], f"seed {seed}: {w}x{h} rgb frame {k} innerit={p.tv_innerit} solverit={p.tv_solverit} delta={p.tv_delta}")
         assert_bits_equal(plain[k], refs[k], f"seed {seed}: per-stage kernels, frame {k}")
 
 

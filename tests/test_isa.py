@@ -95,6 +95,7 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     # takes by itself: profiles/README.md round 3)
     ("tv_fused_kernelILi3ELb1ELi0ELi1EE", 192, "tv_fused_kernel<3, true, 0>, throughput mapping: two wavefronts per SIMD"),
     ("tv_fused_kernelILi3ELb1ELi0ELi3EE", 256, "tv_fused_kernel<3, true, 0, 3>, RGB levels on the throughput mapping (derivative ring of two rows): two wavefronts per SIMD"),
+    ("tv_fused_kernelILi3ELb1ELi1ELi3EE", 256, "tv_fused_kernel<3, true, 1, 3>, RGB levels on the iteration-pipelined mapping: two wavefronts per SIMD"),
     ("tv_fused_kernelILi3ELb1ELi2ELi1EE", 168, "tv_fused_kernel<3, true, 2>, split mapping: 12 wavefronts of a workgroup on one CU"),
     ("tv_fused_xcu_kernelILi3ELb1EE", 128, "tv_fused_xcu_kernel<3, true>, cross-CU mapping: one wavefront per SIMD, four workgroups per CU at most"),
     ("patch_optimize_gray8_kernelILi0ELb0EE", 128, "gray 8x8 patch kernel: four wavefronts per SIMD"),
