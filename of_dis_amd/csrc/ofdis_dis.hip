@@ -1397,24 +1397,38 @@ struct FbCand {
   float w0, w1, w2, w3, p0, p1;
 };
 
-template <bool PLANAR>
+// FB (forward-backward merging): a block is a 16 x 16 pixel TILE and a wavefront a 16 x 4 strip of it, so that the list a
+// pixel walks holds the complementary patches that reach its tile (~40) instead of every patch of its rows (~100 at level 3
+// of operating point 2, 3 000 at operating point 3) and a wavefront skips -- uniformly -- those that miss its strip: the
+// walk was 634 us per 512-pair level-3 launch against 25 us for the grid's own patches.
+template <bool PLANAR, bool FB>
 __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
   const LevelGeom& g = a.g;
   const int npx = g.w * g.h;
-  const int blocks_per_frame = (npx + 255) / 256;
+  const int tiles_x = (g.w + 15) / 16;
+  const int blocks_per_frame = FB ? tiles_x * ((g.h + 15) / 16) : (npx + 255) / 256;
   int frame, blk;
   xcd_frame_map(blockIdx.x, blocks_per_frame, a.nframes, frame, blk);  // a frame's blocks share one XCD's L2
   if (frame >= a.nframes) return;
-  const bool fb = a.cg_p != nullptr;
-  const int i = blk * 256 + threadIdx.x;
-  const bool active = i < npx;
-  if (!active && !fb) return;
+  constexpr bool fb = FB;  // (= a.cg_p != nullptr: the launcher picks the instantiation)
+  int y, x, i;
+  bool active;
+  if constexpr (FB) {
+    const int ty = blk / tiles_x, tx = blk - ty * tiles_x;
+    x = tx * 16 + (threadIdx.x & 15);
+    y = ty * 16 + (threadIdx.x >> 4);
+    active = x < g.w && y < g.h;
+    i = y * g.w + x;
+  } else {
+    i = blk * 256 + threadIdx.x;
+    active = i < npx;
+    if (!active) return;
+    // i / w by multiply-high with ceil(2^32 / w) (exact for i * w < 2^32, checked by the launcher; 0 = divide)
+    auto split = [&](int n, int d) { return a.idx_magic ? (int)__umulhi((unsigned)n, a.idx_magic) : n / d; };
+    y = split(i, g.w);
+    x = i - y * g.w;
+  }
   const long long idx = (long long)frame * npx + i;
-  int y, x;
-  // i / w by multiply-high with ceil(2^32 / w) (exact for i * w < 2^32, checked by the launcher; 0 = divide)
-  auto split = [&](int n, int d) { return a.idx_magic ? (int)__umulhi((unsigned)n, a.idx_magic) : n / d; };
-  y = split(i, g.w);
-  x = i - y * g.w;
   const int P = g.P, lb = -P / 2, ub = P / 2 - 1, st = g.steps, noc = g.noc;
   float we = 0.0f, fu = 0.0f, fv = 0.0f;
   if (active) {
@@ -1426,12 +1440,14 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
     else
       densify_accumulate(g, pf, pwf, x, y, we, fu, fv, pxf);
   }
-  if (fb) {  // block-uniform
+  if constexpr (FB) {
     __shared__ FbCand cand[256];
     __shared__ int wave_cnt[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i1 = min(npx, blk * 256 + 256) - 1;
-    const int yb0 = (blk * 256) / g.w, yb1 = i1 / g.w;  // rows this block's pixels lie in
+    const int tyb = blk / tiles_x, txb = blk - tyb * tiles_x;
+    const int yb0 = tyb * 16, yb1 = min(g.h, yb0 + 16) - 1;  // rows / columns of this block's pixels
+    const int xb0 = txb * 16, xb1 = min(g.w, xb0 + 16) - 1;
+    const int yw0 = yb0 + 4 * wave, yw1 = yw0 + 3;           // ... and rows of this wavefront's strip
     const float* cpf = a.cg_p + (size_t)frame * g.nop * 2;
     const float* cpwf = a.cg_pweight + (size_t)frame * g.nop * g.novals;
     for (int base = 0; base < g.nop; base += 256) {
@@ -1453,8 +1469,8 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
         c.w1 = (1 - r0) * r1;
         c.w2 = r0 * (1 - r1);
         c.w3 = (1 - r0) * (1 - r1);
-        // source rows ys = pos1 + lb .. pos1 + ub feed target rows ys - 1 and ys
-        hit = (c.pos1 + ub >= yb0) && (c.pos1 + lb - 1 <= yb1);
+        // source rows ys = pos1 + lb .. pos1 + ub feed target rows ys - 1 and ys (columns likewise)
+        hit = (c.pos1 + ub >= yb0) && (c.pos1 + lb - 1 <= yb1) && (c.pos0 + ub >= xb0) && (c.pos0 + lb - 1 <= xb1);
       }
       const unsigned long long bal = __ballot(hit);
       const int before = __popcll(bal & ((1ull << lane) - 1ull));
@@ -1468,9 +1484,11 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
       }
       if (hit) cand[off + before] = c;
       __syncthreads();
-      if (active) {
+      {
         for (int k = 0; k < n; ++k) {
           const FbCand& cc = cand[k];
+          if ((cc.pos1 + ub < yw0) | (cc.pos1 + lb - 1 > yw1)) continue;  // (wave-uniform) misses this strip's rows
+          if (!active) continue;
           // valid source rectangle of this patch in patch coordinates (condition patchgrid.cpp:321)
           const int L = max(0, 1 - (cc.pos0 + lb)), Rr = min(P - 1, g.w - 2 - (cc.pos0 + lb));
           const int T = max(0, 1 - (cc.pos1 + lb)), Bt = min(P - 1, g.h - 2 - (cc.pos1 + lb));
@@ -1619,10 +1637,12 @@ hipError_t launch_densify(const DensifyArgs& a_in, hipStream_t s) {
   // patch -- was measured at twice the time of this gather: ~90 dependent LDS read-modify-write rounds per tile.)
   const int blocks_per_frame = (a.g.w * a.g.h + 255) / 256;
   const long long blocks = (long long)((a.nframes + 7) / 8) * 8 * blocks_per_frame;
-  if (a.flow_aos)
-    hipLaunchKernelGGL(densify_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(densify_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  if (a.cg_p) {  // forward-backward merging: 16 x 16 pixel tiles
+    const long long fblocks = (long long)((a.nframes + 7) / 8) * 8 * ((a.g.w + 15) / 16) * ((a.g.h + 15) / 16);
+    if (a.flow_aos) hipLaunchKernelGGL((densify_kernel<false, true>), dim3((unsigned)fblocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((densify_kernel<true, true>), dim3((unsigned)fblocks), dim3(256), 0, s, a);
+  } else if (a.flow_aos) hipLaunchKernelGGL((densify_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((densify_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

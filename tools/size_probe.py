@@ -1,5 +1,5 @@
 """Developer probe: the batched path at another frame size / operating point / channel count / mode, with the per-stage table.
-    [OPP=2] [NOC=1|3] [MODE=1|2 (2 = stereo depth)] python tools/size_probe.py W H [pairs=1024] [contract=fused]"""
+    [OPP=2] [NOC=1|3] [MODE=1|2 (2 = stereo depth)] [FBCON=1] [COST=0|1|2] python tools/size_probe.py W H [pairs=1024] [contract=fused]"""
 import json
 import os
 import sys
@@ -21,7 +21,9 @@ torch.cuda.set_device(0)
 capi.check(capi.lib().ofdis_set_device(0))
 capi.set_tuning(contract=1 if contract == "fused" else 0)
 noc = int(os.environ.get("NOC", "1"))
-p = oppoint(int(os.environ.get("OPP", "2")), W, H, noc=noc, verbosity=0).copy(selectmode=int(os.environ.get("MODE", "1")))
+p = oppoint(int(os.environ.get("OPP", "2")), W, H, noc=noc, verbosity=0).copy(selectmode=int(os.environ.get("MODE", "1")),
+                                                                          usefbcon=int(os.environ.get("FBCON", "0")),
+                                                                          costfct=int(os.environ.get("COST", "0")))
 ia, ib = bench.synth_frames_range(0, min(n, 64), W, H, 1234, dev, channels=noc)
 reps = [(n + ia.shape[0] - 1) // ia.shape[0]] + [1] * (ia.dim() - 1)
 ia, ib = ia.repeat(*reps)[:n].contiguous(), ib.repeat(*reps)[:n].contiguous()
