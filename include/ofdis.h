@@ -269,7 +269,8 @@ typedef struct ofdis_tuning {
   int fused_rgb_min;  /* RGB levels of <= 256 rows (three derivative record arrays) and gray levels of > 256 columns and <= 256
                        * rows take the fused system + SOR kernels behind the TILED warp and derivatives kernels (the latter
                        * writing records; with fused_tv and finish_fusion) in contexts of at least this many frames: 0 = the
-                       * library's choice (16: below it the one-launch-per-stage kernels are as fast), 1 = always, 2^30 = never
+                       * library's choice (16 under the fused contract, 512 under the exact one: below it the
+                       * one-launch-per-stage kernels are as fast or faster), 1 = always, 2^30 = never
                        *                                                                            OFDIS_FUSED_RGB_MIN */
 } ofdis_tuning;
 int ofdis_get_tuning(ofdis_tuning* out);

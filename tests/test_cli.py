@@ -353,16 +353,17 @@ def test_sequence_driver_rgb_and_unreadable_pairs(gpu, tmp_path):
 
 @pytest.mark.gpu
 def test_rgb_sequence_driver_chunks_take_the_fused_tv_kernel(gpu, tmp_path):
-    """run_OF_RGB_seq at its default chunk of 16 pairs: contexts of that size run their RGB levels on the fused system + SOR
-    kernel (ofdis_tuning.fused_rgb_min), the single-pair binary's context the per-stage kernels -- the .flo files are the
-    same bytes (default operating point, TV on)."""
+    """run_OF_RGB_seq with its RGB levels on the fused system + SOR kernel (OFDIS_FUSED_RGB_MIN=1: under the CLI's default,
+    exact, contract only contexts of 512 frames and more take it by themselves) against the single-pair binary's per-stage
+    kernels: the .flo files are the same bytes (default operating point, TV on; a full chunk of 16 and a short last one)."""
     w, h, n = 320, 192, 19
     pairs = _write_pairs(tmp_path, n, w, h, channels=3, seed0=950)
     lst = tmp_path / "rgb16.txt"
     lst.write_text("".join(f"{fa} {fb} {tmp_path}/q{k:02d}.flo\n" for k, (fa, fb) in enumerate(pairs)))
-    r = subprocess.run([SEQ[3], str(lst), "2"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([SEQ[3], str(lst), "2"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, OFDIS_FUSED_RGB_MIN="1"))
     assert r.returncode == 0, (r.stdout, r.stderr)
-    for k in (0, 7, 15, 16, 18):   # pairs of the full chunk of 16 (fused kernel) and of the short last chunk (per-stage kernels)
+    for k in (0, 7, 15, 16, 18):
         fa, fb = pairs[k]
         fo = str(tmp_path / f"one{k:02d}.flo")
         r1 = subprocess.run([EXE[3], fa, fb, fo, "2"], capture_output=True, text=True, timeout=120)

@@ -325,7 +325,7 @@ def test_random_varref_levels(gpu, orc, seed, tv_variant):
 @pytest.mark.parametrize("w,h,nfr", [(300, 40, 2), (512, 224, 1), (600, 100, 3), (260, 64, 4), (257, 65, 2), (700, 17, 2), (1000, 256, 1)])
 def test_wide_gray_levels_on_the_fused_kernels_by_records(gpu, orc, w, h, nfr):
     """Gray levels of more than 256 columns (the finest level of operating points 3 / 4): too wide for the row-marching warp +
-    derivatives kernel, so -- in contexts of 16 frames and more, forced here -- the tiled warp kernel and the derivatives
+    derivatives kernel, so -- in contexts of 16 (fused contract) / 512 (exact contract) frames and more, forced here -- the tiled warp kernel and the derivatives
     kernel in its record form feed the fused system + SOR kernels (one wavefront per frame up to 64 rows, two to four up to
     256): the bits of the per-stage kernels."""
     import gen_synth
@@ -386,7 +386,7 @@ def test_tall_rgb_levels_on_the_fused_kernel(gpu, orc, w, h, nfr, knobs):
 @pytest.mark.parametrize("seed", range(36))
 def test_rgb_levels_on_the_fused_system_and_solver(gpu, orc, seed):
     """RGB levels of at most 64 rows on the fused system + SOR kernel (ofdis_tuning.fused_rgb_min = 1 forces it for these
-    one- to five-frame contexts; by default contexts of 16 frames and more take it): the warp kernel, the derivatives kernel
+    one- to five-frame contexts; by default contexts of 16 / 512 frames and more -- fused / exact contract -- take it): the warp kernel, the derivatives kernel
     in its record form (three arrays of 8-float records in the diag layout, zeroed by the mask) and tv_fused_kernel with the
     RGB data term give the bits of n_inner x (tv_system + SOR) -- random geometry (16 <= w < 140, 4 <= h <= 64), TV
     parameters with and without the brightness term, 1-3 sweeps, a flow with out-of-image displacements."""
