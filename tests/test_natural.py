@@ -171,3 +171,22 @@ def test_cli_on_the_photographs_themselves(gpu, tmp_path):
         ia, ib = natural.to_channels(a, 1), natural.to_channels(b, 1)
         pa, pb = O.build_pyramid(p, ia), O.build_pyramid(p, ib)
         assert_bits_equal(read_pfm(fo), full_res(p, R.flow(p, pa[0], pa[1], pa[2], pb[0]), w, h)[..., 0], "run_DE_INT on the PNG files")
+
+
+@pytest.mark.gpu
+def test_python_tool_writes_the_binaries_bytes(gpu, tmp_path):
+    """tools/flow_images.py (PIL decode -> batch context from 8-bit frames -> device upsample -> .flo / .pfm) on the Middlebury
+    pair: the bytes run_OF_RGB, run_OF_INT and run_DE_INT write for it (exact contract; two pairs in one batch)."""
+    import sys
+    fa, fb = natural.find("motorcycle_left.png"), natural.find("motorcycle_right.png")
+    if fa is None or fb is None or natural.pair("motorcycle") is None:
+        pytest.skip("the Middlebury pair is not available here")
+    tool = os.path.join(ROOT, "tools", "flow_images.py")
+    for exe, flags, ext in (("run_OF_RGB", ["--rgb"], "flo"), ("run_OF_INT", [], "flo"), ("run_DE_INT", ["--stereo"], "pfm")):
+        o1, o2, ob = (str(tmp_path / f"{exe}_{k}.{ext}") for k in ("a", "b", "bin"))
+        r = subprocess.run([sys.executable, tool] + flags + [fa, fb, o1, fb, fa, o2], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        rb = subprocess.run([os.path.join(LIB, exe), fa, fb, ob, "2"], capture_output=True, text=True, timeout=120)
+        assert rb.returncode == 0, rb.stderr
+        assert open(o1, "rb").read() == open(ob, "rb").read(), f"tools/flow_images.py {flags} vs {exe}"
+        assert open(o2, "rb").read() != open(ob, "rb").read()   # (the swapped pair is another problem)
