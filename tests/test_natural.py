@@ -141,6 +141,30 @@ def test_gpu_on_natural_pairs(gpu, name, noc, opp, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,noc,opp,mode", [("motorcycle", 1, 2, 1), ("motorcycle", 3, 2, 1), ("motorcycle", 1, 2, 2), ("china", 1, 3, 1),
+                                               ("astronaut", 3, 2, 1)])
+def test_gpu_forward_backward_and_warm_start_on_natural_pairs(gpu, name, noc, opp, mode):
+    """Forward-backward merging (usefbcon: the second image's gradient pyramid, both grids, the merged densification over pixel
+    tiles) and the initflow warm start on photographs: the HIP library against the reference build, bit for bit."""
+    p, ia, ib, pa, pb, truth = _need(name, noc, opp, mode)
+    h, w = ia.shape[:2]
+    R = _ref(noc, mode)
+    pf = p.copy(usefbcon=1)
+    ref = R.flow(pf, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
+    got = gpu.flow(pf, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
+    assert_bits_equal(got, ref, f"'{name}' noc={noc} op{opp} mode {mode}, usefbcon: HIP vs reference build")
+    assert not np.array_equal(got, R.flow(p, pa[0], pa[1], pa[2], pb[0]))
+    check_accuracy(name, opp, pf, got, truth, w, h)
+    if mode == 1:  # warm start (oflow.cpp:217-220): the coarsest level starts from a given flow of its size
+        wc, hc = p.level_size(p.sc_f)
+        init = np.zeros((hc, wc, 2), np.float32)
+        init[..., 0] = -1.5
+        refi = R.flow(p, pa[0], pa[1], pa[2], pb[0], initflow=init)
+        goti = gpu.flow(p, pa[0], pa[1], pa[2], pb[0], initflow=init)
+        assert_bits_equal(goti, refi, f"'{name}' noc={noc} op{opp}, initflow: HIP vs reference build")
+
+
+@pytest.mark.gpu
 def test_cli_on_the_photographs_themselves(gpu, tmp_path):
     """run_OF_RGB / run_OF_INT / run_DE_INT fed the Middlebury pair's PNG files as they lie on disk (colour PNGs: the gray
     binaries convert): the library's own PNG decoder and colour conversion against PIL + tests/natural.py, then the whole
