@@ -749,17 +749,19 @@ def block_frame_sizes(capi, torch, p, batch, ia, ib, stream, dev, args):
 def block_other_modes(capi, torch, p, batch, ia, ib, stream, dev, args):
     """The reference's other binaries / operating points on the same path (secondary): run_OF_RGB at its default
     operating point (RGB 8x8 patches; also at 1920x1080: finest level 120 x 68), run_OF_INT at operating point 3 (gray 12x12
-    patches, finest level at half resolution) and run_DE_INT (stereo depth, one displacement channel) at a KITTI-sized pair.
+    patches, finest level at half resolution), run_OF_INT with forward-backward merging (usefbcon) and run_DE_INT (stereo depth,
+    one displacement channel) at a KITTI-sized pair.
     Round 6 moved all of them off the one-patch-per-wavefront patch kernel, the RGB levels of up to 256 rows (and gray levels
     wider than 256 columns) onto the fused system + SOR kernels, and the stereo mode off its per-pixel system kernel and
     one-launch-per-sweep solver."""
     from of_dis_amd.params import oppoint
     out = {}
-    for name, (w, h), opp, noc, mode, n in (("run_OF_RGB_op2_1024x436", (WIDTH, HEIGHT), 2, 3, 1, 1024),
-                                            ("run_OF_RGB_op2_1920x1080", (1920, 1080), 2, 3, 1, 512),
-                                            ("run_OF_INT_op3_1024x436", (WIDTH, HEIGHT), 3, 1, 1, 256),
-                                            ("run_DE_INT_op2_1242x375", (1242, 375), 2, 1, 2, 1024)):
-        pq = oppoint(opp, w, h, noc=noc, verbosity=0).copy(selectmode=mode)
+    for name, (w, h), opp, noc, mode, n, fb in (("run_OF_RGB_op2_1024x436", (WIDTH, HEIGHT), 2, 3, 1, 1024, 0),
+                                                ("run_OF_RGB_op2_1920x1080", (1920, 1080), 2, 3, 1, 512, 0),
+                                                ("run_OF_INT_op3_1024x436", (WIDTH, HEIGHT), 3, 1, 1, 256, 0),
+                                                ("run_OF_INT_op2_usefbcon_1024x436", (WIDTH, HEIGHT), 2, 1, 1, 1024, 1),
+                                                ("run_DE_INT_op2_1242x375", (1242, 375), 2, 1, 2, 1024, 0)):
+        pq = oppoint(opp, w, h, noc=noc, verbosity=0).copy(selectmode=mode, usefbcon=fb)
         xa, xb = synth_frames_range(0, 64, w, h, 778, dev, channels=noc)
         reps = [n // 64] + [1] * (xa.dim() - 1)
         xa, xb = xa.repeat(*reps).contiguous(), xb.repeat(*reps).contiguous()
@@ -773,7 +775,7 @@ def block_other_modes(capi, torch, p, batch, ia, ib, stream, dev, args):
         rows = {kn: round(bq.kernel_time(k)[0], 3) for k, kn in enumerate(capi.K_NAMES) if bq.kernel_time(k)[1]}
         bq.close()
         del xa, xb
-        out[name] = {"channels": noc, "operating_point": opp, "selectmode": mode, "pairs_per_step": n,
+        out[name] = {"channels": noc, "operating_point": opp, "selectmode": mode, "usefbcon": fb, "pairs_per_step": n,
                      "levels": [list(pq.level_size(l)) for l in range(pq.sc_l, pq.sc_f + 1)],
                      "ms_per_step": round(dt * 1e3, 3), "value": round(n / dt, 1), "unit": "frames/s", "stage_ms": rows}
     return {"workload": f"the reference's other binaries / operating points, {args.contract_used} contract (secondary)", **out}
