@@ -1395,14 +1395,19 @@ hipError_t launch_patch_optimize(const DisArgs& a, hipStream_t s, const ofdis_tu
 struct FbCand {
   int gx, gy, pos0, pos1;
   float w0, w1, w2, w3, p0, p1;
+  int wbase;         // offset of the patch's first weight row within the frame's weights (ofdis_dev.h: pweight_row)
+  int L, Rr, T, Bt;  // valid source rectangle of the patch in patch coordinates (condition patchgrid.cpp:321)
 };
 
 // FB (forward-backward merging): a block is a 16 x 16 pixel TILE and a wavefront a 16 x 4 strip of it, so that the list a
 // pixel walks holds the complementary patches that reach its tile (~40) instead of every patch of its rows (~100 at level 3
 // of operating point 2, 3 000 at operating point 3) and a wavefront skips -- uniformly -- those that miss its strip: the
 // walk was 634 us per 512-pair level-3 launch against 25 us for the grid's own patches.
-template <bool PLANAR, bool FB>
+// FBN: 0 = no forward-backward merging, else the channel count of the complementary grid's weights (1 / 3: compile-time, so
+// that the gray walk does not carry the RGB running-pointer arithmetic)
+template <bool PLANAR, int FBN>
 __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
+  constexpr bool FB = FBN != 0;
   const LevelGeom& g = a.g;
   const int npx = g.w * g.h;
   const int tiles_x = (g.w + 15) / 16;
@@ -1450,6 +1455,7 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
     const int yw0 = yb0 + 4 * wave, yw1 = yw0 + 3;           // ... and rows of this wavefront's strip
     const float* cpf = a.cg_p + (size_t)frame * g.nop * 2;
     const float* cpwf = a.cg_pweight + (size_t)frame * g.nop * g.novals;
+    const int rowlen = P * noc, wstride = g.nopw * rowlen;  // floats per patch row / between two rows of one patch
     for (int base = 0; base < g.nop; base += 256) {
       const int ipc = base + threadIdx.x;
       FbCand c;
@@ -1469,6 +1475,12 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
         c.w1 = (1 - r0) * r1;
         c.w2 = r0 * (1 - r1);
         c.w3 = (1 - r0) * (1 - r1);
+        // (once per candidate instead of once per pixel and candidate)
+        c.wbase = (int)pweight_row(g, gx, gy, 0);
+        c.L = max(0, 1 - (c.pos0 + lb));
+        c.Rr = min(P - 1, g.w - 2 - (c.pos0 + lb));
+        c.T = max(0, 1 - (c.pos1 + lb));
+        c.Bt = min(P - 1, g.h - 2 - (c.pos1 + lb));
         // source rows ys = pos1 + lb .. pos1 + ub feed target rows ys - 1 and ys (columns likewise)
         hit = (c.pos1 + ub >= yb0) && (c.pos1 + lb - 1 <= yb1) && (c.pos0 + ub >= xb0) && (c.pos0 + lb - 1 <= xb1);
       }
@@ -1489,23 +1501,24 @@ __global__ __launch_bounds__(256) void densify_kernel(const DensifyArgs a) {
           const FbCand& cc = cand[k];
           if ((cc.pos1 + ub < yw0) | (cc.pos1 + lb - 1 > yw1)) continue;  // (wave-uniform) misses this strip's rows
           if (!active) continue;
-          // valid source rectangle of this patch in patch coordinates (condition patchgrid.cpp:321)
-          const int L = max(0, 1 - (cc.pos0 + lb)), Rr = min(P - 1, g.w - 2 - (cc.pos0 + lb));
-          const int T = max(0, 1 - (cc.pos1 + lb)), Bt = min(P - 1, g.h - 2 - (cc.pos1 + lb));
+          const int L = cc.L, Rr = cc.Rr, T = cc.T, Bt = cc.Bt;
           const int in_row = Rr - L + 1;
+          const int dx = x - cc.pos0 - lb, dy = y - cc.pos1 - lb;
+          const float* wrow = cpwf + cc.wbase;  // weight row r of this patch: wrow + r * wstride
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int kx = x + (q & 1) - cc.pos0 - lb, ky = y + (q >> 1) - cc.pos1 - lb;
+            const int kx = dx + (q & 1), ky = dy + (q >> 1);
             if (kx < L || kx > Rr || ky < T || ky > Bt) continue;
             const float wq = q == 0 ? cc.w0 : (q == 1 ? cc.w1 : (q == 2 ? cc.w2 : cc.w3));
             float absw;
-            if (noc == 1) {
-              absw = 1.0f / fmaxf(2.0f, cpwf[pweight_row(g, cc.gx, cc.gy, ky) + kx]);
+            if constexpr (FBN == 1) {
+              absw = 1.0f / fmaxf(2.0f, wrow[ky * wstride + kx]);
             } else {  // running pointer: +1 per visited pixel, +2 more per pixel that passed the condition
               const int pidx = ky * P + kx + 2 * ((ky - T) * in_row + (kx - L));
-              absw = fmaxf(2.0f, cpwf[pweight_entry(g, cc.gx, cc.gy, pidx)]);
-              absw += fmaxf(2.0f, cpwf[pweight_entry(g, cc.gx, cc.gy, pidx + 1)]);
-              absw += fmaxf(2.0f, cpwf[pweight_entry(g, cc.gx, cc.gy, pidx + 2)]);
+              auto wat = [&](int k) { const int r = k / rowlen; return wrow[r * wstride + (k - r * rowlen)]; };
+              absw = fmaxf(2.0f, wat(pidx));
+              absw += fmaxf(2.0f, wat(pidx + 1));
+              absw += fmaxf(2.0f, wat(pidx + 2));
               absw = 1.0f / absw;
             }
             we += wq * absw;
@@ -1639,10 +1652,15 @@ hipError_t launch_densify(const DensifyArgs& a_in, hipStream_t s) {
   const long long blocks = (long long)((a.nframes + 7) / 8) * 8 * blocks_per_frame;
   if (a.cg_p) {  // forward-backward merging: 16 x 16 pixel tiles
     const long long fblocks = (long long)((a.nframes + 7) / 8) * 8 * ((a.g.w + 15) / 16) * ((a.g.h + 15) / 16);
-    if (a.flow_aos) hipLaunchKernelGGL((densify_kernel<false, true>), dim3((unsigned)fblocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((densify_kernel<true, true>), dim3((unsigned)fblocks), dim3(256), 0, s, a);
-  } else if (a.flow_aos) hipLaunchKernelGGL((densify_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((densify_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (a.g.noc == 1) {
+      if (a.flow_aos) hipLaunchKernelGGL((densify_kernel<false, 1>), dim3((unsigned)fblocks), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((densify_kernel<true, 1>), dim3((unsigned)fblocks), dim3(256), 0, s, a);
+    } else {
+      if (a.flow_aos) hipLaunchKernelGGL((densify_kernel<false, 3>), dim3((unsigned)fblocks), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((densify_kernel<true, 3>), dim3((unsigned)fblocks), dim3(256), 0, s, a);
+    }
+  } else if (a.flow_aos) hipLaunchKernelGGL((densify_kernel<false, 0>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((densify_kernel<true, 0>), dim3((unsigned)blocks), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

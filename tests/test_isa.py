@@ -107,7 +107,7 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     ("tv_fused_tall_kernelILi3ELb1ELb1ELi1EE", 216, "tv_fused_tall_kernel<3, true, true> (heads + shared tail): two wavefronts per SIMD"),
     ("tv_fused_tall_kernelILi3ELb1ELb0ELi3EE", 256, "tv_fused_tall_kernel<3, true, false, 3>, RGB: two wavefronts per SIMD"),
     ("tv_fused_tall_kernelILi3ELb1ELb1ELi3EE", 256, "tv_fused_tall_kernel<3, true, true, 3>, RGB, heads + shared tail (eight wavefronts per workgroup: 256 registers at most)"),
-    ("densify_kernelILb1ELb0EE", 64, "densify_kernel<true, false>: eight wavefronts per SIMD"),
+    ("densify_kernelILb1ELi0EE", 64, "densify_kernel<true, 0>: eight wavefronts per SIMD"),
     ("densify_quad_kernel", 64, "densify_quad_kernel: eight wavefronts per SIMD"),
     ("tv_prep_kernelILi2ELb0EE", 84, "tv_prep_kernel<2, false> (two wavefronts per 128-column row): six wavefronts per SIMD by registers"),
     ("tv_prep_kernelILi1ELb0EE", 84, "tv_prep_kernel<1, false>: six wavefronts per SIMD by registers"),
