@@ -270,7 +270,9 @@ typedef struct ofdis_tuning {
                        * rows take the fused system + SOR kernels behind the TILED warp and derivatives kernels (the latter
                        * writing records; with fused_tv and finish_fusion) in contexts of at least this many frames: 0 = the
                        * library's choice (16 under the fused contract, 512 under the exact one: below it the
-                       * one-launch-per-stage kernels are as fast or faster), 1 = always, 2^30 = never
+                       * one-launch-per-stage kernels are as fast or faster), 1 = always, 2^30 = never.  The stereo-depth
+                       * mode's levels of <= 64 rows take their fused kernel (de_fused_kernel) by the same knob; its own
+                       * defaults: always under the fused contract, from 256 frames under the exact one
                        *                                                                            OFDIS_FUSED_RGB_MIN */
 } ofdis_tuning;
 int ofdis_get_tuning(ofdis_tuning* out);

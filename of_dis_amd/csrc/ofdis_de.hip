@@ -8,6 +8,7 @@
 // anti-diagonal wavefront and sweep pipelining as ofdis_sor.hip; the system kernel is tiled like tv_system_kernel.
 #include "ofdis_kernels.h"
 #include "ofdis_tvmath.h"
+#include "ofdis_fused.h"
 
 namespace ofdis {
 namespace OFDIS_KNS {  // the arithmetic contract this file is being compiled for (ofdis_dev.h)
@@ -443,6 +444,237 @@ hipError_t launch_de_sor(const DeSorArgs& a, hipStream_t s) {
     }
     left -= ns;
   }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ fused stereo refinement
+// Every fixed-point iteration of a stereo level of at most 64 rows in ONE launch: the scheme of tv_fused_kernel's throughput
+// mapping (ofdis_fused.hip: lane = row, one anti-diagonal per step, the system of a pixel assembled in registers one step
+// before the pipelined solver sweeps consume it, the iterations of a frame back to back as n_inner * w columns) with one
+// unknown per pixel:
+//   * records in: the derivative records of derivatives_kernel's record form (NOC arrays) and the (wx, 0) records;
+//   * uu = wx in the first iteration, min | max (wx + du, 0) by camera side after it (refine_variational.cpp:283, 299-316);
+//     the smoothness weight is compute_smoothness with vv == 0 (its terms are exact zeros);
+//   * the data term is the flow mode's with v == 0 (compute_data_DE, opticalflow_aux.c:446-548, is compute_data without the
+//     second unknown: data_term_gray / data_term_rgb, a11 and b1 of them), the Laplacian of wx in its scatter order;
+//   * the solver is sor_coupled_slow_but_readable_DE's update (solver.c:436-456) with zero edge weights standing for the
+//     absent neighbours (the sums start at +0 and never become -0: adding or subtracting +-0 x finite changes no bit);
+//   * du goes back to its diag plane (the next iteration of the same wavefront reads it w columns later; de_update forms the
+//     clamped result).
+// n_inner x (de_system + de_sor) become one kernel: the derivative records are read once per iteration, nothing else moves.
+struct DeFRow {
+  float wx, du;
+  bool first;  // the pixel is in its first fixed-point iteration (or past the last): du == 0 and uu = wx, unclamped
+};
+struct DeFSlot {
+  float a11, b1, sh, sv, dur, hl, vt;
+};
+
+template <int NS, bool BRIGHT, int NOC>
+__global__ __launch_bounds__(256) void de_fused_kernel(const DeFusedArgs a, const int R) {
+  constexpr int U = 6, PDW = 5, PDD = NOC == 3 ? 2 : 3;
+  static_assert(2 * (NS - 1) + 1 < U, "slot ring too small for this many pipelined sweeps");
+  const int w = a.t.w, h = a.t.h;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int G = 64 / R;  // frames per wavefront
+  const int s0 = wid * G;
+  if (s0 >= a.t.nframes) return;
+  int fl = lane / R;
+  const int jr = lane % R;
+  const bool row_ok = (s0 + fl < a.t.nframes) && (jr < h);
+  if (s0 + fl >= a.t.nframes) fl = a.t.nframes - 1 - s0;
+  const int j = jr < h ? jr : h - 1;
+  const bool has_top = j > 0, has_bot = j < h - 1;
+  const float omega = a.omega, qa = a.quarter_alpha, hd3 = a.half_delta_over3, hg3 = a.half_gamma_over3;
+  const int camlr = a.camlr;
+  const int nst = min(G, a.t.nframes - s0);
+  const size_t recs = (size_t)w * h;  // records of a frame
+  auto rsrc = [&](const float* base, int rec_floats) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)s0 * recs * rec_floats), 0, (int)(nst * recs * rec_floats * 4),
+                                             0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsW = rsrc(a.wrec, 2), rsU = rsrc(a.du, 1), rsD = rsrc(a.d8, 8);
+  const __amdgpu_buffer_rsrc_t rsD1 = rsrc(a.d8 + (NOC == 3 ? (size_t)a.t.nframes * recs * 8 : 0), 8);
+  const __amdgpu_buffer_rsrc_t rsD2 = rsrc(a.d8 + (NOC == 3 ? (size_t)a.t.nframes * recs * 16 : 0), 8);
+  const int vrec = fl * (int)recs + j;
+  const int vo8 = vrec * 32, vo2 = vrec * 8, vo1 = vrec * 4;
+  auto asf = [](unsigned u) { return __builtin_bit_cast(float, u); };
+
+  DeFRow W[6];
+  FDer D[PDD][NOC];
+  float uu[3], sm[3];
+  DeFSlot slot[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) { W[r] = DeFRow{0, 0, true}; slot[r] = DeFSlot{1, 0, 1, 1, 0, 0, 0}; }  // (finite fill-phase systems)
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { uu[r] = 0.0f; sm[r] = 1.0f; }
+#pragma unroll
+  for (int r = 0; r < PDD; ++r)
+#pragma unroll
+    for (int c = 0; c < NOC; ++c) D[r][c] = FDer{0, 0, 0, 0, 0, 0, 0, 0};
+  float ru[NS], ru2[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) ru[s] = ru2[s] = 0.0f;
+  float ldx = 0.0f;
+
+  auto wrap_row = [&](int r) { r %= w; return r < 0 ? r + w : r; };
+  auto next_row = [&](int r) { return (r + 1 == w) ? 0 : r + 1; };
+  // zero: no memory request for du (an offset beyond the resource reads +0): first iteration, or past the last one
+  auto load_w = [&](DeFRow& r, int drow, bool zero) {
+    r.wx = asf(__builtin_amdgcn_raw_buffer_load_b32(rsW, vo2, drow * h * 8, 0));
+    r.du = asf(__builtin_amdgcn_raw_buffer_load_b32(rsU, zero ? 0x7ffffff0 : vo1, drow * h * 4, 0));
+    r.first = zero;
+  };
+  auto load_d1 = [&](FDer& r, const __amdgpu_buffer_rsrc_t& rs, int o) {
+    const auto lo = __builtin_amdgcn_raw_buffer_load_b128(rs, vo8, o, 0);
+    const auto hi = __builtin_amdgcn_raw_buffer_load_b128(rs, vo8 + 16, o, 0);
+    const unsigned l0 = lo[0], l1 = lo[1], l2 = lo[2], l3 = lo[3], h0 = hi[0], h1 = hi[1], h2 = hi[2], h3 = hi[3];
+    r.ix = asf(l0); r.iz = asf(l1); r.ixx = asf(l2); r.ixz = asf(l3);
+    r.iy = asf(h0); r.ixy = asf(h1); r.iyz = asf(h2); r.iyy = asf(h3);
+  };
+  auto load_d = [&](FDer (&r)[NOC], int drow) {
+    const int o = drow * h * 32;
+    load_d1(r[0], rsD, o);
+    if constexpr (NOC == 3) {
+      load_d1(r[1], rsD1, o);
+      load_d1(r[2], rsD2, o);
+    }
+  };
+  // ring index of diag row rho is (rho + 3) mod ring size; loop variable k = t + 3, u = k % 6: row t + c at index (u + c) % size
+  load_w(W[2], wrap_row(-1), true);
+  load_w(W[3], wrap_row(0), true);
+  load_w(W[4], wrap_row(1), true);
+  int rowW = wrap_row(PDW - 3), rowD = wrap_row(PDD - 3);
+  int srow = wrap_row(-3 - 2 * (NS - 1));  // row the last sweep finishes at step t = -3
+  auto wrap_col = [&](int c) { c %= w; return c < 0 ? c + w : c; };
+  int x2 = wrap_col(-1 - j);                    // this lane's x on diag row t + 2
+  bool x1_last = (wrap_col(-2 - j) == w - 1);   // row t + 1 is the last column
+  const int wtot = a.n_inner * w;
+  const int tend = (wtot - 1) + (h - 1) + 2 * (NS - 1);
+  int ig = -3 - j - 2 * (NS - 1);  // column (over all iterations) the last sweep finishes at step t
+  bool first_w = true;
+  for (int k0 = 0; k0 <= tend + 3; k0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // ---- (1) loads: wx / du row t + 5, derivative row t + PDD
+      load_w(W[(u + PDW) % 6], rowW, first_w);
+      rowW = next_row(rowW);
+      load_d(D[(u + PDD) % PDD], rowD);
+      rowD = next_row(rowD);
+      // ---- (2) uu of row t + 3
+      {
+        const DeFRow& r = W[(u + 3) % 6];
+        const float v = r.wx + r.du;
+        const float cl = camlr == 0 ? (v < 0.0f ? v : 0.0f) : (v > 0.0f ? v : 0.0f);  // minps / maxps (x, 0): 0 for a NaN
+        uu[u % 3] = r.first ? v : cl;
+      }
+      // ---- (3) smoothness of row t + 2 (opticalflow_aux.c:128-140 with vv == 0; see tv_fused_kernel for the scaling)
+      const bool x2_last = (x2 == w - 1);
+      {
+        const float uc = uu[(u + 2) % 3];
+        float ul = uu[(u + 1) % 3], ur = uu[u % 3];
+        float ut = wave_from_prev(uu[(u + 1) % 3]), ub = wave_from_next(uu[u % 3]);
+        if (x2 == 0) ul = uc;
+        if (x2_last) ur = uc;
+        if (!has_top) ut = uc;
+        if (!has_bot) ub = uc;
+        const float ex = ur - ul, ey = ub - ut;
+        sm[(u + 2) % 3] = fdiv_by_sqrt(qa, 0.25f * (ex * ex + ey * ey) + EPS_SMOOTH);
+      }
+      // ---- (4) system of the pixel on row t + 1
+      {
+        const float sc = sm[(u + 1) % 3], s_r = sm[(u + 2) % 3], s_d = wave_from_next(sm[(u + 2) % 3]);
+        const float sh_c = x1_last ? 0.0f : sc + s_r;
+        const float sv_c = has_bot ? sc + s_d : 0.0f;
+        const DeFRow& rc = W[(u + 1) % 6];
+        const DeFRow& rm = W[u % 6];
+        const DeFRow& rp = W[(u + 2) % 6];
+        float a11, a12, a22, b1, b2;
+        if constexpr (NOC == 1) data_term_gray<BRIGHT>(D[(u + 1) % PDD][0], rc.du, 0.0f, hd3, hg3, a11, a12, a22, b1, b2);
+        else data_term_rgb<BRIGHT>(D[(u + 1) % PDD], rc.du, 0.0f, hd3, hg3, a11, a12, a22, b1, b2);
+        const float wx_u = wave_from_prev(rm.wx), wx_d = wave_from_next(rp.wx);
+        const float sh_l = slot[u % 6].sh;
+        const float sv_t = wave_from_prev(slot[u % 6].sv);
+        const float rdx = rp.wx - rc.wx;
+        b1 -= sh_l * ldx;
+        b1 += sh_c * rdx;
+        ldx = rdx;
+        b1 -= sv_t * (rc.wx - wx_u);
+        b1 += sv_c * (wx_d - rc.wx);
+        DeFSlot& o = slot[(u + 1) % 6];
+        o.a11 = a11; o.b1 = b1; o.sh = sh_c; o.sv = sv_c; o.dur = rp.du; o.hl = sh_l; o.vt = sv_t;
+      }
+      x1_last = x2_last;
+      x2 = x2_last ? 0 : x2 + 1;
+      // ---- (5) solver step t: sweep s is at column t - j - 2 s (solver.c:436-456)
+      float nu[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const DeFSlot& c = slot[(u - 2 * s + 12) % 6];
+        float own, right, bottom;
+        if (s == 0) {
+          const DeFSlot& p = slot[(u + 5) % 6];
+          own = p.dur;
+          right = c.dur;
+          bottom = wave_from_next(c.dur);
+        } else {
+          own = ru2[s - 1];
+          right = ru[s - 1];
+          bottom = wave_from_next(ru[s - 1]);
+        }
+        const float top = wave_from_prev(ru[s]);
+        const float left = ru[s];
+        float sigma = 0.0f, sum = 0.0f;
+        sigma -= c.vt * top;    sum += c.vt;
+        sigma -= c.hl * left;   sum += c.hl;
+        sigma -= c.sv * bottom; sum += c.sv;
+        sigma -= c.sh * right;  sum += c.sh;
+        const float A11 = c.a11 + sum;
+        const float B1 = c.b1 - sigma;
+        nu[s] = (1.0f - omega) * own + omega * fdiv_rn(B1, A11);
+      }
+      {
+        const int cw = ig + (PDW + 1 + 2 * (NS - 1));
+        first_w = (cw < w) | (cw >= wtot);  // for the next step's row
+        const bool on = row_ok & (ig >= 0) & (ig < wtot);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nu[NS - 1]), rsU, on ? vo1 : 0x7ffffff0, srow * h * 4, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        ru2[s] = ru[s];
+        ru[s] = nu[s];
+      }
+      srow = next_row(srow);
+      ++ig;
+    }
+  }
+}
+
+bool de_fused_supported(const TvGeom& t, int iterations) {
+  return (t.noc == 1 || t.noc == 3) && t.h >= 4 && t.h <= 64 && t.w >= 16 && iterations >= 1 && iterations <= 3;
+}
+
+hipError_t launch_de_fused(const DeFusedArgs& a, hipStream_t s) {
+  if (!de_fused_supported(a.t, a.iterations) || a.n_inner < 1 || !tv_fused_params_ok(a.quarter_alpha, a.half_delta_over3, a.half_gamma_over3))
+    return hipErrorInvalidValue;
+  const int h = a.t.h;
+  const int R = h <= 16 ? 16 : (h <= 32 ? 32 : 64);
+  const int waves = (a.t.nframes + 64 / R - 1) / (64 / R);
+  const dim3 g((waves + 3) / 4), b(256);
+  const bool bright = a.half_delta_over3 != 0.0f;
+#define OFDIS_DE_FUSED(NS, NOC)                                                                  \
+  if (bright) hipLaunchKernelGGL((de_fused_kernel<NS, true, NOC>), g, b, 0, s, a, R);            \
+  else hipLaunchKernelGGL((de_fused_kernel<NS, false, NOC>), g, b, 0, s, a, R)
+#define OFDIS_DE_FUSED_NS(NOC)                                                                   \
+  switch (a.iterations) {                                                                        \
+    case 1: OFDIS_DE_FUSED(1, NOC); break;                                                       \
+    case 2: OFDIS_DE_FUSED(2, NOC); break;                                                       \
+    default: OFDIS_DE_FUSED(3, NOC); break;                                                      \
+  }
+  if (a.t.noc == 3) { OFDIS_DE_FUSED_NS(3) } else { OFDIS_DE_FUSED_NS(1) }
+#undef OFDIS_DE_FUSED_NS
+#undef OFDIS_DE_FUSED
   return hipGetLastError();
 }
 

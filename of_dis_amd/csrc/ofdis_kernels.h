@@ -195,6 +195,19 @@ struct DeSorArgs {
   int iterations;
   float omega;
 };
+// All fixed-point iterations of a stereo level in one launch (de_fused_kernel, ofdis_de.hip: levels of <= 64 rows): the record
+// arrays of the derivatives kernel in, du out (diag plane; never read during the first iteration)
+struct DeFusedArgs {
+  TvGeom t;
+  const float* d8;    // [noc][B][w*h][8] derivative records (zero where the warp's mask is zero)
+  const float* wrec;  // [B][w*h][2]: wx (and wy = 0)
+  float* du;          // [B][w*h] diag
+  float quarter_alpha, half_delta_over3, half_gamma_over3;
+  int iterations;     // solver sweeps per fixed-point iteration
+  float omega;
+  int n_inner;
+  int camlr;          // 0: left camera (uu = min(wx + du, 0)), 1: right (max)
+};
 
 namespace exact {
 #include "ofdis_launchers.inc"

@@ -10,6 +10,16 @@ from common import assert_bits_equal, rand_planes, synth_case
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["per-stage kernels", "fused stereo kernel"])
+def stereo_tv(gpu, request):
+    """Every test of this file twice: with the refinement on de_system + de_sor per fixed-point iteration (what exact-contract
+    contexts of fewer than 256 frames run by default) and with levels of at most 64 rows forced onto de_fused_kernel (all
+    iterations in one launch; ofdis_tuning.fused_rgb_min = 1)."""
+    old = gpu.set_tuning(fused_rgb_min=1 if request.param.startswith("fused") else (1 << 30))
+    yield request.param
+    gpu.restore_tuning(old)
+
+
 def _case(w, h, seed, noc, opp, tv):
     p, pa, pb, _, _ = synth_case(w, h, seed, noc, opp, tv)
     p = p.copy(selectmode=2)
