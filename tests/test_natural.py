@@ -119,6 +119,13 @@ def test_gpu_on_natural_pairs(gpu, name, noc, opp, mode):
     got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
     assert_bits_equal(got, ref, f"'{name}' {w}x{h} noc={noc} op{opp} mode {mode}: HIP vs reference build")
     check_accuracy(name, opp, p, got, truth, w, h)
+    if mode == 2 or noc == 3 or opp == 3:  # ... and on the kernels larger contexts take: every fixed-point iteration of a
+        old = gpu.set_tuning(fused_rgb_min=1)  # stereo / RGB / wide gray level in one launch (forced for this one pair)
+        try:
+            forced = gpu.flow(p, pa[0], pa[1], pa[2], pb[0])
+        finally:
+            gpu.restore_tuning(old)
+        assert_bits_equal(forced, ref, f"'{name}' noc={noc} op{opp} mode {mode}: fused refinement kernels forced")
     plain = _ref(noc, mode, False).flow(p, pa[0], pa[1], pa[2], pb[0])
     old = gpu.set_tuning(contract=1)
     try:
