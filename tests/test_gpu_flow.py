@@ -503,6 +503,13 @@ def test_random_configurations_modes(gpu, seed):
     ref = oracle.ref(kind, True).flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
     got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
     assert_bits_equal(got, ref, f"seed {seed}: {w}x{h} noc={noc} {over}")
+    if p.usetvref and (stereo or noc == 3):  # ... and with the one-launch refinement kernels of larger contexts forced
+        old = gpu.set_tuning(fused_rgb_min=1)
+        try:
+            got = gpu.flow(p, pa[0], pa[1], pa[2], pb[0], pyr_b_dx=pb[1], pyr_b_dy=pb[2])
+        finally:
+            gpu.restore_tuning(old)
+        assert_bits_equal(got, ref, f"seed {seed}: {w}x{h} noc={noc} fused refinement kernels forced, {over}")
 
 
 @pytest.mark.parametrize("seed", range(8))
